@@ -1,0 +1,130 @@
+"""Oracle (oracle/ref_torch.py) vs fixtures generated from the imported reference.  CPU only."""
+import torch
+
+from conftest import load_golden, rel_l1, state_dict_from
+from oracle import ref_torch as R
+
+torch.set_num_threads(4)
+ATOL_VOL = 1e-5  # variance / warped volumes: abs 1e-5 + rel 1e-4 (SURVEY 8(c) caveat iii)
+
+
+def close(a, b, atol=ATOL_VOL, rtol=1e-4):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    assert bool((err <= atol + rtol * b.abs()).all()), "max err %g" % float(err.detach().max())
+
+
+def test_g1_homo_warping():
+    for tag in "ab":
+        g = load_golden("g1_homo_warping_" + tag)
+        src = g["src_fea"].clone().requires_grad_(True)
+        out = R.homo_warping(src, g["src_proj"], g["ref_proj"], g["depth_values"])
+        close(out, g["out"])
+        out.backward(g["grad_out"])
+        close(src.grad, g["grad_src"], atol=1e-4)
+        assert float((g["out"] == 0).float().mean()) > 0.02  # fixture exercises out-of-image samples
+
+
+def test_g3_proj_cost_and_ms_warp():
+    g = load_golden("g3_proj_cost")
+    ref = g["ref_fea"].clone().requires_grad_(True)
+    srcs = [g["src_fea0"].clone().requires_grad_(True), g["src_fea1"].clone().requires_grad_(True)]
+    cost = R.proj_cost(2, ref, srcs, g["ref_in"], g["src_in"], g["ref_ex"], g["src_ex"], g["hypos"])
+    close(cost, g["cost"], atol=1e-4)
+    cost.backward(g["grad_out"])
+    close(ref.grad, g["grad_ref"], atol=2e-3, rtol=1e-3)
+    close(srcs[0].grad, g["grad_src0"], atol=2e-3, rtol=1e-3)
+    close(srcs[1].grad, g["grad_src1"], atol=2e-3, rtol=1e-3)
+    w = R.homo_warping_ms(g["src_fea0"], g["ref_in"], g["src_in"][:, 0], g["ref_ex"], g["src_ex"][:, 0], g["planes"])
+    close(w, g["warped_ms"])
+
+
+def _check_regnet(g, net, has_second):
+    net.load_state_dict(state_dict_from(g))
+    net.train()
+    x = g["x"].clone().requires_grad_(True)
+    y = net(x)
+    y = y if y.dim() == g["y_train"].dim() else y.unsqueeze(1)
+    close(y, g["y_train"], atol=2e-4, rtol=1e-3)
+    y.backward(g["grad_out"].view_as(y))
+    close(x.grad, g["grad_x"], atol=1e-3, rtol=2e-2)
+    for k, p in net.named_parameters():
+        ref = g["grad." + k]
+        assert rel_l1(p.grad, ref) < 2e-3, k
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith("after1.") and "num_batches" not in k:
+            close(sd[k[7:]], v, atol=1e-5, rtol=1e-4)
+    if has_second:
+        with torch.no_grad():
+            net(g["x2"])
+    net.eval()
+    with torch.no_grad():
+        ye = net(g["x"])
+    ye = ye if ye.dim() == g["y_eval"].dim() else ye.unsqueeze(1)
+    close(ye, g["y_eval"], atol=2e-4, rtol=1e-3)
+
+
+def test_g4_costregnet_mvs():
+    _check_regnet(load_golden("g4_costregnet_mvs"), R.OracleCostRegNet(), True)
+
+
+def test_g4_costregnet_cvp():
+    _check_regnet(load_golden("g4_costregnet_cvp"), R.OracleCostRegNetMS(), False)
+
+
+def test_g5_softargmin():
+    g = load_golden("g5_softargmin")
+    lg = g["logits"].clone().requires_grad_(True)
+    depth, conf, _ = R.softargmin_conf(lg, g["depth_values"])
+    close(depth, g["depth"], atol=1e-3, rtol=1e-6)
+    close(conf, g["conf"], atol=1e-6)
+    depth.backward(g["grad_depth"])
+    close(lg.grad, g["grad_logits"], atol=1e-4, rtol=1e-4)
+
+
+def test_g6_mvsnet_end_to_end():
+    g = load_golden("g6_mvsnet_e2e")
+    net = R.OracleMVSNet(refine=False)
+    net.load_state_dict(state_dict_from(g))
+    net.train()
+    out = net(g["imgs"], g["proj"], g["depth_values"], return_intermediates=True)
+    close(out["variance"], g["train_variance"])
+    close(out["logits"].unsqueeze(1), g["train_logits"], atol=1e-3, rtol=1e-3)
+    assert rel_l1(out["depth"], g["train_depth"]) < 1e-5
+    assert float(g["train_depth"].std()) > 1.0  # non-degenerate golden (SURVEY 8(c) caveat ii)
+    close(out["photometric_confidence"], g["train_conf"], atol=1e-4)
+    wts = torch.linspace(0.5, 1.5, out["depth"].numel()).view_as(out["depth"])
+    (out["depth"] * wts).mean().backward()
+    for k, p in net.named_parameters():
+        if k.endswith("prob.bias"):  # softmax is shift invariant: true gradient is 0, value is roundoff
+            assert float(p.grad.abs().max()) < 1e-4
+            continue
+        assert rel_l1(p.grad.detach(), g["grad." + k]) < 5e-3, k
+    # eval with the fixture's calibrated running stats
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith("cal."):
+            sd[k[4:]] = v
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        oe = net(g["imgs"], g["proj"], g["depth_values"], return_intermediates=True)
+    close(oe["variance"], g["eval_variance"])
+    assert rel_l1(oe["depth"], g["eval_depth"]) < 1e-5
+    close(oe["photometric_confidence"], g["eval_conf"], atol=1e-4)
+
+
+def test_g7_cvpmvsnet_end_to_end():
+    g = load_golden("g7_cvpmvsnet_e2e")
+    net = R.OracleCVPMVSNet(R.cvp_args(nsrc=2, nscale=2, mode="train"))
+    net.load_state_dict(state_dict_from(g), strict=False)
+    net.train()
+    with torch.no_grad():
+        out = net(g["ref_img"], g["src_imgs"], g["ref_in"], g["src_in"], g["ref_ex"], g["src_ex"],
+                  g["depth_min"], g["depth_max"])
+        hyp = R.cal_depth_hypo(g["depth_up"], g["ref_in"], g["src_in"], g["ref_ex"], g["src_ex"])
+    close(hyp, g["hypos0"], atol=1e-3, rtol=1e-6)
+    assert rel_l1(out["depth_est_list"][1], g["depth1"]) < 1e-5
+    assert rel_l1(out["depth_est_list"][0], g["depth0"]) < 1e-4
+    close(out["prob_confidence"], g["conf"], atol=1e-3)
