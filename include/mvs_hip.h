@@ -1,0 +1,135 @@
+/* mvs_hip.h -- C ABI of libmvs_hip.so: the MI355X (gfx950) hot path of Self-Supervised-MVS.
+ *
+ * The reference (ToughStoneX/Self-Supervised-MVS) has NO native boundary on this path: the path is
+ * a sequence of ATen calls inside two nn.Module.forward()s.  Each entry point below therefore cites
+ * the reference Python it replaces (paths relative to the reference root); INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (e.g. PyTorch's caching allocator); the
+ *    library never allocates, frees or retains them.  Outputs are fully overwritten unless stated.
+ *  - Work is enqueued on `stream` only; no call synchronises the device.  Re-entrant: no global
+ *    mutable state (the last-error string is thread local).
+ *  - fp32 everywhere.  Feature maps are channels-last [B,H,W,C]; volumes channels-last [B,D,H,W,C]
+ *    (== torch.channels_last / torch.channels_last_3d memory formats of NCHW / NCDHW tensors).
+ *  - Return value: 0 on success, negative on error (MVS_ERR_*), message via mvs_last_error().
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t; /* same opaque type as <hip/hip_runtime_api.h> */
+#endif
+
+#define MVS_OK 0
+#define MVS_ERR_SHAPE (-1)
+#define MVS_ERR_UNSUPPORTED (-2)
+#define MVS_ERR_LAUNCH (-3)
+#define MVS_ERR_NULL (-4)
+#define MVS_MAX_SRC 10
+
+int mvs_version(void);              /* 100 == 0.1.0 */
+const char* mvs_last_error(void);   /* thread-local, valid until the next failing call */
+int mvs_is_emulation(void);         /* 0 in the product library */
+
+/* ---- K1/K2: homography warp + variance cost volume -------------------------------------------
+ * Replaces homo_warping + the sum / sum-of-squares / variance chain:
+ *   jdacs/models/module.py:105-140 (homo_warping), jdacs/models/mvsnet.py:120-136 (variance);
+ *   jdacs-ms/models/modules.py:62-104 (homo_warping), :209-261 (proj_cost, per-pixel hypotheses),
+ *   jdacs-ms/models/network.py:114-137 (coarse variance, in-place alias quirk => ms_alias=1).
+ * ref, srcs[i]: [B,H,W,C] (N-1 source pointers, HOST array of device pointers); rot [B,N-1,9] and
+ * trans [B,N-1,3] are rot=proj[:3,:3], trans=proj[:3,3] of src_proj @ inverse(ref_proj)
+ * (module.py:116-118), computed by the caller.  depth: [B,D] or, if depth_is_per_pixel, [B,D,H,W].
+ * align_corners: 0 = what F.grid_sample does on torch>=1.3 for the reference's call (default),
+ * 1 = torch 1.1 behaviour.  C in {8,16,32}.  var_out: [B,D,H,W,C]. */
+int mvs_plane_sweep_variance_fwd(const float* ref, const float* const* srcs, const float* rot, const float* trans,
+                                 const float* depth, int depth_is_per_pixel, int B, int N, int C, int D, int H,
+                                 int W, int align_corners, int ms_alias, float* var_out, hipStream_t stream);
+/* Backward of the above w.r.t. the feature maps (the reference builds the sampling grid under
+ * no_grad, module.py:115).  grad_ref and grad_srcs[i] ([B,H,W,C]) must be ZERO-FILLED by the caller
+ * (accumulated with atomics). */
+int mvs_plane_sweep_variance_bwd(const float* grad_var, const float* ref, const float* const* srcs,
+                                 const float* rot, const float* trans, const float* depth, int depth_is_per_pixel,
+                                 int B, int N, int C, int D, int H, int W, int align_corners, int ms_alias,
+                                 float* grad_ref, float* const* grad_srcs, hipStream_t stream);
+
+/* homo_warping alone (jdacs/models/module.py:105-140): warped volume [B,D,H,W,C] of ONE source view
+ * and its backward (grad_src zero-filled by the caller). */
+int mvs_homo_warp_fwd(const float* src, const float* rot, const float* trans, const float* depth,
+                      int depth_is_per_pixel, int B, int C, int D, int H, int W, int align_corners,
+                      float* warped_out, hipStream_t stream);
+int mvs_homo_warp_bwd(const float* grad_warped, const float* src, const float* rot, const float* trans,
+                      const float* depth, int depth_is_per_pixel, int B, int C, int D, int H, int W,
+                      int align_corners, float* grad_src, hipStream_t stream);
+
+/* ---- K3-K8: 3-D convolutions of CostRegNet ------------------------------------------------------
+ * Replace nn.Conv3d / nn.ConvTranspose3d (k=3, pad=1, bias=False; stride 1|2; transposed stride 2
+ * has output_padding 1, stride 1 has 0) forward / input-gradient / weight-gradient:
+ *   jdacs/models/module.py:35-42, jdacs/models/mvsnet.py:40-63; jdacs-ms/models/network.py:47-65.
+ * (D,H,W) are ALWAYS the spatial dims of the forward op's input x.  Weights are the PyTorch
+ * parameter tensors as they are: conv [Cout][Cin][3][3][3], transposed conv [Cin][Cout][3][3][3].
+ * ws: workspace of mvs_conv3d_workspace_bytes(op,...) bytes, 16-byte aligned.
+ * Forward epilogue (any subset): scale&&shift -> y*scale[c]+shift[c] (folded eval BatchNorm);
+ * shift only -> y+shift[c] (bias of the prob layer, mvsnet.py:63); relu; + skip (added AFTER the
+ * ReLU, mvsnet.py:70-72); stat_partials != NULL -> also writes [rows][2][Cout] partial sums
+ * (sum, sum of squares) of the RAW conv output for train-mode BatchNorm, rows = mvs_conv3d_stat_rows. */
+enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
+       MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
+long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int W, int Cin, int Cout, int stride);
+int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int stride);
+int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin, int Cout,
+                   int stride, const float* scale, const float* shift, const float* skip, int relu,
+                   float* stat_partials, hipStream_t stream);
+int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W, int Cin,
+                     int Cout, int stride, hipStream_t stream);
+int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
+                     int Cout, int stride, hipStream_t stream);
+int mvs_convT3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin,
+                    int Cout, int stride, const float* scale, const float* shift, const float* skip, int relu,
+                    float* stat_partials, hipStream_t stream);
+int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W, int Cin,
+                      int Cout, int stride, hipStream_t stream);
+int mvs_convT3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
+                      int Cout, int stride, hipStream_t stream);
+
+/* ---- BatchNorm3d (+ReLU, + post-ReLU skip add) on channels-last [V][C], V = B*D*H*W ------------
+ * Replace nn.BatchNorm3d + F.relu of ConvBnReLU3D (module.py:35-42) and of the deconv blocks
+ * (mvsnet.py:48-61).  C in {4,8,16,32,64}. */
+int mvs_bn_reduce_blocks(void);   /* max rows mvs_bn_stats writes (1024) */
+int mvs_bn_stats(const float* x, long long V, int C, float* partials, int* nparts_out, hipStream_t stream);
+/* partials [nparts][2][C] -> mean, invstd (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale;
+ * running stats (may be NULL) updated with `momentum` and the unbiased variance (PyTorch defaults). */
+int mvs_bn_finalize(const float* partials, int nparts, int C, long long count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                    float* scale, float* shift, hipStream_t stream);
+int mvs_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, hipStream_t stream);
+/* y = relu?(x*scale+shift) (+ skip) */
+int mvs_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, int relu, long long V,
+                    int C, float* y, hipStream_t stream);
+/* dy = grad w.r.t. relu(bn(x)); ws >= (1024*2*C + 2*C) floats; outputs dx [V][C], dgamma [C], dbeta [C] */
+int mvs_bn_relu_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* scale,
+                    const float* shift, int relu, long long V, int C, float* ws, float* dx, float* dgamma,
+                    float* dbeta, hipStream_t stream);
+
+/* ---- K9/K10: softmax over depth + soft-argmin regression + photometric confidence --------------
+ * Replace F.softmax(dim=1) + depth_regression + the pad/avg_pool3d/gather confidence:
+ *   jdacs/models/mvsnet.py:141-151, jdacs/models/module.py:145-148;
+ *   jdacs-ms/models/network.py:147-149,173-189, jdacs-ms/models/modules.py:324-331.
+ * logits [B,D,H,W]; depth [B,D] or [B,D,H,W]; outputs [B,H,W].  save_max/save_sum (may be NULL in
+ * inference) are the per-pixel softmax max and denominator the backward needs. */
+int mvs_softargmin_conf_fwd(const float* logits, const float* depth, int depth_is_per_pixel, int B, int D, int H,
+                            int W, float* out_depth, float* out_conf, float* save_max, float* save_sum,
+                            hipStream_t stream);
+int mvs_softargmin_conf_bwd(const float* grad_depth, const float* logits, const float* depth, int depth_is_per_pixel,
+                            const float* out_depth, const float* save_max, const float* save_sum, int B, int D, int H,
+                            int W, float* grad_logits, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

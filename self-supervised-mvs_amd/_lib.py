@@ -1,0 +1,87 @@
+"""ctypes binding of libmvs_hip.so (C ABI declared in include/mvs_hip.h).
+
+The product has NO fallback: if the HIP library is missing or fails to load, ``get()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
+
+_f = C.c_void_p      # float* (device pointer)
+_i = C.c_int
+_ll = C.c_longlong
+_s = C.c_void_p      # hipStream_t
+_fl = C.c_float
+
+# name -> (restype, argtypes); every symbol include/mvs_hip.h declares
+SIGNATURES = {
+    "mvs_version": (_i, []),
+    "mvs_last_error": (C.c_char_p, []),
+    "mvs_is_emulation": (_i, []),
+    "mvs_plane_sweep_variance_fwd": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
+    "mvs_plane_sweep_variance_bwd": (_i, [_f, _f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                          _f, C.POINTER(C.c_void_p), _s]),
+    "mvs_homo_warp_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
+    "mvs_homo_warp_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
+    "mvs_conv3d_workspace_bytes": (_ll, [_i] * 8),
+    "mvs_conv3d_stat_rows": (_i, [_i] * 6),
+    "mvs_conv3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
+    "mvs_conv3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_convT3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
+    "mvs_convT3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_convT3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_bn_reduce_blocks": (_i, []),
+    "mvs_bn_stats": (_i, [_f, _ll, _i, _f, C.POINTER(_i), _s]),
+    "mvs_bn_finalize": (_i, [_f, _i, _i, _ll, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _s]),
+    "mvs_bn_eval_affine": (_i, [_f, _f, _f, _f, _fl, _i, _f, _f, _s]),
+    "mvs_bn_relu_fwd": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _s]),
+    "mvs_bn_relu_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f, _f, _f, _s]),
+    "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
+    "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
+}
+
+OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD = range(6)
+
+
+class MvsLib:
+    """Loaded library + checked calls.  ``device_type`` is the torch device type whose pointers the
+    library accepts ("cuda" for the product)."""
+
+    def __init__(self, path: str = LIB_PATH, device_type: str = "cuda"):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "libmvs_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU / PyTorch fallback for the hot path" % path)
+        self.path = path
+        self.device_type = device_type
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+
+    def call(self, name: str, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if rc != 0:
+            msg = self._mvs_last_error().decode("utf-8", "replace")
+            if rc in (-1, -2, -4):
+                raise ValueError("%s failed (%d): %s" % (name, rc, msg))
+            raise RuntimeError("%s failed (%d): %s" % (name, rc, msg))
+
+    def raw(self, name: str, *args):
+        return getattr(self, "_" + name)(*args)
+
+
+_INSTANCE = None
+
+
+def get() -> MvsLib:
+    global _INSTANCE
+    if _INSTANCE is None:
+        _INSTANCE = MvsLib()
+    return _INSTANCE

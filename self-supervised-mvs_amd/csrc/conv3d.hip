@@ -1,0 +1,628 @@
+// K3-K8: 3-D convolution family of the cost-volume regulariser as fp32 MFMA implicit GEMMs.
+//
+// Replaces nn.Conv3d / nn.ConvTranspose3d forward, input-gradient and weight-gradient of
+// CostRegNet (jdacs/models/mvsnet.py:37-74) and its CVP twin (jdacs-ms/models/network.py:44-74).
+// All kernels k=3, pad=1; stride 1 or 2; transposed stride 2 has output_padding 1, stride 1 has 0.
+//
+// Layout: activations channels-last [B,D,H,W,C] fp32.  GEMM view: M = voxels, N = Cout, K = taps*Cin.
+// A workgroup (4 wavefronts) owns a TQDxTQHx16 block of "coarse grid" positions; the input halo
+// region of that block is staged once into LDS (zero filled outside the volume, so the inner loop
+// has no bounds checks), and every wavefront walks K in steps of 16 with
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain).  One ds_read_b128 per lane feeds the
+// A operand of 4 MFMAs; B operands come from a pre-packed weight image (conv_map.h) that is
+// L1/L2 resident.  Epilogue: raw store + per-workgroup BatchNorm partial sums (train), or
+// scale/shift/ReLU/skip fused (eval), or bias (prob layer).
+#include "mvs_rt.h"
+#include "conv_map.h"
+
+struct ConvArgs {
+    const float* x;         // [B,Di,Hi,Wi,Cin]
+    const float* wp;        // packed weights
+    float* y;               // [B,Do,Ho,Wo,Cout]
+    const float* scale;     // [Cout] or null
+    const float* shift;     // [Cout] or null (bias when scale == null)
+    const float* skip;      // like y, or null (added after the ReLU)
+    float* partials;        // [numWG][2][Cout] or null
+    int relu;
+    int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout;
+    int QD, QH, QW;         // coarse-grid extents
+    int ntd, nth, ntw;      // tiles per dim
+};
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                                int geom, int CC, int Cin, int Cout, int NB,
+                                                                int layout, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    const int nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
+    const int co = nb * 16 + (lane & 15);
+    int ks, chunk = 0, cls = 0;
+    if (geom == GEOM_TR2) {
+        int k0 = 0;
+        for (cls = 0; cls < 8; ++cls) {
+            int n = tr2_ntaps(cls) * CC / 16;
+            if (kk < k0 + n) break;
+            k0 += n;
+        }
+        ks = kk - k0;
+    } else {
+        const int KS = ksteps_for(27, CC);
+        chunk = kk / KS;
+        ks = kk % KS;
+    }
+    const int kflat = 16 * ks + 4 * (lane >> 4) + j;
+    const int tap = kflat / CC, ci = chunk * CC + kflat % CC;
+    int kd, kh, kw;
+    bool valid = co < Cout;
+    if (geom == GEOM_TR2) {
+        int dd, dh, dw;
+        tr2_tap(cls, tap, dd, dh, dw, kd, kh, kw);
+    } else {
+        valid = valid && tap < 27;
+        kd = tap / 9; kh = (tap / 3) % 3; kw = tap % 3;
+    }
+    if (flip) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+    float v = 0.f;
+    if (valid) {
+        const int kidx = kd * 9 + kh * 3 + kw;
+        v = layout == WL_OIK ? w[((size_t)co * Cin + ci) * 27 + kidx] : w[((size_t)ci * Cout + co) * 27 + kidx];
+    }
+    wp[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// implicit-GEMM forward-style kernel (conv s1/s2, transposed s2; dgrads map onto these)
+// ------------------------------------------------------------------------------------------------
+template <int GEOM, int CC, int NB>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    using G = ConvGeom<GEOM>;
+    constexpr int CCP = CC + 4;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int MB = G::MB;
+    constexpr int CQ = CC / 4;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ int tapoff[32];
+    __shared__ float red[4 * NB * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+
+    if (tid < 32) {
+        int off = 0;
+        if (GEOM == GEOM_TR2) {
+            if (tid < 27) {
+                int cls = 0, k0 = 0;
+                for (; cls < 8; ++cls) {
+                    int n = tr2_ntaps(cls);
+                    if (tid < k0 + n) break;
+                    k0 += n;
+                }
+                int dd, dh, dw, kd, kh, kw;
+                tr2_tap(cls, tid - k0, dd, dh, dw, kd, kh, kw);
+                off = ((dd * G::RH + dh) * G::RW + dw) * CCP;
+            }
+        } else if (tid < 27) {
+            off = (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP;
+        }
+        tapoff[tid] = off;
+    }
+
+    int baseA[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int f = wave * MB + mb;
+        const int qd_l = f / G::TQH, qh_l = f % G::TQH;
+        baseA[mb] = (((qd_l * G::IS) * G::RH + qh_l * G::IS) * G::RW + l15 * G::IS) * CCP;
+    }
+
+    f32x4 acc[MB][NB];
+    float st1[NB], st2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { st1[nb] = 0.f; st2[nb] = 0.f; }
+
+    const int nchunks = GEOM == GEOM_TR2 ? 1 : a.Cin / CC;
+    const int KSF = ksteps_for(27, CC);
+
+    for (int cls = 0; cls < G::NCLS; ++cls) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (cls == 0) {
+                // ---- stage the input halo region (channels [chunk*CC, +CC)) into LDS ----
+                __syncthreads();
+                for (int i = tid; i < NR * CQ; i += 256) {
+                    const int vox = i / CQ, cq = i % CQ;
+                    const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+                    const int id = qd0 * G::IS + rd - G::PAD, ih = qh0 * G::IS + rh - G::PAD,
+                              iw = qw0 * G::IS + rw - G::PAD;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                        v = *reinterpret_cast<const float4*>(
+                            a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
+                    *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
+                }
+                __syncthreads();
+            }
+            int KS, kk0, tapbase;
+            if (GEOM == GEOM_TR2) {
+                KS = tr2_ntaps(cls) * CC / 16;
+                tapbase = tr2_tap_prefix(cls);
+                kk0 = tapbase * CC / 16;
+            } else {
+                KS = KSF;
+                tapbase = 0;
+                kk0 = chunk * KSF;
+            }
+            for (int ks = 0; ks < KS; ++ks) {
+                const int kflat = 16 * ks + 4 * g;
+                const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
+                float4 bf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ks) * NB + nb) * 64 + lane) * 4);
+                float4 af[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bf[nb].x, acc[mb][nb]);
+                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bf[nb].y, acc[mb][nb]);
+                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bf[nb].z, acc[mb][nb]);
+                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bf[nb].w, acc[mb][nb]);
+                    }
+            }
+        }
+
+        // ---- epilogue for this class: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
+        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int f = wave * MB + mb;
+            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+            if (qd >= a.QD || qh >= a.QH) continue;
+            const int od = qd * G::OS + pd, oh = qh * G::OS + ph;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = qw0 + 4 * g + r;
+                if (qw >= a.QW) continue;
+                const int ow = qw * G::OS + pw;
+                const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = nb * 16 + l15;
+                    if (co >= a.Cout) continue;
+                    float v = acc[mb][nb][r];
+                    st1[nb] += v;
+                    st2[nb] += v * v;
+                    if (a.scale) v = v * a.scale[co] + a.shift[co];
+                    else if (a.shift) v = v + a.shift[co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.skip) v += a.skip[obase + co];
+                    a.y[obase + co] = v;
+                }
+            }
+        }
+    }
+
+    if (a.partials) {
+        // reduce the 4 lane groups of the wave, then the 4 waves, -> partials[block][2][Cout]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float s1 = st1[nb], s2 = st2[nb];
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
+                red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB * 16) {
+            const int stat = tid / (NB * 16), n = tid % (NB * 16);
+            if (n < a.Cout) {
+                float s = 0.f;
+                for (int w = 0; w < 4; ++w) s += red[(w * NB * 16 + n) * 2 + stat];
+                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + n] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 1 (input gradient of the Cout=1 probability layer): direct form, one thread per voxel.
+// y[v][co] = sum_t x[v + t - 1] * wt[t][co]   (wt already flipped / transposed by the caller-side packer)
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                        float* __restrict__ y, int B, int D, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = wt[i];
+    __syncthreads();
+    const size_t total = (size_t)B * D * H * W;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= total) return;
+    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int t = 0; t < 27; ++t) {
+        const int dd = d_ + t / 9 - 1, hh = h_ + (t / 3) % 3 - 1, ww = w_ + t % 3 - 1;
+        if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+        const float xv = x[v + ((long long)(t / 9 - 1) * H + ((t / 3) % 3 - 1)) * W + (t % 3 - 1)];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xv, ws[t * COUT + c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4)
+        *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+}
+
+// wt[t][co] = W[0][co][2-kd][2-kh][2-kw]   (W is [1][Cin][3][3][3], OIK with O == 1)
+__global__ void conv_cin1_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * C) return;
+    const int t = i / C, c = i % C;
+    wt[i] = w[(size_t)c * 27 + (26 - t)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dW[tap][ci][co] = sum_{b,o} X[b, o*S + tap - 1][ci] * G[b,o][co]
+// GEMM view: M = ci (CC=16) or (tap pair, ci) (CC=8), N = co, K = positions.  Persistent workgroups
+// walk tiles, keep dW for their (ci chunk, co chunk) in MFMA accumulators, and emit one partial
+// image each; wgrad_reduce sums the partial images deterministically.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;      // [B,Di,Hi,Wi,CX]
+    const float* g;      // [B,QD,QH,QW,CG]
+    float* part;         // [gridDim.x][27][CX][CG]
+    int B, Di, Hi, Wi, CX, CG;
+    int QD, QH, QW, ntd, nth, ntw;
+};
+
+template <int GEOM, int CC, int NBW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    using G = ConvGeom<GEOM>;
+    constexpr int CCP = CC + 4;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int NPOS = G::TQD * G::TQH * G::TQW;
+    constexpr int COP = NBW * 16 + ((NBW % 2 == 0) ? 16 : 0);
+    constexpr int CQ = CC / 4;
+    constexpr int NSLOT = CC == 16 ? 27 : 14;   // CC==8: a slot is a pair of taps (2s, 2s+1)
+    constexpr int SPW = (NSLOT + 3) / 4;        // slots per wave
+    __shared__ __attribute__((aligned(16))) float xt[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float gt[NPOS * COP];
+    __shared__ int tapoff[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kpos = lane >> 4, l15 = lane & 15;
+    const int chunk = blockIdx.y, cobase = blockIdx.z * NBW * 16;
+
+    if (tid < 32) tapoff[tid] = tid < 27 ? (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP : 0;
+
+    f32x4 acc[SPW][NBW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw = t % a.ntw; t /= a.ntw;
+        const int th = t % a.nth; t /= a.nth;
+        const int td = t % a.ntd; t /= a.ntd;
+        const int b = t;
+        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+        __syncthreads();
+        for (int i = tid; i < NR * CQ; i += 256) {
+            const int vox = i / CQ, cq = i % CQ;
+            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+            const int id = qd0 * G::IS + rd - 1, ih = qh0 * G::IS + rh - 1, iw = qw0 * G::IS + rw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                v = *reinterpret_cast<const float4*>(
+                    a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq);
+            *reinterpret_cast<float4*>(&xt[vox * CCP + 4 * cq]) = v;
+        }
+        for (int i = tid; i < NPOS * NBW * 16; i += 256) {
+            const int p = i / (NBW * 16), n = i % (NBW * 16);
+            const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
+            const int co = cobase + n;
+            float v = 0.f;
+            if (qd < a.QD && qh < a.QH && qw < a.QW && co < a.CG)
+                v = a.g[((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * a.CG + co];
+            gt[p * COP + n] = v;
+        }
+        __syncthreads();
+        for (int ks = 0; ks < NPOS / 4; ++ks) {
+            const int p = 4 * ks + kpos;
+            const int pw_ = p % G::TQW, ph_ = (p / G::TQW) % G::TQH, pd_ = p / (G::TQW * G::TQH);
+            const int xoff = (((pd_ * G::IS) * G::RH + ph_ * G::IS) * G::RW + pw_ * G::IS) * CCP;
+            float bfr[NBW];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) bfr[nb] = gt[p * COP + nb * 16 + l15];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const int slot = wave + 4 * s;
+                if (slot < NSLOT) {
+                    float av;
+                    if (CC == 16) av = xt[xoff + tapoff[slot] + l15];
+                    else av = xt[xoff + tapoff[2 * slot + (l15 >> 3)] + (l15 & 7)];
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = MVS_MFMA_16x16x4(av, bfr[nb], acc[s][nb]);
+                }
+            }
+        }
+    }
+    // D layout: col = lane&15 -> co, row = 4*(lane>>4)+r -> M index
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int slot = wave + 4 * s;
+        if (slot >= NSLOT) continue;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int co = cobase + nb * 16 + l15;
+            if (co >= a.CG) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * kpos + r;
+                int tap, ci;
+                if (CC == 16) { tap = slot; ci = chunk * 16 + i; }
+                else { tap = 2 * slot + (i >> 3); ci = i & 7; }
+                if (tap < 27) a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + ci) * a.CG + co] = acc[s][nb][r];
+            }
+        }
+    }
+}
+
+// out (OIK: [CG][CX][27]) = sum over partial images;  part index [p][tap][cx][cg]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int CX,
+                                                                int CG, float* __restrict__ gw) {
+    const int n = 27 * CX * CG;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const size_t stride = (size_t)n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < nparts; p += 4) {
+        s0 += part[(size_t)p * stride + e];
+        s1 += part[(size_t)(p + 1) * stride + e];
+        s2 += part[(size_t)(p + 2) * stride + e];
+        s3 += part[(size_t)(p + 3) * stride + e];
+    }
+    for (; p < nparts; ++p) s0 += part[(size_t)p * stride + e];
+    const int cg = e % CG, cx = (e / CG) % CX, tap = e / (CG * CX);
+    gw[((size_t)cg * CX + cx) * 27 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int pick_cc(int geom, int cin) {
+    if (geom == GEOM_TR2) return cin;
+    if (geom == GEOM_S2) return 8;
+    return (cin % 16 == 0) ? 16 : 8;
+}
+
+static size_t packed_floats(int geom, int cin, int cout) {
+    const int cc = pick_cc(geom, cin);
+    const int nb = mvs_cdiv(cout, 16);
+    return (size_t)total_ksteps(geom, cin, cc) * nb * 256;
+}
+
+template <int GEOM, int CC>
+static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
+    dim3 grid(nblocks), block(256);
+    switch (NB) {
+        case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1>), grid, block, 0, st, a); break;
+        case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2>), grid, block, 0, st, a); break;
+        case 4: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 4>), grid, block, 0, st, a); break;
+        default: mvs_set_error("conv igemm: Cout tile count %d unsupported", NB); return MVS_ERR_UNSUPPORTED;
+    }
+    return mvs_check_launch("conv_igemm");
+}
+
+struct Epilogue {
+    const float* scale; const float* shift; const float* skip; int relu; float* partials;
+};
+
+// in: [B,Di,Hi,Wi,cin] ; out: [B,Do,Ho,Wo,cout] ; coarse grid: S1/S2 -> output dims, TR2 -> input dims
+static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, int flip, float* out, float* ws,
+                     int B, int Di, int Hi, int Wi, int cin, int cout, const Epilogue& ep, hipStream_t st) {
+    MVS_REQUIRE(in && wsrc && out && ws, MVS_ERR_NULL, "conv: null pointer argument");
+    MVS_REQUIRE(cin == 8 || cin == 16 || cin == 32 || cin == 64, MVS_ERR_UNSUPPORTED,
+                "conv igemm: input channels must be 8/16/32/64, got %d", cin);
+    MVS_REQUIRE(cout >= 1 && cout <= 64, MVS_ERR_UNSUPPORTED, "conv igemm: output channels must be <= 64, got %d", cout);
+    MVS_REQUIRE(!(geom == GEOM_TR2 && cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
+    ConvArgs a = {};
+    a.x = in; a.y = out; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = cin; a.Cout = cout;
+    a.scale = ep.scale; a.shift = ep.shift; a.skip = ep.skip; a.relu = ep.relu; a.partials = ep.partials;
+    if (geom == GEOM_S1) { a.Do = Di; a.Ho = Hi; a.Wo = Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
+    else if (geom == GEOM_S2) {
+        a.Do = (Di - 1) / 2 + 1; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1;
+        a.QD = a.Do; a.QH = a.Ho; a.QW = a.Wo;
+    } else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
+    const int tqd = geom == GEOM_S2 ? 2 : 4;
+    a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    const int nblocks = B * a.ntd * a.nth * a.ntw;
+    const int cc = pick_cc(geom, cin);
+    int NB = mvs_cdiv(cout, 16);
+    if (NB == 3) NB = 4;
+    // pack weights into ws
+    {
+        const int total = (int)((size_t)total_ksteps(geom, cin, cc) * NB * 256);
+        MVS_LAUNCH(conv_pack_weights_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, wsrc, ws, geom, cc, cin, cout,
+                   NB, wlayout, flip, total);
+    }
+    a.wp = ws;
+    if (geom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
+                                         : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
+    if (geom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);
+    if (cc == 16) return launch_igemm_nb<GEOM_TR2, 16>(a, NB, nblocks, st);
+    if (cc == 32) return launch_igemm_nb<GEOM_TR2, 32>(a, NB, nblocks, st);
+    return launch_igemm_nb<GEOM_TR2, 64>(a, NB, nblocks, st);
+}
+
+static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi) {
+    int QD = Di, QH = Hi, QW = Wi;
+    if (geom == GEOM_S2) { QD = (Di - 1) / 2 + 1; QH = (Hi - 1) / 2 + 1; QW = (Wi - 1) / 2 + 1; }
+    return B * mvs_cdiv(QD, geom == GEOM_S2 ? 2 : 4) * mvs_cdiv(QH, 4) * mvs_cdiv(QW, 16);
+}
+
+static const int WGRAD_MAX_GROUPS = 256;
+
+template <int GEOM, int CC>
+static void launch_wgrad(const WgradArgs& a, int nbw, dim3 grid, hipStream_t st) {
+    if (nbw == 1) MVS_LAUNCH((conv_wgrad_kernel<GEOM, CC, 1>), grid, dim3(256), 0, st, a);
+    else MVS_LAUNCH((conv_wgrad_kernel<GEOM, CC, 2>), grid, dim3(256), 0, st, a);
+}
+
+// X: [B,Di,Hi,Wi,CX] (the tensor indexed at o*S + tap - 1), G: [B,QD,QH,QW,CG]; out OIK [CG][CX][27]
+static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float* ws, int B, int Di, int Hi, int Wi,
+                     int CX, int CG, hipStream_t st) {
+    MVS_REQUIRE(X && Gt && gw && ws, MVS_ERR_NULL, "conv wgrad: null pointer argument");
+    MVS_REQUIRE(CX == 8 || CX == 16 || CX == 32 || CX == 64, MVS_ERR_UNSUPPORTED,
+                "conv wgrad: X channels must be 8/16/32/64, got %d", CX);
+    MVS_REQUIRE(CG >= 1 && CG <= 64, MVS_ERR_UNSUPPORTED, "conv wgrad: G channels must be <= 64, got %d", CG);
+    WgradArgs a = {};
+    a.x = X; a.g = Gt; a.part = ws; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.CX = CX; a.CG = CG;
+    if (geom == GEOM_S1) { a.QD = Di; a.QH = Hi; a.QW = Wi; }
+    else { a.QD = (Di - 1) / 2 + 1; a.QH = (Hi - 1) / 2 + 1; a.QW = (Wi - 1) / 2 + 1; }
+    a.ntd = mvs_cdiv(a.QD, geom == GEOM_S2 ? 2 : 4); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    const int ntiles = B * a.ntd * a.nth * a.ntw;
+    const int cc = CX % 16 == 0 ? 16 : 8;
+    const int nbw = CG > 16 ? 2 : 1;
+    const int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+    dim3 grid(groups, CX / cc, mvs_cdiv(CG, nbw * 16));
+    if (geom == GEOM_S1) { if (cc == 16) launch_wgrad<GEOM_S1, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S1, 8>(a, nbw, grid, st); }
+    else { if (cc == 16) launch_wgrad<GEOM_S2, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S2, 8>(a, nbw, grid, st); }
+    int rc = mvs_check_launch("conv_wgrad");
+    if (rc) return rc;
+    const int n = 27 * CX * CG;
+    MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, groups, CX, CG, gw);
+    return mvs_check_launch("conv_wgrad_reduce");
+}
+
+static size_t wgrad_ws_floats(int CX, int CG) { return (size_t)WGRAD_MAX_GROUPS * 27 * CX * CG; }
+
+static int check_stride(int stride, int D, int H, int W, const char* what) {
+    MVS_REQUIRE(stride == 1 || stride == 2, MVS_ERR_UNSUPPORTED, "%s: stride must be 1 or 2, got %d", what, stride);
+    MVS_REQUIRE(D > 0 && H > 0 && W > 0, MVS_ERR_SHAPE, "%s: bad spatial shape %dx%dx%d", what, D, H, W);
+    return MVS_OK;
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+// (D,H,W) are always the spatial dims of the forward op's INPUT x.
+enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
+       MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
+
+extern "C" long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int W, int Cin, int Cout, int stride) {
+    (void)B; (void)D; (void)H; (void)W;
+    size_t fl = 0;
+    switch (op) {
+        case MVS_OP_CONV_FWD: fl = packed_floats(stride == 2 ? GEOM_S2 : GEOM_S1, Cin, Cout); break;
+        case MVS_OP_CONV_DGRAD: fl = Cout == 1 ? (size_t)27 * Cin : packed_floats(stride == 2 ? GEOM_TR2 : GEOM_S1, Cout, Cin); break;
+        case MVS_OP_CONVT_FWD: fl = packed_floats(stride == 2 ? GEOM_TR2 : GEOM_S1, Cin, Cout); break;
+        case MVS_OP_CONVT_DGRAD: fl = packed_floats(stride == 2 ? GEOM_S2 : GEOM_S1, Cout, Cin); break;
+        case MVS_OP_CONV_WGRAD: fl = wgrad_ws_floats(Cin, Cout); break;
+        case MVS_OP_CONVT_WGRAD: fl = wgrad_ws_floats(Cout, Cin); break;
+        default: return -1;
+    }
+    return (long long)(fl * sizeof(float) + 256);
+}
+
+// rows of the [rows][2][Cout] BatchNorm partial-sum buffer a forward call writes
+extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int stride) {
+    if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W);
+    if (op == MVS_OP_CONVT_FWD) return igemm_blocks(stride == 2 ? GEOM_TR2 : GEOM_S1, B, D, H, W);
+    return -1;
+}
+
+// y = conv3d(x, w[Cout][Cin][3][3][3], stride, pad 1) then optional epilogue:
+//   scale&&shift: y*scale[c]+shift[c] ; only shift: y+shift[c] (bias) ; relu ; + skip ; stat partials of raw y
+extern "C" int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W,
+                              int Cin, int Cout, int stride, const float* scale, const float* shift,
+                              const float* skip, int relu, float* stat_partials, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "conv3d_fwd");
+    if (rc) return rc;
+    Epilogue ep = {scale, shift, skip, relu, stat_partials};
+    return run_igemm(stride == 2 ? GEOM_S2 : GEOM_S1, x, w, WL_OIK, 0, y, ws, B, D, H, W, Cin, Cout, ep, stream);
+}
+
+// gx[B,D,H,W,Cin] = d conv3d / dx applied to gy[B,Do,Ho,Wo,Cout]
+extern "C" int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W,
+                                int Cin, int Cout, int stride, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "conv3d_dgrad");
+    if (rc) return rc;
+    Epilogue ep = {nullptr, nullptr, nullptr, 0, nullptr};
+    if (stride == 1) {
+        if (Cout == 1) {
+            MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv3d_dgrad: null pointer argument");
+            MVS_REQUIRE(Cin == 8 || Cin == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", Cin);
+            MVS_LAUNCH(conv_cin1_pack_kernel, dim3(mvs_cdiv(27 * Cin, 256)), dim3(256), 0, stream, w, ws, Cin);
+            const size_t total = (size_t)B * D * H * W;
+            dim3 grid((unsigned)((total + 255) / 256));
+            if (Cin == 8) MVS_LAUNCH((conv_cin1_kernel<8>), grid, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
+            else MVS_LAUNCH((conv_cin1_kernel<16>), grid, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
+            return mvs_check_launch("conv_cin1");
+        }
+        return run_igemm(GEOM_S1, gy, w, WL_IOK, 1, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
+    }
+    MVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MVS_ERR_SHAPE, "conv3d_dgrad stride 2: D,H,W must be even");
+    return run_igemm(GEOM_TR2, gy, w, WL_IOK, 0, gx, ws, B, D / 2, H / 2, W / 2, Cout, Cin, ep, stream);
+}
+
+// gw[Cout][Cin][27] = d conv3d / dw
+extern "C" int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W,
+                                int Cin, int Cout, int stride, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "conv3d_wgrad");
+    if (rc) return rc;
+    return run_wgrad(stride == 2 ? GEOM_S2 : GEOM_S1, x, gy, gw, ws, B, D, H, W, Cin, Cout, stream);
+}
+
+// y = conv_transpose3d(x, w[Cin][Cout][3][3][3], stride, pad 1, output_padding stride-1)
+extern "C" int mvs_convT3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W,
+                               int Cin, int Cout, int stride, const float* scale, const float* shift,
+                               const float* skip, int relu, float* stat_partials, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "convT3d_fwd");
+    if (rc) return rc;
+    Epilogue ep = {scale, shift, skip, relu, stat_partials};
+    if (stride == 1) return run_igemm(GEOM_S1, x, w, WL_IOK, 1, y, ws, B, D, H, W, Cin, Cout, ep, stream);
+    return run_igemm(GEOM_TR2, x, w, WL_IOK, 0, y, ws, B, D, H, W, Cin, Cout, ep, stream);
+}
+
+// gx[B,D,H,W,Cin] from gy[B,sD,sH,sW,Cout]
+extern "C" int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W,
+                                 int Cin, int Cout, int stride, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "convT3d_dgrad");
+    if (rc) return rc;
+    Epilogue ep = {nullptr, nullptr, nullptr, 0, nullptr};
+    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_OIK, 0, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
+    return run_igemm(GEOM_S2, gy, w, WL_OIK, 0, gx, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, ep, stream);
+}
+
+// gw[Cin][Cout][27]
+extern "C" int mvs_convT3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W,
+                                 int Cin, int Cout, int stride, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "convT3d_wgrad");
+    if (rc) return rc;
+    // roles swap: the tensor indexed at o*S + tap - 1 is gy (fine grid), the "G" operand is x (coarse grid)
+    if (stride == 1) return run_wgrad(GEOM_S1, gy, x, gw, ws, B, D, H, W, Cout, Cin, stream);
+    return run_wgrad(GEOM_S2, gy, x, gw, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, stream);
+}

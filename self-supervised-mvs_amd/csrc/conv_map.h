@@ -1,0 +1,72 @@
+// Index maps shared by the implicit-GEMM convolution kernels, the weight packer and the host code.
+//
+// Geometry (all k=3, pad=1 as in the reference: jdacs/models/mvsnet.py:40-63,
+// jdacs-ms/models/network.py:47-65):
+//   GEOM_S1 : y[o] = sum_t x[o + t - 1] W[t]        "coarse grid" q = o      (stride-1 conv, and the
+//             stride-1 transposed conv / stride-1 dgrad after flipping taps in the packer)
+//   GEOM_S2 : y[o] = sum_t x[2o + t - 1] W[t]       q = o                    (stride-2 conv)
+//   GEOM_TR2: y[2q+p] = sum_{t in class p} x[q + delta_t] W[k_t]             (stride-2 transposed conv
+//             with output_padding 1 == dgrad of the stride-2 conv); 8 parity classes p=(pd,ph,pw);
+//             per dim: p=0 -> {(delta 0, k 1)}, p=1 -> {(delta 1, k 0), (delta 0, k 2)}.
+#pragma once
+
+#if defined(__HIPCC__) || defined(MVS_CPU_EMUL)
+#define MVS_HD __host__ __device__
+#else
+#define MVS_HD
+#endif
+
+enum { GEOM_S1 = 0, GEOM_S2 = 1, GEOM_TR2 = 2 };
+// source weight tensor layout: OIK = [out'][in'][3][3][3], IOK = [in'][out'][3][3][3]
+enum { WL_OIK = 0, WL_IOK = 1 };
+
+template <int GEOM>
+struct ConvGeom;
+template <>
+struct ConvGeom<GEOM_S1> {
+    static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;
+    static constexpr int IS = 1, OS = 1, NCLS = 1, PAD = 1;
+    static constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
+};
+template <>
+struct ConvGeom<GEOM_S2> {
+    static constexpr int TQD = 2, TQH = 4, TQW = 16, MB = 2;
+    static constexpr int IS = 2, OS = 1, NCLS = 1, PAD = 1;
+    static constexpr int RD = 2 * TQD + 1, RH = 2 * TQH + 1, RW = 2 * TQW + 1;
+};
+template <>
+struct ConvGeom<GEOM_TR2> {
+    static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;
+    static constexpr int IS = 1, OS = 2, NCLS = 8, PAD = 0;
+    static constexpr int RD = TQD + 1, RH = TQH + 1, RW = TQW + 1;
+};
+
+// number of taps of a TR2 parity class and of the classes before it (class id = pd*4 + ph*2 + pw)
+MVS_HD inline int tr2_ntaps(int cls) { return (1 + ((cls >> 2) & 1)) * (1 + ((cls >> 1) & 1)) * (1 + (cls & 1)); }
+MVS_HD inline int tr2_tap_prefix(int cls) {
+    int s = 0;
+    for (int c = 0; c < cls; ++c) s += tr2_ntaps(c);
+    return s;
+}
+// tap t of class cls -> region offset (dd,dh,dw) in {0,1} and kernel index (kd,kh,kw)
+MVS_HD inline void tr2_tap(int cls, int t, int& dd, int& dh, int& dw, int& kd, int& kh, int& kw) {
+    const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int nh = 1 + ph, nw = 1 + pw;
+    const int tw = t % nw, th = (t / nw) % nh, td = t / (nw * nh);
+    dd = (pd && td == 0) ? 1 : 0; kd = pd ? (td == 0 ? 0 : 2) : 1;
+    dh = (ph && th == 0) ? 1 : 0; kh = ph ? (th == 0 ? 0 : 2) : 1;
+    dw = (pw && tw == 0) ? 1 : 0; kw = pw ? (tw == 0 ? 0 : 2) : 1;
+}
+
+// K-steps (16 flattened (tap, ci) indices each) of one class for a CC-channel chunk
+MVS_HD inline int ksteps_for(int ntaps, int CC) { return (ntaps * CC + 15) / 16; }
+
+// Packed weight buffer: [kk][nb][64 lanes][4] floats, kk = global k-step index:
+//   S1/S2 : kk = chunk * ksteps_for(27, CC) + ks
+//   TR2   : kk = tr2_tap_prefix(cls) * CC / 16 + ks        (single chunk, CC == Cin, CC % 16 == 0)
+// lane l, element j holds W[flattened k = 16*ks + 4*(l>>4) + j][co = 16*nb + (l & 15)],
+// flattened k -> (tap = k / CC, ci = chunk*CC + k % CC).
+MVS_HD inline int total_ksteps(int geom, int Cin, int CC) {
+    if (geom == GEOM_TR2) return 27 * CC / 16;
+    return (Cin / CC) * ksteps_for(27, CC);
+}

@@ -1,0 +1,42 @@
+// Runtime glue shared by every kernel file.
+//  * hipcc build (the product): plain HIP for gfx950.
+//  * -DMVS_CPU_EMUL (tests/cpu_emul only): the same kernel sources are compiled with g++ against a
+//    tiny pthread-based emulation of the HIP execution model so kernel *logic* (index maps, MFMA
+//    fragment layouts, reductions) can be checked in the GPU-less build container.  The emulation
+//    library is test infrastructure; the product never loads it.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(MVS_CPU_EMUL)
+#include "hip_emul.h"
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MVS_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#define MVS_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+#define MVS_WAVE 64
+#define MVS_MAX_SRC 10
+
+// ---- error reporting (no exceptions across the C boundary) ---------------------------------
+#define MVS_OK 0
+#define MVS_ERR_SHAPE (-1)
+#define MVS_ERR_UNSUPPORTED (-2)
+#define MVS_ERR_LAUNCH (-3)
+#define MVS_ERR_NULL (-4)
+
+void mvs_set_error(const char* fmt, ...);
+int mvs_check_launch(const char* what);
+
+#define MVS_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            mvs_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+static inline int mvs_cdiv(int a, int b) { return (a + b - 1) / b; }

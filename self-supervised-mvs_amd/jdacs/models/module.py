@@ -1,0 +1,41 @@
+"""Drop-in for jdacs/models/module.py: same public names, HIP kernels underneath.
+
+  homo_warping(src_fea, src_proj, ref_proj, depth_values) -> [B,C,D,H,W]   (module.py:105-140)
+  depth_regression(p, depth_values)                        -> [B,H,W]      (module.py:145-148)
+  ConvBnReLU3D                                                             (module.py:35-42)
+  ConvBnReLU (2-D, FeatureNet/RefineNet: stock PyTorch, not on the hot path; module.py:15-22)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...nn3d import ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d  # noqa: F401
+
+ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >= 1.3
+
+
+class ConvBnReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth_values, align_corners=None):
+    """Warp one source feature map into every depth plane of the reference view."""
+    with torch.no_grad():
+        rot, trans = ops.relative_projection(src_proj, ref_proj)
+    ac = ALIGN_CORNERS if align_corners is None else align_corners
+    return ops.HomoWarp.apply(src_fea, rot, trans, depth_values, ac)
+
+
+def depth_regression(p, depth_values):
+    """Expectation of the depth hypotheses under p [B,D,H,W] (an already-normalised probability
+    volume).  Tiny elementwise host op; the fused softmax+regression kernel is ops.softargmin_conf."""
+    if depth_values.dim() <= 2:
+        depth_values = depth_values.view(*depth_values.shape, 1, 1)
+    return torch.sum(p * depth_values, 1)

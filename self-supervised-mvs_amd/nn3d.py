@@ -1,0 +1,67 @@
+"""Building blocks of the 3-D regularisers, with the reference's parameter names.
+
+The stock ``nn.Conv3d`` / ``nn.ConvTranspose3d`` / ``nn.BatchNorm3d`` modules are kept ONLY as
+parameter / buffer containers (identical ``state_dict`` keys, shapes and default initialisation as
+jdacs/models/module.py:35-42 and jdacs/models/mvsnet.py:48-63, so reference checkpoints load
+unchanged); their ``forward`` is never called -- the arithmetic runs in the HIP kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _bn_step(bn: nn.BatchNorm3d, training: bool):
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return bn.momentum if bn.momentum is not None else 0.1
+
+
+class ConvBnReLU3D(nn.Module):
+    """jdacs/models/module.py:35-42 (and jdacs-ms/models/modules.py:285-292).  ``skip`` (optional) is
+    added after the ReLU, which is how the U-Nets use it (mvsnet.py:70-72)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        if kernel_size != 3 or pad != 1 or stride not in (1, 2):
+            raise ValueError("mvs_amd ConvBnReLU3D supports kernel_size=3, pad=1, stride 1|2 (the reference's use)")
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm3d(out_channels)
+        self.stride = stride
+
+    def forward(self, x, skip=None):
+        bn = self.bn
+        momentum = _bn_step(bn, self.training)
+        return ops.ConvBnReLU3dFn.apply(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        skip, self.stride, False, self.training, bn.eps, momentum)
+
+
+class DeconvBnReLU3D(nn.Sequential):
+    """nn.Sequential(ConvTranspose3d(k3, p1, output_padding=stride-1, bias=False), BatchNorm3d, ReLU)
+    with keys ``0.weight`` / ``1.*`` (jdacs/models/mvsnet.py:48-61; jdacs-ms/models/network.py:55-64)."""
+
+    def __init__(self, in_channels, out_channels, stride=2):
+        if stride not in (1, 2):
+            raise ValueError("stride must be 1 or 2")
+        super().__init__(
+            nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, padding=1, output_padding=stride - 1,
+                               stride=stride, bias=False),
+            nn.BatchNorm3d(out_channels),
+            nn.ReLU(inplace=True))
+        self.stride = stride
+
+    def forward(self, x, skip=None):
+        bn = self[1]
+        momentum = _bn_step(bn, self.training)
+        return ops.ConvBnReLU3dFn.apply(x, self[0].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, skip,
+                                        self.stride, True, self.training, bn.eps, momentum)
+
+
+class ProbConv3d(nn.Conv3d):
+    """nn.Conv3d(C, 1, 3, stride=1, padding=1) with bias (mvsnet.py:63); keys ``weight`` / ``bias``."""
+
+    def __init__(self, in_channels):
+        super().__init__(in_channels, 1, 3, stride=1, padding=1)
+
+    def forward(self, x):
+        return ops.ConvBias3dFn.apply(x, self.weight, self.bias)

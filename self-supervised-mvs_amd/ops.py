@@ -1,0 +1,343 @@
+"""torch <-> libmvs_hip.so glue: functional wrappers and autograd Functions for the hot path.
+
+Host code is PyTorch (device memory, streams, autograd graph); all arithmetic on the path happens in
+the HIP kernels behind the C ABI (include/mvs_hip.h).  Tensors keep the reference's LOGICAL shapes
+([B,C,H,W], [B,C,D,H,W]) but are physically channels-last (torch.channels_last / channels_last_3d),
+which is the layout the kernels index.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (OP_CONV_DGRAD, OP_CONV_FWD, OP_CONV_WGRAD, OP_CONVT_DGRAD, OP_CONVT_FWD, OP_CONVT_WGRAD)
+
+CL2 = torch.channels_last
+CL3 = torch.channels_last_3d
+
+
+def _lib_for(t: torch.Tensor) -> _lib.MvsLib:
+    lib = _lib.get()
+    if t.device.type != lib.device_type:
+        raise RuntimeError("mvs_amd: tensor on %s but the HIP library serves '%s' devices; the hot path has no "
+                           "CPU fallback" % (t.device, lib.device_type))
+    if t.dtype != torch.float32:
+        raise TypeError("mvs_amd: fp32 tensors required, got %s" % t.dtype)
+    return lib
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def as_cl2(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous(memory_format=CL2)
+
+
+def as_cl3(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous(memory_format=CL3)
+
+
+def empty_cl3(b, c, d, h, w, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((b, c, d, h, w), dtype=torch.float32, device=like.device, memory_format=CL3)
+
+
+# ------------------------------------------------------------------------------------------------
+# plane sweep (K1/K2)
+# ------------------------------------------------------------------------------------------------
+def relative_projection(src_proj: torch.Tensor, ref_proj: torch.Tensor):
+    """rot [B,3,3] / trans [B,3] of src_proj @ inverse(ref_proj) -- host torch code, exactly the
+    reference's lines (jdacs/models/module.py:116-118)."""
+    proj = torch.matmul(src_proj, torch.inverse(ref_proj))
+    return proj[:, :3, :3], proj[:, :3, 3]
+
+
+def _depth_arg(depth: torch.Tensor, b: int, h: int, w: int):
+    if depth.dim() == 2:
+        return depth.contiguous(), 0
+    if depth.dim() == 4 and depth.shape[0] == b and depth.shape[2] == h and depth.shape[3] == w:
+        return depth.contiguous(), 1
+    raise ValueError("depth hypotheses must be [B,D] or [B,D,H,W], got %s" % (tuple(depth.shape),))
+
+
+class PlaneSweepVariance(torch.autograd.Function):
+    """var[B,C,D,H,W] = variance over {ref, warped sources}.  Differentiable
+    w.r.t. the feature maps only, like the reference (grid built under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, depth, rot, trans, align_corners, ms_alias, ref, *srcs):
+        lib = _lib_for(ref)
+        b, c, h, w = ref.shape
+        n = len(srcs) + 1
+        ref_c = as_cl2(ref)
+        srcs_c = [as_cl2(s) for s in srcs]
+        for s in srcs_c:
+            if s.shape != ref_c.shape:
+                raise ValueError("source feature map shape %s != reference %s" % (tuple(s.shape), tuple(ref.shape)))
+        depth_c, per_pixel = _depth_arg(depth, b, h, w)
+        nd = depth_c.shape[1]
+        rot_c = rot.reshape(b, n - 1, 9).contiguous().float()
+        trans_c = trans.reshape(b, n - 1, 3).contiguous().float()
+        var = empty_cl3(b, c, nd, h, w, ref)
+        lib.call("mvs_plane_sweep_variance_fwd", _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c), _p(depth_c),
+                 per_pixel, b, n, c, nd, h, w, int(align_corners), int(ms_alias), _p(var), _stream(ref))
+        ctx.save_for_backward(ref_c, depth_c, rot_c, trans_c, *srcs_c)
+        ctx.cfg = (per_pixel, int(align_corners), int(ms_alias))
+        return var
+
+    @staticmethod
+    def backward(ctx, gvar):
+        ref_c, depth_c, rot_c, trans_c, *srcs_c = ctx.saved_tensors
+        per_pixel, align_corners, ms_alias = ctx.cfg
+        lib = _lib_for(ref_c)
+        b, c, h, w = ref_c.shape
+        n = len(srcs_c) + 1
+        nd = depth_c.shape[1]
+        g = as_cl3(gvar)
+        gref = torch.zeros_like(ref_c, memory_format=CL2)
+        gsrcs = [torch.zeros_like(s, memory_format=CL2) for s in srcs_c]
+        lib.call("mvs_plane_sweep_variance_bwd", _p(g), _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c),
+                 _p(depth_c), per_pixel, b, n, c, nd, h, w, align_corners, ms_alias, _p(gref), _ptr_array(gsrcs),
+                 _stream(ref_c))
+        return (None, None, None, None, None, gref, *gsrcs)
+
+
+def plane_sweep_variance(ref, srcs, rot, trans, depth, align_corners=False, ms_alias=False):
+    """ref [B,C,H,W]; srcs list of [B,C,H,W]; rot [B,N-1,3,3]; trans [B,N-1,3]; depth [B,D]|[B,D,H,W]."""
+    return PlaneSweepVariance.apply(depth, rot, trans, align_corners, ms_alias, ref, *srcs)
+
+
+class HomoWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, rot, trans, depth, align_corners):
+        lib = _lib_for(src)
+        b, c, h, w = src.shape
+        src_c = as_cl2(src)
+        depth_c, per_pixel = _depth_arg(depth, b, h, w)
+        nd = depth_c.shape[1]
+        rot_c = rot.reshape(b, 9).contiguous().float()
+        trans_c = trans.reshape(b, 3).contiguous().float()
+        out = empty_cl3(b, c, nd, h, w, src)
+        lib.call("mvs_homo_warp_fwd", _p(src_c), _p(rot_c), _p(trans_c), _p(depth_c), per_pixel, b, c, nd, h, w,
+                 int(align_corners), _p(out), _stream(src))
+        ctx.save_for_backward(src_c, rot_c, trans_c, depth_c)
+        ctx.cfg = (per_pixel, int(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src_c, rot_c, trans_c, depth_c = ctx.saved_tensors
+        per_pixel, align_corners = ctx.cfg
+        lib = _lib_for(src_c)
+        b, c, h, w = src_c.shape
+        g = as_cl3(gout)
+        gsrc = torch.zeros_like(src_c, memory_format=CL2)
+        lib.call("mvs_homo_warp_bwd", _p(g), _p(src_c), _p(rot_c), _p(trans_c), _p(depth_c), per_pixel, b, c,
+                 depth_c.shape[1], h, w, align_corners, _p(gsrc), _stream(src_c))
+        return gsrc, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# 3-D convolution family + BatchNorm (K3-K8)
+# ------------------------------------------------------------------------------------------------
+def _ws(lib, op, b, d, h, w, cin, cout, stride, like):
+    nbytes = lib.raw("mvs_conv3d_workspace_bytes", op, b, d, h, w, cin, cout, stride)
+    if nbytes < 0:
+        raise ValueError("mvs_conv3d_workspace_bytes: bad op %d" % op)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=like.device)
+
+
+def _out_dims(d, h, w, stride, transposed):
+    if transposed:
+        return (d * stride, h * stride, w * stride)
+    if stride == 1:
+        return (d, h, w)
+    return ((d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
+
+
+def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None, skip=None, relu=False,
+                   want_stats=False):
+    """Raw C-ABI call.  x [B,Cin,D,H,W] (channels_last_3d).  Returns (y, stat_partials|None)."""
+    lib = _lib_for(x)
+    x = as_cl3(x)
+    b, cin, d, h, w = x.shape
+    wt = weight.contiguous()
+    cout = wt.shape[1] if transposed else wt.shape[0]
+    if (wt.shape[0] if transposed else wt.shape[1]) != cin or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError("weight shape %s does not match %d input channels / 3x3x3" % (tuple(wt.shape), cin))
+    op = OP_CONVT_FWD if transposed else OP_CONV_FWD
+    od, oh, ow = _out_dims(d, h, w, stride, transposed)
+    y = empty_cl3(b, cout, od, oh, ow, x)
+    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
+    parts = None
+    if want_stats:
+        rows = lib.raw("mvs_conv3d_stat_rows", op, b, d, h, w, stride)
+        parts = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    if skip is not None:
+        skip = as_cl3(skip)
+        if skip.shape != y.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(y.shape)))
+    lib.call("mvs_convT3d_fwd" if transposed else "mvs_conv3d_fwd", _p(x), _p(wt), _p(y), _p(ws), b, d, h, w, cin,
+             cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(parts), _stream(x))
+    return y, parts
+
+
+def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False):
+    lib = _lib_for(gy)
+    gy = as_cl3(gy)
+    b, cin, d, h, w = in_shape
+    wt = weight.contiguous()
+    cout = wt.shape[1] if transposed else wt.shape[0]
+    op = OP_CONVT_DGRAD if transposed else OP_CONV_DGRAD
+    gx = empty_cl3(b, cin, d, h, w, gy)
+    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, gy)
+    lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(gx), _p(ws), b, d, h, w,
+             cin, cout, stride, _stream(gy))
+    return gx
+
+
+def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
+    lib = _lib_for(x)
+    x = as_cl3(x)
+    gy = as_cl3(gy)
+    b, cin, d, h, w = x.shape
+    cout = weight_shape[1] if transposed else weight_shape[0]
+    op = OP_CONVT_WGRAD if transposed else OP_CONV_WGRAD
+    gw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
+    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
+    lib.call("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad", _p(x), _p(gy), _p(gw), _p(ws), b, d, h, w,
+             cin, cout, stride, _stream(x))
+    return gw
+
+
+class ConvBnReLU3dFn(torch.autograd.Function):
+    """conv3d | conv_transpose3d (bias-free, k3 p1) -> BatchNorm3d -> ReLU (-> + skip, after the ReLU).
+
+    Train: batch statistics (partials from the conv epilogue), running stats updated in place.
+    Eval : BatchNorm folded into the conv epilogue (no gradient support -- the reference only
+    evaluates under no_grad, jdacs/eval.py:143)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, skip, stride, transposed, training, eps,
+                momentum):
+        lib = _lib_for(x)
+        st = _stream(x)
+        x = as_cl3(x)
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        dev = x.device
+        if not training:
+            scale = torch.empty(cout, dtype=torch.float32, device=dev)
+            shift = torch.empty_like(scale)
+            lib.call("mvs_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), cout,
+                     _p(scale), _p(shift), st)
+            y, _ = conv3d_forward(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
+            ctx.eval_mode = True
+            return y
+        raw, parts = conv3d_forward(x, weight, stride, transposed, want_stats=True)
+        b, _, od, oh, ow = raw.shape
+        count = b * od * oh * ow
+        stats = torch.empty((4, cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        lib.call("mvs_bn_finalize", _p(parts), parts.shape[0], cout, count, _p(gamma), _p(beta), float(eps),
+                 float(momentum), _p(running_mean), _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                 _p(stats[3]), st)
+        y = torch.empty_like(raw, memory_format=CL3)
+        skip_c = None if skip is None else as_cl3(skip)
+        lib.call("mvs_bn_relu_fwd", _p(raw), _p(stats[2]), _p(stats[3]), _p(skip_c), 1, count, cout, _p(y), st)
+        ctx.save_for_backward(x, weight, raw, stats)
+        ctx.cfg = (stride, transposed, skip is not None, count, cout)
+        ctx.eval_mode = False
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.eval_mode:
+            raise NotImplementedError("mvs_amd: backward through eval-mode (folded) BatchNorm is not supported; "
+                                      "call .train() for training or use torch.no_grad() for inference")
+        x, weight, raw, stats = ctx.saved_tensors
+        stride, transposed, has_skip, count, cout = ctx.cfg
+        lib = _lib_for(x)
+        st = _stream(x)
+        gy = as_cl3(gy)
+        ws = torch.empty(1024 * 2 * cout + 2 * cout, dtype=torch.float32, device=x.device)
+        draw = torch.empty_like(raw, memory_format=CL3)
+        dgb = torch.empty((2, cout), dtype=torch.float32, device=x.device)
+        lib.call("mvs_bn_relu_bwd", _p(gy), _p(raw), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, count,
+                 cout, _p(ws), _p(draw), _p(dgb[0]), _p(dgb[1]), st)
+        gx = conv3d_dgrad(draw, weight, tuple(x.shape), stride, transposed) if ctx.needs_input_grad[0] else None
+        gw = conv3d_wgrad(x, draw, tuple(weight.shape), stride, transposed) if ctx.needs_input_grad[1] else None
+        gskip = gy if has_skip else None
+        return gx, gw, dgb[0], dgb[1], None, None, gskip, None, None, None, None, None
+
+
+class ConvBias3dFn(torch.autograd.Function):
+    """Conv3d k3 p1 s1 with bias, no BN / activation: the `prob` layer (jdacs/models/mvsnet.py:63,73;
+    jdacs-ms/models/network.py:65,73)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = as_cl3(x)
+        y, _ = conv3d_forward(x, weight, 1, False, shift=bias.contiguous())
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = as_cl3(gy)
+        gx = conv3d_dgrad(gy, weight, tuple(x.shape), 1, False) if ctx.needs_input_grad[0] else None
+        gw = conv3d_wgrad(x, gy, tuple(weight.shape), 1, False) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+# ------------------------------------------------------------------------------------------------
+# soft-argmin + confidence (K9/K10)
+# ------------------------------------------------------------------------------------------------
+class SoftArgminConf(torch.autograd.Function):
+    """logits [B,D,H,W], depth hypotheses [B,D] | [B,D,H,W] -> (depth [B,H,W], confidence [B,H,W]).
+    Confidence is computed under no_grad in the reference (mvsnet.py:145) -> non differentiable."""
+
+    @staticmethod
+    def forward(ctx, logits, depth_values):
+        lib = _lib_for(logits)
+        logits = logits.contiguous()
+        b, nd, h, w = logits.shape
+        dv, per_pixel = _depth_arg(depth_values, b, h, w)
+        if dv.shape[1] != nd:
+            raise ValueError("depth hypotheses D=%d != logits D=%d" % (dv.shape[1], nd))
+        depth, conf, smax, ssum = (torch.empty((b, h, w), dtype=torch.float32, device=logits.device)
+                                   for _ in range(4))
+        lib.call("mvs_softargmin_conf_fwd", _p(logits), _p(dv), per_pixel, b, nd, h, w, _p(depth), _p(conf),
+                 _p(smax), _p(ssum), _stream(logits))
+        ctx.save_for_backward(logits, dv, depth, smax, ssum)
+        ctx.per_pixel = per_pixel
+        ctx.mark_non_differentiable(conf)
+        return depth, conf
+
+    @staticmethod
+    def backward(ctx, gdepth, _gconf):
+        logits, dv, depth, smax, ssum = ctx.saved_tensors
+        lib = _lib_for(logits)
+        b, nd, h, w = logits.shape
+        gl = torch.empty_like(logits)
+        lib.call("mvs_softargmin_conf_bwd", _p(gdepth.contiguous()), _p(logits), _p(dv), ctx.per_pixel, _p(depth),
+                 _p(smax), _p(ssum), b, nd, h, w, _p(gl), _stream(logits))
+        return gl, None
+
+
+def softargmin_conf(logits, depth_values):
+    return SoftArgminConf.apply(logits, depth_values)

@@ -1,0 +1,152 @@
+// TEST INFRASTRUCTURE ONLY: minimal emulation of the HIP execution model on host threads.
+// One OS thread per work-item of ONE workgroup at a time (workgroups run sequentially), pthread
+// barriers for __syncthreads and for wave-level exchanges (shuffles, MFMA).  Slow; for tiny shapes.
+#pragma once
+#include <pthread.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+#include <functional>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace emul {
+struct Wave {
+    pthread_barrier_t bar;
+    float fa[2][64];
+    float fb[2][64];
+};
+struct Block {
+    pthread_barrier_t bar;
+    std::vector<Wave> waves;
+};
+inline thread_local Block* cur_block = nullptr;
+inline thread_local Wave* cur_wave = nullptr;
+inline thread_local int lane = 0;
+inline thread_local unsigned xcnt = 0;
+
+template <class F>
+void launch(dim3 grid, dim3 block, F body);
+}  // namespace emul
+
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emul::cur_block->bar); }
+
+static inline float __shfl_xor(float v, int mask, int width = 64) {
+    (void)width;
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    w->fa[s][emul::lane] = v;
+    pthread_barrier_wait(&w->bar);
+    return w->fa[s][emul::lane ^ mask];
+}
+static inline float __shfl(float v, int src, int width = 64) {
+    (void)width;
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    w->fa[s][emul::lane] = v;
+    pthread_barrier_wait(&w->bar);
+    return w->fa[s][src & 63];
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+r,
+// k-ordered fmaf chain (cdna_hip_programming.md section 3).
+static inline f32x4 emul_mfma_16x16x4(float a, float b, f32x4 c) {
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    int l = emul::lane;
+    w->fa[s][l] = a;
+    w->fb[s][l] = b;
+    pthread_barrier_wait(&w->bar);
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w->fa[s][k * 16 + row], w->fb[s][k * 16 + col], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define MVS_MFMA_16x16x4(a, b, c) emul_mfma_16x16x4((a), (b), (c))
+
+static inline float atomicAdd(float* addr, float v) {
+    unsigned* p = (unsigned*)addr;
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED), nw;
+    float f;
+    do {
+        memcpy(&f, &old, 4);
+        f += v;
+        memcpy(&nw, &f, 4);
+    } while (!__atomic_compare_exchange_n(p, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &old, 4);
+    return f;
+}
+
+namespace emul {
+template <class F>
+void launch(dim3 grid, dim3 block, F body) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    const int nwaves = (nthreads + 63) / 64;
+    Block blk;
+    blk.waves = std::vector<Wave>(nwaves);
+    pthread_barrier_init(&blk.bar, nullptr, nthreads);
+    for (int w = 0; w < nwaves; ++w) {
+        int cnt = nthreads - w * 64;
+        if (cnt > 64) cnt = 64;
+        pthread_barrier_init(&blk.waves[w].bar, nullptr, cnt);
+    }
+    std::vector<std::thread> ts;
+    ts.reserve(nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        ts.emplace_back([&, t]() {
+            cur_block = &blk;
+            cur_wave = &blk.waves[t / 64];
+            lane = t % 64;
+            xcnt = 0;
+            blockDim = block;
+            gridDim = grid;
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        blockIdx = dim3(bx, by, bz);
+                        body();
+                        pthread_barrier_wait(&blk.bar);
+                    }
+        });
+    }
+    for (auto& th : ts) th.join();
+    pthread_barrier_destroy(&blk.bar);
+    for (int w = 0; w < nwaves; ++w) pthread_barrier_destroy(&blk.waves[w].bar);
+}
+}  // namespace emul
+
+#define MVS_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    emul::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }

@@ -1,0 +1,183 @@
+"""Kernel LOGIC checks without a GPU: the product's kernel sources compiled for the host
+(tests/cpu_emul) and driven through the product's Python wrappers, compared with the oracle.
+(The real parity tests are the -m gpu ones; these catch index-map / fragment-layout / reduction
+bugs in the build container.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_l1, state_dict_from
+from emul_util import emul_lib  # noqa: F401
+from oracle import ref_torch as R
+
+torch.set_num_threads(4)
+
+
+def _cams(b, ns, h, w, gen):
+    K, E = R.synthetic_cameras(ns + 1, h, w, 4 * w)
+    P = E.clone()
+    P[:, :3, :4] = K @ E[:, :3, :4]
+    rots, transs = [], []
+    for s in range(1, ns + 1):
+        r, t = R.relative_projection(P[s:s + 1].repeat(b, 1, 1), P[0:1].repeat(b, 1, 1))
+        rots.append(r)
+        transs.append(t)
+    return torch.stack(rots, 1), torch.stack(transs, 1)
+
+
+@pytest.mark.parametrize("c,ns,per_pixel,alias,ac", [(8, 1, False, False, False), (16, 2, True, True, False),
+                                                     (32, 2, False, False, True), (32, 4, False, False, False)])
+def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    b, d, h, w = 2, 5, 12, 20
+    rot, trans = _cams(b, ns, h, w, g)
+    ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+    srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
+    if per_pixel:
+        depth = 450 + 30 * torch.rand(b, 1, h, w, generator=g) + 20.0 * torch.arange(d).view(1, d, 1, 1)
+    else:
+        depth = (430 + 35.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, align_corners=ac, ms_alias=alias)
+    assert var.is_contiguous(memory_format=torch.channels_last_3d)
+    gup = torch.randn(var.shape, generator=g)
+    var.backward(gup)
+    got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
+    for t in [ref] + srcs:
+        t.grad = None
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth,
+                                 ms_alias=alias, align_corners=ac)
+    exp.backward(gup)
+    assert float((var - exp).abs().max()) < 2e-5
+    for a, t in zip(got, [ref] + srcs):
+        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+def test_homo_warping_golden(emul_lib):
+    from mvs_amd.jdacs.models.module import homo_warping
+    g = load_golden("g1_homo_warping_a")
+    src = g["src_fea"].clone().requires_grad_(True)
+    out = homo_warping(src, g["src_proj"], g["ref_proj"], g["depth_values"])
+    assert float((out - g["out"]).abs().max()) < 2e-5
+    out.backward(g["grad_out"])
+    assert float((src.grad - g["grad_src"]).abs().max()) < 1e-4
+
+
+def test_softargmin_golden(emul_lib):
+    from mvs_amd import ops
+    g = load_golden("g5_softargmin")
+    lg = g["logits"].clone().requires_grad_(True)
+    depth, conf = ops.softargmin_conf(lg, g["depth_values"])
+    assert float((depth - g["depth"]).abs().max()) < 1e-3
+    assert float((conf - g["conf"]).abs().max()) < 1e-5
+    depth.backward(g["grad_depth"])
+    assert float((lg.grad - g["grad_logits"]).abs().max()) < 1e-5 * float(g["grad_logits"].abs().max()) + 1e-5
+    # per-pixel hypotheses, small D (CVP refine levels) -> DS=1 kernel
+    gen = torch.Generator().manual_seed(5)
+    lg2 = torch.randn(1, 8, 6, 70, generator=gen) * 3
+    hyp = 500 + torch.rand(1, 8, 6, 70, generator=gen) * 50
+    d2, c2 = ops.softargmin_conf(lg2, hyp)
+    e2, ec2, _ = R.softargmin_conf(lg2, hyp)
+    assert float((d2 - e2).abs().max()) < 1e-3 and float((c2 - ec2).abs().max()) < 1e-5
+
+
+CONV_CASES = [
+    # cin, cout, stride, transposed, (d,h,w)
+    (8, 16, 1, False, (4, 6, 20)),
+    (16, 8, 1, False, (5, 4, 16)),
+    (32, 8, 1, False, (4, 4, 18)),
+    (8, 16, 2, False, (4, 8, 20)),
+    (16, 32, 2, False, (6, 4, 8)),
+    (16, 8, 2, True, (2, 4, 10)),
+    (64, 32, 2, True, (2, 2, 4)),
+    (64, 32, 1, True, (3, 4, 6)),
+    (8, 1, 1, False, (4, 5, 18)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", CONV_CASES)
+def test_conv3d_family(emul_lib, cin, cout, stride, transposed, dims):
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    b = 2 if max(dims) <= 16 else 1
+    x = torch.randn(b, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if transposed:
+        yr = F.conv_transpose3d(xr, wr, stride=stride, padding=1, output_padding=stride - 1)
+    else:
+        yr = F.conv3d(xr, wr, stride=stride, padding=1)
+    y, parts = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
+    assert y.shape == yr.shape
+    assert float((y - yr).abs().max()) < 2e-4
+    s = parts.sum(0)
+    assert torch.allclose(s[0], yr.detach().sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+    assert torch.allclose(s[1], (yr.detach() ** 2).sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed)
+    assert float((gx - xr.grad).abs().max()) < 3e-4
+    gw = ops.conv3d_wgrad(x, gy, wshape, stride, transposed)
+    assert float((gw - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+
+
+def test_conv_epilogue_and_bn(emul_lib):
+    from mvs_amd import ops
+    from mvs_amd.nn3d import ConvBnReLU3D, DeconvBnReLU3D
+    g = torch.Generator().manual_seed(9)
+    for mod_t, ref_mod, xs in ((ConvBnReLU3D(8, 16, stride=2), None, (1, 8, 4, 8, 16)),
+                               (DeconvBnReLU3D(16, 8, stride=2), None, (1, 16, 2, 4, 8))):
+        transposed = isinstance(mod_t, DeconvBnReLU3D)
+        conv = mod_t[0] if transposed else mod_t.conv
+        bn = mod_t[1] if transposed else mod_t.bn
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5, generator=g)
+            bn.bias.uniform_(-0.3, 0.3, generator=g)
+        import copy
+        conv_r, bn_r = copy.deepcopy(conv), copy.deepcopy(bn)
+        x = torch.randn(xs, generator=g)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        mod_t.train()
+        bn_r.train()
+        yr0 = F.relu(bn_r(conv_r(xb)))
+        skip = torch.randn(yr0.shape, generator=g)
+        sa, sb = skip.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        y = mod_t(xa, skip=sa)
+        yr = sb + yr0
+        assert float((y - yr).abs().max()) < 2e-4
+        gy = torch.randn(yr.shape, generator=g)
+        y.backward(gy)
+        yr.backward(gy)
+        assert float((xa.grad - xb.grad).abs().max()) < 1e-3
+        assert float((sa.grad - sb.grad).abs().max()) == 0
+        assert rel_l1(conv.weight.grad, conv_r.weight.grad) < 1e-3
+        assert rel_l1(bn.weight.grad, bn_r.weight.grad) < 1e-3 and rel_l1(bn.bias.grad, bn_r.bias.grad) < 1e-3
+        assert torch.allclose(bn.running_mean, bn_r.running_mean, atol=1e-5)
+        assert torch.allclose(bn.running_var, bn_r.running_var, atol=1e-5, rtol=1e-4)
+        assert int(bn.num_batches_tracked) == 1
+        mod_t.eval()
+        bn_r.eval()
+        with torch.no_grad():
+            ye = mod_t(x, skip=skip)
+            yre = skip + F.relu(bn_r(conv_r(x)))
+        assert float((ye - yre).abs().max()) < 2e-4
+
+
+def test_costregnet_golden(emul_lib):
+    from mvs_amd.jdacs.models.mvsnet import CostRegNet
+    g = load_golden("g4_costregnet_mvs")
+    net = CostRegNet()
+    net.load_state_dict(state_dict_from(g))
+    net.train()
+    x = g["x"].clone().requires_grad_(True)
+    y = net(x)
+    assert float((y - g["y_train"]).abs().max()) < 1e-3 * max(1.0, float(g["y_train"].abs().max()))
+    y.backward(g["grad_out"])
+    assert rel_l1(x.grad, g["grad_x"]) < 5e-3
+    for k, p in net.named_parameters():
+        assert rel_l1(p.grad, g["grad." + k]) < 5e-3, k
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith("after1.") and "num_batches" not in k:
+            assert torch.allclose(sd[k[7:]], v, atol=1e-5, rtol=1e-3), k
