@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- depth-samples/s of the MVSNet hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic DTU-shaped input on every rank:
+BASELINE config 2 -- MVSNet (refine off), N=3 views, 640x512 images, D=192, fp32, forward + loss
+(mvsnet_loss, jdacs/models/mvsnet.py:164) + backward + gradient all-reduce (RCCL, N>1) + Adam step.
+1 sample per GPU per step (weak scaling, like the reference's batch 1/GPU recipe, jdacs/train.sh).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+# config 2 of BASELINE.json
+NVIEWS, IMG_H, IMG_W, NDEPTH, FEAT_C = 3, 512, 640, 192, 32
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+
+
+def algorithmic_work():
+    """Per-launch algorithmic bytes / flops (stated in DESIGN.md)."""
+    hf, wf = IMG_H // 4, IMG_W // 4
+    vox = NDEPTH * hf * wf
+    return {
+        "sweep_fwd": ("hbm", NVIEWS * FEAT_C * hf * wf * 4 + FEAT_C * vox * 4),            # 511 180 800 B
+        "sweep_bwd": ("hbm", FEAT_C * vox * 4 + 2 * NVIEWS * FEAT_C * hf * wf * 4),       # 519 045 120 B
+        "conv0_fwd": ("mfma", 2 * 27 * 32 * 8 * vox),                                     # 54.4 GFLOP
+        "conv0_wgrad": ("mfma", 2 * 27 * 32 * 8 * vox),
+        "conv0_dgrad": ("mfma", 2 * 27 * 32 * 8 * vox),
+    }
+
+
+def cpu_baseline(net_state, seed):
+    """The oracle (a torch-ops port of the reference path) timed on this box's host cores on a bounded
+    sample of the same workload: ONE config-2 training sample (forward + loss + backward)."""
+    from oracle import ref_torch as R
+    cores = torch.get_num_threads()
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net_state)
+    oracle.train()
+    small = R.synthetic_mvsnet_inputs(1, NVIEWS, 64, 96, 16, seed=seed)
+    oracle(*small)["depth"].mean().backward()  # thread-pool / allocator warm-up on a tiny case
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=seed)
+    gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0)
+    t0 = time.perf_counter()
+    out = oracle(imgs, proj, dv)
+    R.mvsnet_loss(out["depth"], gt, torch.ones_like(gt)).backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "depth-samples/s", "cores": cores, "kind": "port",
+            "sample": "1 sample of the same workload (MVSNet N=3 640x512 D=192 fp32 fwd+loss+bwd), "
+                      "oracle/ref_torch.py on CPU, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="extra untimed pass bracketing EVERY C-ABI call with HIP events (diagnostics to stderr)")
+    args = ap.parse_args()
+
+    import mvs_amd  # noqa: F401
+    from mvs_amd import _lib, dist as mdist
+    from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
+    from oracle.ref_torch import synthetic_mvsnet_inputs  # input generator only (shared synthetic cameras)
+
+    rank, world, local = mdist.init_from_env("nccl")
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("warning: --gpus %d but WORLD_SIZE %d\n" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = True  # as the reference does (jdacs/train.py:35); FeatureNet uses MIOpen
+
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    mdist.broadcast_parameters(net)
+    bucket = mdist.FlatGradBucket(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+
+    imgs, proj, dv = synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=1 + rank)
+    imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
+    gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0, device=dev)
+    mask = torch.ones_like(gt)
+
+    def step():
+        bucket.zero()
+        out = net(imgs, proj, dv)
+        loss = mvsnet_loss(out["depth"], gt, mask)
+        loss.backward()
+        bucket.all_reduce()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = _lib.get()
+    for _ in range(args.warmup):
+        step()
+    # live HIP-event timing of the roofline kernels over the timed region, on the launch stream
+    work = algorithmic_work()
+    tagmap = {
+        "sweep_fwd": ("mvs_plane_sweep_variance_fwd", "sweep_fwd:N3:C32:1x192x128x160"),
+        "sweep_bwd": ("mvs_plane_sweep_variance_bwd", "sweep_bwd:N3:C32:1x192x128x160"),
+        "conv0_fwd": ("mvs_conv3d_fwd", "fwd:32>8:s1:1x192x128x160"),
+        "conv0_wgrad": ("mvs_conv3d_wgrad", "wgrad:32>8:s1:1x192x128x160"),
+        "conv0_dgrad": ("mvs_conv3d_dgrad", "dgrad:32>8:s1:1x192x128x160"),
+    }
+    timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
+    lib.profiler = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.profiler = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    lossv = float(loss)
+
+    if rank == 0:
+        summ = timer.summary()
+        kernels = {}
+        for key, (name, tag) in tagmap.items():
+            if (name, tag) in summ:
+                calls, ms = summ[(name, tag)]
+                bound, amount = work[key]
+                if bound == "hbm":
+                    ach, peak, unit = amount / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+                else:
+                    ach, peak, unit = amount / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                kernels[key] = {"bound": bound, "ms": ms, "achieved": ach, "peak": peak, "unit": unit,
+                                "frac": ach / peak, "calls": calls}
+        dom = max((k for k in kernels if kernels[k]["bound"] == "mfma"), key=lambda k: kernels[k]["ms"], default=None)
+        roof = None
+        if dom is not None:
+            roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
+                    "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
+                    "traffic": None, "ms": kernels[dom]["ms"]}
+        res = {
+            "metric": "depth-samples/sec (N=3, 640x512, D=192)", "value": world * args.steps / dt,
+            "unit": "depth-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MVSNet N=3 640x512 D=192 fp32 forward+loss+backward+allreduce+Adam, "
+                                   "1 sample/GPU/step (BASELINE configs[1])",
+                       "views": NVIEWS, "image": [IMG_H, IMG_W], "depth_planes": NDEPTH,
+                       "global_batch": world, "parallelism": "dp%d" % world},
+            "roofline": roof, "kernels": kernels, "final_loss": lossv,
+            "grad_bucket_bytes": bucket.nbytes,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(state0, 1)
+            except Exception as e:  # the bench line must still come out
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if args.time_all_kernels:
+            t_all = _lib.KernelTimer(None)
+            lib.profiler = t_all
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            lib.profiler = None
+            rows = sorted(((ms * c / 3.0, n, t, c // 3, ms) for (n, t), (c, ms) in t_all.summary().items()), reverse=True)
+            tot = sum(r[0] for r in rows)
+            sys.stderr.write("---- per-step kernel time by C-ABI call (HIP events), total %.3f ms ----\n" % tot)
+            for r in rows:
+                sys.stderr.write("%8.3f ms/step  x%d  %8.3f ms  %-32s %s\n" % (r[0], r[3], r[4], r[1], r[2]))
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,14 +59,24 @@ class MvsLib:
         self.path = path
         self.device_type = device_type
         self.cdll = C.CDLL(path)
+        self.profiler = None  # optional KernelTimer (HIP-event timing per C-ABI call, used by bench.py)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
             setattr(self, "_" + name, fn)
 
-    def call(self, name: str, *args):
-        rc = getattr(self, "_" + name)(*args)
+    def call(self, name: str, *args, tag: str = ""):
+        prof = self.profiler
+        if prof is not None and prof.wants(name, tag):
+            import torch
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()  # current stream == the stream the kernel is enqueued on (ops._stream)
+            rc = getattr(self, "_" + name)(*args)
+            ev1.record()
+            prof.add(name, tag, ev0, ev1)
+        else:
+            rc = getattr(self, "_" + name)(*args)
         if rc != 0:
             msg = self._mvs_last_error().decode("utf-8", "replace")
             if rc in (-1, -2, -4):
@@ -85,3 +95,26 @@ def get() -> MvsLib:
     if _INSTANCE is None:
         _INSTANCE = MvsLib()
     return _INSTANCE
+
+
+class KernelTimer:
+    """HIP-event timing of individual C-ABI calls on the stream they are launched on.
+    ``only``: None = every call, or a set of call names / tags."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.events = {}
+
+    def wants(self, name, tag):
+        return self.only is None or name in self.only or tag in self.only
+
+    def add(self, name, tag, ev0, ev1):
+        self.events.setdefault((name, tag), []).append((ev0, ev1))
+
+    def summary(self):
+        """{(name, tag): (calls, mean_ms)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for k, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[k] = (len(ms), sum(ms) / len(ms))
+        return out

@@ -94,7 +94,8 @@ class PlaneSweepVariance(torch.autograd.Function):
         trans_c = trans.reshape(b, n - 1, 3).contiguous().float()
         var = empty_cl3(b, c, nd, h, w, ref)
         lib.call("mvs_plane_sweep_variance_fwd", _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c), _p(depth_c),
-                 per_pixel, b, n, c, nd, h, w, int(align_corners), int(ms_alias), _p(var), _stream(ref))
+                 per_pixel, b, n, c, nd, h, w, int(align_corners), int(ms_alias), _p(var), _stream(ref),
+                 tag="sweep_fwd:N%d:C%d:%dx%dx%dx%d" % (n, c, b, nd, h, w))
         ctx.save_for_backward(ref_c, depth_c, rot_c, trans_c, *srcs_c)
         ctx.cfg = (per_pixel, int(align_corners), int(ms_alias))
         return var
@@ -112,7 +113,7 @@ class PlaneSweepVariance(torch.autograd.Function):
         gsrcs = [torch.zeros_like(s, memory_format=CL2) for s in srcs_c]
         lib.call("mvs_plane_sweep_variance_bwd", _p(g), _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c),
                  _p(depth_c), per_pixel, b, n, c, nd, h, w, align_corners, ms_alias, _p(gref), _ptr_array(gsrcs),
-                 _stream(ref_c))
+                 _stream(ref_c), tag="sweep_bwd:N%d:C%d:%dx%dx%dx%d" % (n, c, b, nd, h, w))
         return (None, None, None, None, None, gref, *gsrcs)
 
 
@@ -161,6 +162,10 @@ def _ws(lib, op, b, d, h, w, cin, cout, stride, like):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=like.device)
 
 
+def _ctag(kind, cin, cout, stride, b, d, h, w):
+    return "%s:%d>%d:s%d:%dx%dx%dx%d" % (kind, cin, cout, stride, b, d, h, w)
+
+
 def _out_dims(d, h, w, stride, transposed):
     if transposed:
         return (d * stride, h * stride, w * stride)
@@ -192,7 +197,8 @@ def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None
         if skip.shape != y.shape:
             raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(y.shape)))
     lib.call("mvs_convT3d_fwd" if transposed else "mvs_conv3d_fwd", _p(x), _p(wt), _p(y), _p(ws), b, d, h, w, cin,
-             cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(parts), _stream(x))
+             cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(parts), _stream(x),
+             tag=_ctag("fwdT" if transposed else "fwd", cin, cout, stride, b, d, h, w))
     return y, parts
 
 
@@ -206,7 +212,7 @@ def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False):
     gx = empty_cl3(b, cin, d, h, w, gy)
     ws = _ws(lib, op, b, d, h, w, cin, cout, stride, gy)
     lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(gx), _p(ws), b, d, h, w,
-             cin, cout, stride, _stream(gy))
+             cin, cout, stride, _stream(gy), tag=_ctag("dgradT" if transposed else "dgrad", cin, cout, stride, b, d, h, w))
     return gx
 
 
@@ -220,7 +226,7 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
     gw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
     ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
     lib.call("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad", _p(x), _p(gy), _p(gw), _p(ws), b, d, h, w,
-             cin, cout, stride, _stream(x))
+             cin, cout, stride, _stream(x), tag=_ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
     return gw
 
 

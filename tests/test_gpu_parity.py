@@ -1,0 +1,311 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against the oracle.
+
+Small cases: oracle on CPU + committed golden fixtures.  BASELINE config sizes: oracle evaluated with
+the same torch ops on the GPU (it is device agnostic) plus size-independent properties (linearity of
+the warp, zero variance for identical views, softmax normalisation)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_l1, state_dict_from
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from mvs_amd import _lib
+    _lib._INSTANCE = None
+    lib = _lib.get()
+    assert lib.raw("mvs_is_emulation") == 0  # the product library, not the test emulation
+    return torch.device("cuda:0")
+
+
+def _cams(b, ns, h, w):
+    K, E = R.synthetic_cameras(ns + 1, h, w, 4 * w)
+    P = E.clone()
+    P[:, :3, :4] = K @ E[:, :3, :4]
+    rots, transs = [], []
+    for s in range(1, ns + 1):
+        r, t = R.relative_projection(P[s:s + 1].repeat(b, 1, 1), P[0:1].repeat(b, 1, 1))
+        rots.append(r)
+        transs.append(t)
+    return torch.stack(rots, 1), torch.stack(transs, 1)
+
+
+@pytest.mark.parametrize("c,ns,per_pixel,alias,ac,dims", [
+    (8, 1, False, False, False, (5, 12, 20)),
+    (16, 2, True, True, False, (8, 24, 36)),
+    (32, 2, False, False, False, (48, 32, 40)),       # BASELINE config 1 cost volume
+    (32, 2, False, False, True, (16, 30, 44)),
+    (32, 4, False, False, False, (12, 20, 28)),       # N=5 (config 3 view count)
+    (32, 6, False, False, False, (6, 16, 24)),        # N=7 (config 5 view count)
+    (16, 5, False, True, False, (6, 16, 24)),         # runtime-NS path
+])
+def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    b = 2
+    d, h, w = dims
+    rot, trans = _cams(b, ns, h, w)
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    if per_pixel:
+        depth = 450 + 30 * torch.rand(b, 1, h, w, generator=g) + 20.0 * torch.arange(d).view(1, d, 1, 1)
+    else:
+        depth = (430 + 9.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    refg = ref.to(dev).requires_grad_(True)
+    srcg = [s.to(dev).requires_grad_(True) for s in srcs]
+    var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev), align_corners=ac,
+                                   ms_alias=alias)
+    gup = torch.randn(var.shape, generator=g)
+    var.backward(gup.to(dev))
+    refc = ref.clone().requires_grad_(True)
+    srcc = [s.clone().requires_grad_(True) for s in srcs]
+    exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth,
+                                 ms_alias=alias, align_corners=ac)
+    exp.backward(gup)
+    # white-noise features (unit variance, steep gradients): abs 1e-4 on the volume covers the 1-ulp
+    # differences of the fp32 coordinate chain between devices
+    assert float((var.cpu() - exp).abs().max()) < 1e-4
+    for a, t in zip([refg] + srcg, [refc] + srcc):
+        assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+def test_golden_homo_warping_and_proj_cost(dev):
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.module import homo_warping
+    for tag in "ab":
+        g = load_golden("g1_homo_warping_" + tag)
+        src = g["src_fea"].to(dev).requires_grad_(True)
+        # rot/trans from the CPU inverse so the ill-conditioned P_src P_ref^-1 is identical on both sides
+        rot, trans = R.relative_projection(g["src_proj"], g["ref_proj"])
+        out = ops.HomoWarp.apply(src, rot.to(dev), trans.to(dev), g["depth_values"].to(dev), False)
+        assert float((out.cpu() - g["out"]).abs().max()) < 2e-5
+        out.backward(g["grad_out"].to(dev))
+        assert float((src.grad.cpu() - g["grad_src"]).abs().max()) < 2e-4
+        # public function with on-device inverse (looser: conditioning of the homography, see make_goldens.py)
+        out2 = homo_warping(g["src_fea"].to(dev), g["src_proj"].to(dev), g["ref_proj"].to(dev),
+                            g["depth_values"].to(dev))
+        assert float((out2.cpu() - g["out"]).abs().max()) < 1e-3
+    g = load_golden("g3_proj_cost")
+    rts = [R.relative_projection(R.ms_projection(g["src_in"][:, s], g["src_ex"][:, s]),
+                                 R.ms_projection(g["ref_in"], g["ref_ex"])) for s in range(2)]
+    rot = torch.stack([r for r, _ in rts], 1).to(dev)
+    trans = torch.stack([t for _, t in rts], 1).to(dev)
+    ref = g["ref_fea"].to(dev).requires_grad_(True)
+    srcs = [g["src_fea0"].to(dev).requires_grad_(True), g["src_fea1"].to(dev).requires_grad_(True)]
+    cost = ops.plane_sweep_variance(ref, srcs, rot, trans, g["hypos"].to(dev), ms_alias=True)
+    assert float((cost.cpu() - g["cost"]).abs().max()) < 2e-4
+    cost.backward(g["grad_out"].to(dev))
+    for a, k in ((ref, "grad_ref"), (srcs[0], "grad_src0"), (srcs[1], "grad_src1")):
+        assert float((a.grad.cpu() - g[k]).abs().max()) < 2e-3 * max(1.0, float(g[k].abs().max()))
+
+
+def test_golden_softargmin(dev):
+    from mvs_amd import ops
+    g = load_golden("g5_softargmin")
+    lg = g["logits"].to(dev).requires_grad_(True)
+    depth, conf = ops.softargmin_conf(lg, g["depth_values"].to(dev))
+    assert float((depth.cpu() - g["depth"]).abs().max()) < 1e-3
+    assert float((conf.cpu() - g["conf"]).abs().max()) < 1e-5
+    depth.backward(g["grad_depth"].to(dev))
+    assert float((lg.grad.cpu() - g["grad_logits"]).abs().max()) < 1e-5 * float(g["grad_logits"].abs().max()) + 1e-5
+
+
+CONV_CASES = [
+    (8, 16, 1, False, (12, 20, 36)), (16, 16, 1, False, (8, 16, 32)), (32, 8, 1, False, (16, 16, 32)),
+    (32, 32, 1, False, (6, 8, 20)), (64, 64, 1, False, (3, 4, 20)), (8, 16, 2, False, (8, 16, 40)),
+    (16, 32, 2, False, (12, 8, 20)), (32, 64, 2, False, (6, 8, 12)), (64, 32, 2, True, (3, 4, 10)),
+    (32, 16, 2, True, (6, 8, 20)), (16, 8, 2, True, (4, 8, 20)), (64, 32, 1, True, (4, 6, 10)),
+    (8, 1, 1, False, (8, 10, 34)), (16, 1, 1, False, (4, 6, 18)), (16, 32, 2, False, (5, 7, 9)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", CONV_CASES)
+def test_conv3d_family_vs_torch(dev, cin, cout, stride, transposed, dims):
+    """Every conv geometry of both regularisers vs the reference's ATen ops (CPU, fp32)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    if transposed or stride == 1 or all(s % 2 == 0 for s in dims):
+        pass
+    x = torch.randn(2, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = (F.conv_transpose3d(xr, wr, stride=stride, padding=1, output_padding=stride - 1) if transposed
+          else F.conv3d(xr, wr, stride=stride, padding=1))
+    y, parts = ops.conv3d_forward(x.to(dev), w.to(dev), stride, transposed, want_stats=True)
+    assert float((y.cpu() - yr).abs().max()) < 3e-4
+    s = parts.sum(0).cpu()
+    assert torch.allclose(s[0], yr.detach().sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
+    assert torch.allclose(s[1], (yr.detach() ** 2).sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    if not (stride == 2 and not transposed and any(s % 2 for s in dims)):
+        gx = ops.conv3d_dgrad(gy.to(dev), w.to(dev), tuple(x.shape), stride, transposed)
+        assert float((gx.cpu() - xr.grad).abs().max()) < 5e-4
+    gw = ops.conv3d_wgrad(x.to(dev), gy.to(dev), wshape, stride, transposed)
+    assert float((gw.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+
+
+def _run_regnet_golden(dev, net, g, has_second):
+    net.load_state_dict(state_dict_from(g))
+    net = net.to(dev).train()
+    x = g["x"].to(dev).requires_grad_(True)
+    y = net(x)
+    yt = g["y_train"] if g["y_train"].dim() == 5 else g["y_train"].unsqueeze(1)
+    assert float((y.cpu() - yt).abs().max()) < 1e-3 * max(1.0, float(yt.abs().max()))
+    y.backward(g["grad_out"].view_as(y).to(dev))
+    assert rel_l1(x.grad.cpu(), g["grad_x"]) < 5e-3
+    for k, p in net.named_parameters():
+        assert rel_l1(p.grad.cpu(), g["grad." + k]) < 5e-3, k
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith("after1.") and "num_batches" not in k:
+            assert torch.allclose(sd[k[7:]].cpu(), v, atol=1e-5, rtol=1e-3), k
+        if k.startswith("after1.") and "num_batches" in k:
+            assert int(sd[k[7:]]) == int(v)
+    if has_second:
+        with torch.no_grad():
+            net(g["x2"].to(dev))
+    net.eval()
+    with torch.no_grad():
+        ye = net(g["x"].to(dev))
+    yev = g["y_eval"] if g["y_eval"].dim() == 5 else g["y_eval"].unsqueeze(1)
+    assert float((ye.cpu() - yev).abs().max()) < 1e-3 * max(1.0, float(yev.abs().max()))
+
+
+def test_golden_costregnet_mvs(dev):
+    from mvs_amd.jdacs.models.mvsnet import CostRegNet
+    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_mvs"), True)
+
+
+def test_golden_mvsnet_end_to_end(dev):
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    g = load_golden("g6_mvsnet_e2e")
+    net = MVSNet(refine=False)
+    net.load_state_dict(state_dict_from(g))
+    net = net.to(dev).train()
+    cap = {}
+    hk = net.cost_regularization.register_forward_hook(lambda m, i, o: cap.update(var=i[0], logits=o))
+    out = net(g["imgs"].to(dev), g["proj"].to(dev), g["depth_values"].to(dev))
+    assert float((cap["var"].cpu() - g["train_variance"]).abs().max()) < 2e-4
+    assert rel_l1(out["depth"].cpu(), g["train_depth"]) < 1e-3          # BASELINE tolerance: 1e-3 relative L1
+    assert float((out["depth"].cpu() - g["train_depth"]).abs().mean()) < 0.5  # abs-depth L1 (mm)
+    assert float((out["photometric_confidence"].cpu() - g["train_conf"]).abs().mean()) < 2e-3
+    wts = torch.linspace(0.5, 1.5, out["depth"].numel()).view_as(out["depth"]).to(dev)
+    (out["depth"] * wts).mean().backward()
+    bad = []
+    for k, p in net.named_parameters():
+        if k.endswith("prob.bias"):
+            continue
+        if rel_l1(p.grad.cpu(), g["grad." + k]) > 3e-2:
+            bad.append((k, rel_l1(p.grad.cpu(), g["grad." + k])))
+    assert not bad, bad
+    sd = net.state_dict()
+    for k, v in g.items():
+        if k.startswith("cal."):
+            sd[k[4:]] = v.to(dev)
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        oe = net(g["imgs"].to(dev), g["proj"].to(dev), g["depth_values"].to(dev))
+    hk.remove()
+    assert rel_l1(oe["depth"].cpu(), g["eval_depth"]) < 1e-3
+    assert float((oe["photometric_confidence"].cpu() - g["eval_conf"]).abs().mean()) < 2e-3
+
+
+def test_config1_eval_plumbing(dev):
+    """BASELINE config 1: MVSNet forward, N=3, 160x128, D=48, eval mode, vs the oracle on CPU."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 3, 128, 160, 48, seed=1)
+    # calibrate BN running stats with one train pass on both, then eval
+    net = net.to(dev).train()
+    oracle.train()
+    with torch.no_grad():
+        net(imgs.to(dev), proj.to(dev), dv.to(dev))
+        oracle(imgs, proj, dv)
+    net.eval()
+    oracle.eval()
+    with torch.no_grad():
+        o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+        r = oracle(imgs, proj, dv)
+    assert o["depth"].shape == (1, 32, 40) and o["photometric_confidence"].shape == (1, 32, 40)
+    assert rel_l1(o["depth"].cpu(), r["depth"]) < 1e-3
+    assert float((o["photometric_confidence"].cpu() - r["photometric_confidence"]).abs().mean()) < 5e-3
+
+
+def test_config2_full_size_properties_and_gpu_oracle(dev):
+    """BASELINE config 2 volume (N=3, features 32x128x160, D=192): HIP vs the oracle's torch ops run
+    on the GPU, plus size-independent properties."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(21)
+    b, c, d, h, w, ns = 1, 32, 192, 128, 160, 2
+    rot, trans = _cams(b, ns, h, w)
+    feats = [F.avg_pool2d(torch.randn(b, c, h, w, generator=g), 5, 1, 2) for _ in range(ns + 1)]  # smooth-ish
+    depth = (425 + 2.65 * torch.arange(d)).unsqueeze(0)
+    fd = [f.to(dev) for f in feats]
+    rd, td, dd = rot.to(dev), trans.to(dev), depth.to(dev)
+    var = ops.plane_sweep_variance(fd[0], fd[1:], rd, td, dd)
+    exp = R.plane_sweep_variance(fd[0], fd[1:], [rd[:, i] for i in range(ns)], [td[:, i] for i in range(ns)], dd)
+    assert var.shape == (1, 32, 192, 128, 160)
+    assert float((var - exp).abs().max()) < 1e-4
+    del exp
+    # property: identical views + identity homography (align_corners=True sampling) -> variance == 0
+    eye = torch.eye(3).view(1, 1, 3, 3).repeat(1, ns, 1, 1).to(dev)
+    zero = torch.zeros(1, ns, 3, device=dev)
+    v0 = ops.plane_sweep_variance(fd[0], [fd[0]] * ns, eye, zero, dd, align_corners=True)
+    assert float(v0.abs().max()) < 1e-6
+    # property: the warp is linear in the features
+    wa = ops.HomoWarp.apply(fd[1], rd[:, 0], td[:, 0], dd, False)
+    wb = ops.HomoWarp.apply(fd[2], rd[:, 0], td[:, 0], dd, False)
+    wab = ops.HomoWarp.apply(2.0 * fd[1] - 0.5 * fd[2], rd[:, 0], td[:, 0], dd, False)
+    assert float((wab - (2.0 * wa - 0.5 * wb)).abs().max()) < 1e-5
+    del wa, wb, wab, v0
+    # soft-argmin at full size: depth within the hypothesis range, confidence in [0,1], vs GPU oracle
+    lg = torch.randn(1, d, h, w, generator=g).to(dev) * 3
+    dep, conf = ops.softargmin_conf(lg, dd)
+    e_dep, e_conf, _ = R.softargmin_conf(lg, dd)
+    assert float(dep.min()) >= 425.0 - 1e-3 and float(dep.max()) <= float(depth.max()) + 1e-3
+    assert float(conf.min()) >= 0 and float(conf.max()) <= 1 + 1e-5
+    assert float((dep - e_dep).abs().max()) < 1e-2 and float((conf - e_conf).abs().max()) < 1e-4
+
+
+def test_config2_train_step_vs_gpu_oracle(dev):
+    """MVSNet fwd+bwd at a reduced config-2 aspect (N=3, 256x320, D=96; full size is bench.py's job):
+    depth rel-L1 <= 1e-3 and parameter gradients vs the oracle's torch ops on the same GPU."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 3, 256, 320, 96, seed=1)
+    net = net.to(dev).train()
+    oracle = oracle.to(dev).train()
+    o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+    r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    gt = r["depth"].detach() + 3.0
+    mask = torch.ones_like(gt)
+    from mvs_amd.jdacs.models.mvsnet import mvsnet_loss
+    mvsnet_loss(o["depth"], gt, mask).backward()
+    R.mvsnet_loss(r["depth"], gt, mask).backward()
+    bad = []
+    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
+        if k.endswith("prob.bias"):
+            continue
+        e = rel_l1(p.grad, q.grad)
+        if e > 5e-2:
+            bad.append((k, e))
+    assert not bad, bad

@@ -1,0 +1,29 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench (+ per-kernel HIP-event table), rocprofv3 kernel stats.
+# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tests|bench|prof|all]
+set -u
+what=${1:-all}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+if [ "$what" = "tests" ] || [ "$what" = "all" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+  tail -n 40 gpurun_out/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log
+  tail -n 5 gpurun_out/smoke.log
+fi
+if [ "$what" = "bench" ] || [ "$what" = "all" ]; then
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cat gpurun_out/bench.json; tail -n 60 gpurun_out/bench.err
+fi
+if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  echo "prof exit $?"
+  find gpurun_out/prof -name "*stats*" | head; 
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 40 "$f"
+  # keep the merged-back payload small: drop the raw trace, keep the stats
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+fi
