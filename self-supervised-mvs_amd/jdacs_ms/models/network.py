@@ -1,0 +1,125 @@
+"""Drop-in for jdacs-ms/models/network.py: CVPMVSNet(args).forward(ref_img, src_imgs, ref_in, src_in,
+ref_ex, src_ex, depth_min, depth_max) -> {"depth_est_list": [finest..coarsest], "prob_confidence"}
+with identical state_dict names.  Cost volumes, the shared 3-D regulariser and soft-argmin run in HIP."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from .modules import (ALIGN_CORNERS, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, _ms_rot_trans, calDepthHypo,
+                      calSweepingDepthHypo, conditionIntrinsics, conv, proj_cost)
+
+
+class FeaturePyramid(nn.Module):
+    """network.py:16-41 -- 9 conv+LeakyReLU blocks, shared over a x0.5 image pyramid (stock PyTorch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0aa = conv(3, 64, kernel_size=3, stride=1)
+        self.conv0ba = conv(64, 64, kernel_size=3, stride=1)
+        self.conv0bb = conv(64, 64, kernel_size=3, stride=1)
+        self.conv0bc = conv(64, 32, kernel_size=3, stride=1)
+        self.conv0bd = conv(32, 32, kernel_size=3, stride=1)
+        self.conv0be = conv(32, 32, kernel_size=3, stride=1)
+        self.conv0bf = conv(32, 16, kernel_size=3, stride=1)
+        self.conv0bg = conv(16, 16, kernel_size=3, stride=1)
+        self.conv0bh = conv(16, 16, kernel_size=3, stride=1)
+
+    def _trunk(self, img):
+        f = self.conv0aa(img)
+        return self.conv0bh(self.conv0bg(self.conv0bf(self.conv0be(self.conv0bd(self.conv0bc(self.conv0bb(
+            self.conv0ba(f))))))))
+
+    def forward(self, img, scales=5):
+        fp = [self._trunk(img)]
+        for _ in range(scales - 1):
+            img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=None).detach()
+            fp.append(self._trunk(img))
+        return fp
+
+
+class CostRegNet(nn.Module):
+    """network.py:44-74; one down-sampling, even D/H/W required; weights shared by all pyramid levels."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
+        self.conv0a = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
+        self.conv1 = ConvBnReLU3D(16, 32, stride=2, kernel_size=3, pad=1)
+        self.conv2 = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
+        self.conv2a = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
+        self.conv3 = ConvBnReLU3D(32, 64, kernel_size=3, pad=1)
+        self.conv4 = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
+        self.conv4a = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
+        self.conv5 = DeconvBnReLU3D(64, 32, stride=1)
+        self.conv6 = DeconvBnReLU3D(32, 16, stride=2)
+        self.prob0 = ProbConv3d(16)
+
+    def forward(self, x):
+        if x.dim() != 5 or x.shape[1] != 16:
+            raise ValueError("CVP CostRegNet expects [B,16,D,H,W], got %s" % (tuple(x.shape),))
+        if any(s % 2 for s in x.shape[2:]):
+            raise ValueError("CVP CostRegNet needs even D,H,W, got %s" % (tuple(x.shape[2:]),))
+        conv0 = self.conv0a(self.conv0(x))
+        conv2 = self.conv2a(self.conv2(self.conv1(conv0)))
+        conv4 = self.conv4a(self.conv4(self.conv3(conv2)))
+        conv5 = self.conv5(conv4, skip=conv2)   # conv2 + relu(bn(deconv_s1(conv4)))  (network.py:71)
+        conv6 = self.conv6(conv5, skip=conv0)
+        return self.prob0(conv6).squeeze(1)
+
+
+class CVPMVSNet(nn.Module):
+    def __init__(self, args, align_corners=ALIGN_CORNERS):
+        super().__init__()
+        self.featurePyramid = FeaturePyramid()
+        self.cost_reg_refine = CostRegNet()
+        self.args = args
+        self.align_corners = align_corners
+
+    def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max):
+        a = self.args
+        depth_est_list = []
+        # feature pyramids (stock PyTorch)
+        ref_fp = self.featurePyramid(ref_img, a.nscale)
+        src_fps = [self.featurePyramid(src_imgs[:, i], a.nscale) for i in range(a.nsrc)]
+        ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_fp])
+        src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_fps[i]])
+                                 for i in range(a.nsrc)]).permute(1, 0, 2, 3, 4)
+
+        # coarse level: 48 fronto-parallel planes, fused warp + variance (alias quirk on, network.py:114-137)
+        depth_hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max)
+        rts = [_ms_rot_trans(ref_in_ms[:, -1], src_in_ms[:, i, -1], ref_ex, src_ex[:, i]) for i in range(a.nsrc)]
+        rot = torch.stack([r for r, _ in rts], 1)
+        trans = torch.stack([t for _, t in rts], 1)
+        cost_volume = ops.plane_sweep_variance(ref_fp[-1], [fp[-1] for fp in src_fps], rot, trans, depth_hypos,
+                                               align_corners=self.align_corners, ms_alias=True)
+        cost_reg = self.cost_reg_refine(cost_volume)
+        del cost_volume
+        depth, conf = ops.softargmin_conf(cost_reg, depth_hypos)
+        depth_est_list.append(depth)
+
+        # refine along the pyramid (network.py:153-180)
+        for level in range(a.nscale - 2, -1, -1):
+            depth_up = F.interpolate(depth[None, :], size=None, scale_factor=2, mode='bilinear',
+                                     align_corners=None).squeeze(0)
+            depth_hypos = calDepthHypo(a, depth_up, ref_in_ms[:, level], src_in_ms[:, :, level], ref_ex, src_ex,
+                                       depth_min, depth_max, level)
+            cost_volume = proj_cost(a, ref_fp[level], src_fps, level, ref_in_ms[:, level], src_in_ms[:, :, level],
+                                    ref_ex, src_ex[:, :], depth_hypos, align_corners=self.align_corners)
+            cost_reg2 = self.cost_reg_refine(cost_volume)
+            del cost_volume
+            depth, conf = ops.softargmin_conf(cost_reg2, depth_hypos)
+            depth_est_list.append(depth)
+
+        depth_est_list.reverse()  # [0] is the finest scale (network.py:195)
+        return {"depth_est_list": depth_est_list, "prob_confidence": conf}
+
+
+def sL1_loss(depth_est, depth_gt, mask):
+    """network.py:202-203."""
+    return F.smooth_l1_loss(depth_est[mask], depth_gt[mask], reduction='mean')
+
+
+def MSE_loss(depth_est, depth_gt, mask):
+    """network.py:206-207."""
+    return F.mse_loss(depth_est[mask], depth_gt[mask], reduction='mean')

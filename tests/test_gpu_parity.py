@@ -309,3 +309,64 @@ def test_config2_train_step_vs_gpu_oracle(dev):
         if e > 5e-2:
             bad.append((k, e))
     assert not bad, bad
+
+
+def test_golden_costregnet_cvp(dev):
+    from mvs_amd.jdacs_ms.models.network import CostRegNet
+    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_cvp"), False)
+
+
+def test_golden_cvpmvsnet_end_to_end(dev):
+    """jdacs-ms: 2-level CVP-MVSNet vs the fixture from the imported reference (train-mode BN)."""
+    from mvs_amd.jdacs_ms.models import modules as M
+    from mvs_amd.jdacs_ms.models.network import CVPMVSNet
+    g = load_golden("g7_cvpmvsnet_e2e")
+    net = CVPMVSNet(R.cvp_args(nsrc=2, nscale=2, mode="train"))
+    net.load_state_dict(state_dict_from(g), strict=False)
+    net = net.to(dev).train()
+    t = {k: g[k].to(dev) for k in ("ref_img", "src_imgs", "ref_in", "src_in", "ref_ex", "src_ex", "depth_min",
+                                   "depth_max")}
+    with torch.no_grad():
+        out = net(t["ref_img"], t["src_imgs"], t["ref_in"], t["src_in"], t["ref_ex"], t["src_ex"], t["depth_min"],
+                  t["depth_max"])
+        hyp = M.calDepthHypo(None, g["depth_up"].to(dev), t["ref_in"], t["src_in"], t["ref_ex"], t["src_ex"],
+                             None, None, 0)
+    assert float((hyp.cpu() - g["hypos0"]).abs().max()) < 1e-3
+    assert len(out["depth_est_list"]) == 2 and out["depth_est_list"][0].shape == g["depth0"].shape
+    assert rel_l1(out["depth_est_list"][1].cpu(), g["depth1"]) < 1e-3
+    assert rel_l1(out["depth_est_list"][0].cpu(), g["depth0"]) < 1e-3
+    assert float((out["prob_confidence"].cpu() - g["conf"]).abs().mean()) < 5e-3
+
+
+def test_cvp_three_level_train_step_vs_gpu_oracle(dev):
+    """CVP-MVSNet N=5 (nsrc 4), 3 levels, fwd+bwd vs the oracle's torch ops on the same GPU."""
+    from mvs_amd.jdacs_ms.models.network import CVPMVSNet
+    torch.manual_seed(0)
+    args = R.cvp_args(nsrc=4, nscale=3, mode="train")
+    net = CVPMVSNet(args)
+    oracle = R.OracleCVPMVSNet(args)
+    oracle.load_state_dict(net.state_dict())
+    g = torch.Generator().manual_seed(4)
+    ih, iw = 128, 160
+    ref_img = torch.randn(1, 3, ih, iw, generator=g)
+    src_imgs = torch.randn(1, 4, 3, ih, iw, generator=g)
+    K, E = R.synthetic_cameras(5, ih, iw, iw)
+    ins = [ref_img, src_imgs, K.unsqueeze(0), K.view(1, 1, 3, 3).repeat(1, 4, 1, 1), E[0].unsqueeze(0),
+           E[1:].unsqueeze(0), torch.tensor([425.0]), torch.tensor([425.0 + 47 * 13.5])]
+    ins = [t.to(dev) for t in ins]
+    net = net.to(dev).train()
+    oracle = oracle.to(dev).train()
+    o = net(*ins)
+    r = oracle(*ins)
+    for a, b in zip(o["depth_est_list"], r["depth_est_list"]):
+        assert rel_l1(a, b) < 1e-3
+    sum(d.mean() for d in o["depth_est_list"]).backward()
+    sum(d.mean() for d in r["depth_est_list"]).backward()
+    bad = []
+    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
+        if k.endswith("prob0.bias"):
+            continue
+        e = rel_l1(p.grad, q.grad)
+        if e > 5e-2:
+            bad.append((k, e))
+    assert not bad, bad
