@@ -45,8 +45,8 @@ def warp_pixel_coords(rot, trans, depth, height: int, width: int):
     """
     b = rot.shape[0]
     dev = rot.device
-    ys = torch.arange(0, height, dtype=torch.float32, device=dev)
-    xs = torch.arange(0, width, dtype=torch.float32, device=dev)
+    ys = torch.arange(0, height, dtype=rot.dtype, device=dev)  # fp32 in the reference; fp64 for truth tests
+    xs = torch.arange(0, width, dtype=rot.dtype, device=dev)
     y = ys.view(height, 1).expand(height, width).reshape(-1)
     x = xs.view(1, width).expand(height, width).reshape(-1)
     xyz = torch.stack((x, y, torch.ones_like(x))).unsqueeze(0).expand(b, 3, -1)

@@ -321,6 +321,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    __syncthreads();
+    int toff[SPW];   // LDS offset of this wave's tap slots (per lane for CC == 8: two taps share a fragment)
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int slot = wave + 4 * s;
+        toff[s] = slot < NSLOT ? (CC == 16 ? tapoff[slot] + l15 : tapoff[2 * slot + (l15 >> 3)] + (l15 & 7)) : 0;
+    }
+
     const int ntiles = a.B * a.ntd * a.nth * a.ntw;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
@@ -361,9 +369,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int s = 0; s < SPW; ++s) {
                 const int slot = wave + 4 * s;
                 if (slot < NSLOT) {
-                    float av;
-                    if (CC == 16) av = xt[xoff + tapoff[slot] + l15];
-                    else av = xt[xoff + tapoff[2 * slot + (l15 >> 3)] + (l15 & 7)];
+                    const float av = xt[xoff + toff[s]];
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = MVS_MFMA_16x16x4(av, bfr[nb], acc[s][nb]);
                 }
@@ -409,6 +415,124 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     for (; p < nparts; ++p) s0 += part[(size_t)p * stride + e];
     const int cg = e % CG, cx = (e / CG) % CX, tap = e / (CG * CX);
     gw[((size_t)cg * CX + cx) * 27 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 1 (the probability layer, mvsnet.py:63 / network.py:65): a 16-wide MFMA N tile would be
+// 1/16 used, so this layer runs as a direct VALU convolution: one thread per output voxel, input halo
+// tile in LDS, weights broadcast from LDS.  HBM bound (reads the 8/16-channel activation once).
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float* __restrict__ w) {
+    using G = ConvGeom<GEOM_S1>;
+    constexpr int CCP = CIN + 4;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int CQ = CIN / 4;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float wl[27 * CIN];   // [tap][ci]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+    for (int i = tid; i < 27 * CIN; i += 256) wl[i] = w[(size_t)(i % CIN) * 27 + i / CIN];   // W[0][ci][tap]
+    for (int i = tid; i < NR * CQ; i += 256) {
+        const int vox = i / CQ, cq = i % CQ;
+        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+        const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+            v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CIN + 4 * cq);
+        *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
+    }
+    __syncthreads();
+    const int pw = tid % G::TQW, ph = (tid / G::TQW) % G::TQH, pd = tid / (G::TQW * G::TQH);
+    const int base = ((pd * G::RH + ph) * G::RW + pw) * CCP;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int off = base + (((tap / 9) * G::RH + (tap / 3) % 3) * G::RW + tap % 3) * CCP;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const float4 xv = *reinterpret_cast<const float4*>(&tile[off + 4 * cq]);
+            const float4 wv = *reinterpret_cast<const float4*>(&wl[tap * CIN + 4 * cq]);
+            acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        }
+    }
+    const int qd = qd0 + pd, qh = qh0 + ph, qw = qw0 + pw;
+    if (qd < a.QD && qh < a.QH && qw < a.QW) {
+        const size_t o = (((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw;
+        float v = acc;
+        if (a.scale) v = v * a.scale[0] + a.shift[0];
+        else if (a.shift) v = v + a.shift[0];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.skip) v += a.skip[o];
+        a.y[o] = v;
+    }
+}
+
+// dW[tap][cx] = sum_pos X[pos + tap - 1][cx] * g[pos]   (CG == 1, stride 1): thread = one (tap, cx) output
+// (two for CX == 16), persistent over tiles; X halo tile and g tile in LDS.  Partial image per workgroup
+// in the generic layout [group][27][CX][1] so conv_wgrad_reduce_kernel finishes it.
+template <int CX>
+__global__ __launch_bounds__(256) void conv_wgrad_cg1_kernel(WgradArgs a) {
+    using G = ConvGeom<GEOM_S1>;
+    constexpr int CCP = CX + 1;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int NPOS = G::TQD * G::TQH * G::TQW;
+    constexpr int NOUT = 27 * CX, OPT = (NOUT + 255) / 256;
+    __shared__ float xt[NR * CCP];
+    __shared__ float gt[NPOS];
+    const int tid = threadIdx.x;
+    float acc[OPT];
+    int ooff[OPT];
+#pragma unroll
+    for (int k = 0; k < OPT; ++k) {
+        acc[k] = 0.f;
+        const int o = tid + 256 * k;   // o = tap * CX + cx
+        const int tap = o < NOUT ? o / CX : 0, cx = o % CX;
+        ooff[k] = (((tap / 9) * G::RH + (tap / 3) % 3) * G::RW + tap % 3) * CCP + cx;
+    }
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw = t % a.ntw; t /= a.ntw;
+        const int th = t % a.nth; t /= a.nth;
+        const int td = t % a.ntd; t /= a.ntd;
+        const int b = t;
+        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+        __syncthreads();
+        for (int i = tid; i < NR * CX; i += 256) {
+            const int vox = i / CX, c = i % CX;
+            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+            float v = 0.f;
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                v = a.x[((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CX + c];
+            xt[vox * CCP + c] = v;
+        }
+        {
+            const int pw = tid % G::TQW, ph = (tid / G::TQW) % G::TQH, pd = tid / (G::TQW * G::TQH);
+            const int qd = qd0 + pd, qh = qh0 + ph, qw = qw0 + pw;
+            gt[tid] = (qd < a.QD && qh < a.QH && qw < a.QW) ? a.g[(((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < NPOS; ++p) {
+            const int pw = p % G::TQW, ph = (p / G::TQW) % G::TQH, pd = p / (G::TQW * G::TQH);
+            const int xoff = ((pd * G::RH + ph) * G::RW + pw) * CCP;
+            const float gv = gt[p];
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) acc[k] = fmaf(xt[xoff + ooff[k]], gv, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < OPT; ++k) {
+        const int o = tid + 256 * k;
+        if (o < NOUT) a.part[(size_t)blockIdx.x * NOUT + o] = acc[k];
+    }
 }
 
 // ================================================================================================
@@ -461,6 +585,11 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     const int tqd = geom == GEOM_S2 ? 2 : 4;
     a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
     const int nblocks = B * a.ntd * a.nth * a.ntw;
+    if (geom == GEOM_S1 && cout == 1 && wlayout == WL_OIK && !flip && !ep.partials && (cin == 8 || cin == 16)) {
+        if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
+        else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
+        return mvs_check_launch("conv_cout1");
+    }
     const int cc = pick_cc(geom, cin);
     int NB = mvs_cdiv(cout, 16);
     if (NB == 3) NB = 4;
@@ -485,7 +614,7 @@ static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi) {
     return B * mvs_cdiv(QD, geom == GEOM_S2 ? 2 : 4) * mvs_cdiv(QH, 4) * mvs_cdiv(QW, 16);
 }
 
-static const int WGRAD_MAX_GROUPS = 256;
+static const int WGRAD_MAX_GROUPS = 768;   // persistent workgroups per (ci chunk, co chunk): ~3 per CU
 
 template <int GEOM, int CC>
 static void launch_wgrad(const WgradArgs& a, int nbw, dim3 grid, hipStream_t st) {
@@ -509,6 +638,15 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     const int cc = CX % 16 == 0 ? 16 : 8;
     const int nbw = CG > 16 ? 2 : 1;
     const int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+    if (geom == GEOM_S1 && CG == 1 && (CX == 8 || CX == 16)) {
+        if (CX == 8) MVS_LAUNCH((conv_wgrad_cg1_kernel<8>), dim3(groups), dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv_wgrad_cg1_kernel<16>), dim3(groups), dim3(256), 0, st, a);
+        int rc1 = mvs_check_launch("conv_wgrad_cg1");
+        if (rc1) return rc1;
+        const int n1 = 27 * CX;
+        MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n1, 256)), dim3(256), 0, st, (const float*)ws, groups, CX, CG, gw);
+        return mvs_check_launch("conv_wgrad_reduce");
+    }
     dim3 grid(groups, CX / cc, mvs_cdiv(CG, nbw * 16));
     if (geom == GEOM_S1) { if (cc == 16) launch_wgrad<GEOM_S1, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S1, 8>(a, nbw, grid, st); }
     else { if (cc == 16) launch_wgrad<GEOM_S2, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S2, 8>(a, nbw, grid, st); }

@@ -24,6 +24,7 @@ if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
   echo "prof exit $?"
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 40 "$f"
-  # keep the merged-back payload small: drop the raw trace, keep the stats
-  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+  # keep the merged-back payload small: keep only the stats CSVs
+  mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+  rm -rf gpurun_out/prof
 fi
