@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-reference", action="store_true",
+                    help="also time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, "
+                         "MIOpen conv3d) = 'the reference GPU path'; reported as reference_gpu_path")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="extra untimed pass bracketing EVERY C-ABI call with HIP events (diagnostics to stderr)")
     args = ap.parse_args()
@@ -179,6 +182,34 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(state0, 1)
             except Exception as e:  # the bench line must still come out
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if args.gpu_reference:
+            try:
+                from oracle import ref_torch as R
+                oracle = R.OracleMVSNet(refine=False)
+                oracle.load_state_dict(state0)
+                oracle = oracle.to(dev).train()
+                oopt = torch.optim.Adam(oracle.parameters(), lr=1e-4)
+
+                def ostep():
+                    oopt.zero_grad(set_to_none=True)
+                    o = oracle(imgs, proj, dv)
+                    R.mvsnet_loss(o["depth"], gt, mask).backward()
+                    oopt.step()
+                for _ in range(3):
+                    ostep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    ostep()
+                torch.cuda.synchronize()
+                odt = (time.perf_counter() - t1) / 5
+                res["reference_gpu_path"] = {"value": 1.0 / odt, "unit": "depth-samples/s", "ms_per_step": odt * 1e3,
+                                             "what": "oracle/ref_torch.py (stock PyTorch-ROCm ops) on the same MI355X, "
+                                                     "same step", "speedup": (world * args.steps / dt) * odt}
+                del oracle, oopt
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["reference_gpu_path"] = {"value": None, "error": repr(e)}
         if args.time_all_kernels:
             t_all = _lib.KernelTimer(None)
             lib.profiler = t_all

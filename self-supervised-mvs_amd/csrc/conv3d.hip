@@ -167,16 +167,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 tapbase = 0;
                 kk0 = chunk * KSF;
             }
-            for (int ks = 0; ks < KS; ++ks) {
-                const int kflat = 16 * ks + 4 * g;
+            // software pipeline: operands of k-step ks+1 are in flight while the MFMAs of k-step ks issue
+            float4 bf[NB], af[MB];
+            {
+                const int kflat = 4 * g;
                 const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
-                float4 bf[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ks) * NB + nb) * 64 + lane) * 4);
-                float4 af[MB];
+                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)kk0 * NB + nb) * 64 + lane) * 4);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+            }
+            for (int ks = 0; ks < KS; ++ks) {
+                float4 bn[NB], an[MB];
+                const int ksn = ks + 1 < KS ? ks + 1 : ks;   // last iteration re-reads its own operands (harmless)
+                {
+                    const int kflat = 16 * ksn + 4 * g;
+                    const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        bn[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ksn) * NB + nb) * 64 + lane) * 4);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+                }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -186,6 +199,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                         acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bf[nb].z, acc[mb][nb]);
                         acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bf[nb].w, acc[mb][nb]);
                     }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bf[nb] = bn[nb];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) af[mb] = an[mb];
             }
         }
 
@@ -365,15 +382,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             float bfr[NBW];
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) bfr[nb] = gt[p * COP + nb * 16 + l15];
+            // straight-line: all A reads first, then all MFMAs (a slot past NSLOT computes unused values from
+            // offset 0 instead of branching, which would serialise read -> MFMA)
+            float av[SPW];
 #pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                const int slot = wave + 4 * s;
-                if (slot < NSLOT) {
-                    const float av = xt[xoff + toff[s]];
+            for (int s = 0; s < SPW; ++s) av[s] = xt[xoff + toff[s]];
 #pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = MVS_MFMA_16x16x4(av, bfr[nb], acc[s][nb]);
-                }
-            }
+            for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = MVS_MFMA_16x16x4(av[s], bfr[nb], acc[s][nb]);
         }
     }
     // D layout: col = lane&15 -> co, row = 4*(lane>>4)+r -> M index

@@ -17,6 +17,7 @@
 // align_corners=True), bilinear weights w = ix - floor(ix), e = 1 - w, zero padding, no z>0 guard (Q14).
 // The reference reaches the same index through  g = p/((W-1)/2) - 1 ; ix = ((g+1)*W - 1)/2  -- the same
 // value up to fp32 rounding of the chain (tests bound both against an fp64 evaluation).
+#include <stdlib.h>
 #include "mvs_rt.h"
 
 struct SweepArgs {
@@ -98,6 +99,35 @@ __device__ __forceinline__ float4 sample4(const float* __restrict__ f, const Tap
 // pixel tile of a workgroup: 256/(C/4) pixels as TW x TH (C=32: 8x4, C=16: 8x8, C=8: 16x8)
 template <int C> struct Tile { static constexpr int TW = C == 8 ? 16 : 8, TH = (256 / (C / 4)) / TW; };
 
+// ---- footprint windows (shared by the LDS-staged forward and the LDS-privatised backward) ----
+template <int C> struct BwdCfg { static constexpr int WCAP = C == 32 ? 240 : (C == 16 ? 480 : 900), CP = C + 1; };
+
+struct Win { int x0, y0, w, h; };
+
+__device__ __forceinline__ void corner_bounds(const SweepArgs& a, const float* R, const float* T, float xa, float xb,
+                                              float ya, float yb, float da, float db, float& lox, float& hix,
+                                              float& loy, float& hiy) {
+    lox = loy = 3.0e38f;
+    hix = hiy = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float ix, iy;
+        source_index(R, T, (k & 1) ? xb : xa, (k & 2) ? yb : ya, (k & 4) ? db : da, a, ix, iy);
+        lox = fminf(lox, ix); hix = fmaxf(hix, ix); loy = fminf(loy, iy); hiy = fmaxf(hiy, iy);
+    }
+}
+
+__device__ __forceinline__ Win make_window(const SweepArgs& a, float lox, float hix, float loy, float hiy) {
+    // taps touch floor(lo) .. floor(hi)+1; clip to the image (outside taps are dropped anyway)
+    float fx0 = fminf(fmaxf(floorf(lox), 0.0f), (float)(a.W - 1)), fx1 = fminf(fmaxf(floorf(hix) + 1.0f, 0.0f), (float)(a.W - 1));
+    float fy0 = fminf(fmaxf(floorf(loy), 0.0f), (float)(a.H - 1)), fy1 = fminf(fmaxf(floorf(hiy) + 1.0f, 0.0f), (float)(a.H - 1));
+    Win w;
+    if (!(lox == lox) || !(hix == hix) || !(loy == loy) || !(hiy == hiy)) { w.x0 = w.y0 = 0; w.w = w.h = 1 << 14; return w; }
+    w.x0 = (int)fx0; w.y0 = (int)fy0; w.w = (int)fx1 - w.x0 + 1; w.h = (int)fy1 - w.y0 + 1;
+    return w;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +184,150 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_kernel(SweepArgs
     }
 }
 
+
+// Forward, LDS-staged variant.  The direct kernel above pulls every bilinear tap through the vector
+// L1 (4 taps x C*4 B per voxel and view ~ 4 GB per launch at config 2, i.e. TA bound at ~64 B/clk/CU).
+// Here the workgroup first copies each source view's footprint window of its (pixel tile x depth
+// segment) box into LDS with coalesced loads -- every source texel is fetched once per segment instead
+// of once per tap -- and the taps become ds_read_b128 (4x the L1 rate).  Window = image-clipped bounding
+// box of the 8 projected corners (the warp is projective); a tap that rounding puts outside it, or a
+// plane whose footprint does not fit, falls back to the global load, so results never depend on it.
+template <int C> struct FwdCfg { static constexpr int CPF = C + 4, WTOT = C == 32 ? 480 : (C == 16 ? 900 : 1600); };
+
+template <int C>
+__device__ __forceinline__ float4 tap_load(const float* __restrict__ win, const Win& w, bool use_win,
+                                           const float* __restrict__ f, int xi, int yi, int W, int q) {
+    const int wx = xi - w.x0, wy = yi - w.y0;
+    if (use_win && wx >= 0 && wx < w.w && wy >= 0 && wy < w.h)
+        return *reinterpret_cast<const float4*>(win + (wy * w.w + wx) * FwdCfg<C>::CPF + 4 * q);
+    return ld4(f + ((size_t)yi * W + xi) * C);
+}
+
+template <int C>
+__device__ __forceinline__ float4 sample4_win(const float* __restrict__ win, const Win& w, bool use_win,
+                                              const float* __restrict__ f, const Taps& t, int W, int q) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t.v00) { float4 a = tap_load<C>(win, w, use_win, f, t.x0, t.y0, W, q); v.x = a.x * t.w00; v.y = a.y * t.w00; v.z = a.z * t.w00; v.w = a.w * t.w00; }
+    if (t.v01) {
+        float4 a = tap_load<C>(win, w, use_win, f, t.x0 + 1, t.y0, W, q);
+        v.x = fmaf(a.x, t.w01, v.x); v.y = fmaf(a.y, t.w01, v.y); v.z = fmaf(a.z, t.w01, v.z); v.w = fmaf(a.w, t.w01, v.w);
+    }
+    if (t.v10) {
+        float4 a = tap_load<C>(win, w, use_win, f, t.x0, t.y0 + 1, W, q);
+        v.x = fmaf(a.x, t.w10, v.x); v.y = fmaf(a.y, t.w10, v.y); v.z = fmaf(a.z, t.w10, v.z); v.w = fmaf(a.w, t.w10, v.w);
+    }
+    if (t.v11) {
+        float4 a = tap_load<C>(win, w, use_win, f, t.x0 + 1, t.y0 + 1, W, q);
+        v.x = fmaf(a.x, t.w11, v.x); v.y = fmaf(a.y, t.w11, v.y); v.z = fmaf(a.z, t.w11, v.z); v.w = fmaf(a.w, t.w11, v.w);
+    }
+    return v;
+}
+
+template <int C, int NS_T>
+__global__ __launch_bounds__(256) void plane_sweep_variance_fwd_lds_kernel(SweepArgs a) {
+    constexpr int QUADS = C / 4;
+    constexpr int TW = Tile<C>::TW, TH = Tile<C>::TH;
+    constexpr int CPF = FwdCfg<C>::CPF, WCAP = FwdCfg<C>::WTOT / NS_T;
+    __shared__ __attribute__((aligned(16))) float win[NS_T * WCAP * CPF];
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int q = tid % QUADS, pl = tid / QUADS;
+    const int tx0 = (blockIdx.x % a.tiles_x) * TW, ty0 = (blockIdx.x / a.tiles_x) * TH;
+    const int x = tx0 + pl % TW, y = ty0 + pl / TW;
+    const int b = blockIdx.z;
+    const bool valid = x < a.W && y < a.H;
+    const int HW = a.H * a.W, pix = valid ? y * a.W + x : 0;
+    const int d0 = blockIdx.y * a.dslab;
+    const int d1 = min(a.D, d0 + a.dslab);
+    const float xf = (float)x, yf = (float)y;
+    const size_t fbase = (size_t)b * HW * C + 4 * q;
+    const float4 r = ld4(a.ref + fbase + (size_t)pix * C);
+    const float4 r2 = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
+    const float inv_n = 1.0f / (float)(NS_T + 1);
+    const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
+    const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
+    const float cxa = (float)tx0, cxb = (float)min(tx0 + TW - 1, a.W - 1);
+    const float cya = (float)ty0, cyb = (float)min(ty0 + TH - 1, a.H - 1);
+
+    int ds = d0;
+    while (ds < d1) {
+        int de = d1;
+        Win w[NS_T];
+        bool use[NS_T];
+        for (int it = 0; it < 12; ++it) {
+            float da, db;
+            if (a.per_pixel) {
+                float lo = 3.0e38f, hi = -3.0e38f;
+                if (valid && q == 0)
+                    for (int d = ds; d < de; ++d) {
+                        float v = a.depth[((size_t)b * a.D + d) * HW + pix];
+                        lo = fminf(lo, v); hi = fmaxf(hi, v);
+                    }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
+                __syncthreads();
+                if ((tid & 63) == 0) { red[(tid >> 6) * 2] = lo; red[(tid >> 6) * 2 + 1] = hi; }
+                __syncthreads();
+                da = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+                db = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+            } else {
+                da = a.depth[b * a.D + ds];
+                db = a.depth[b * a.D + de - 1];
+            }
+            bool fits = true;
+#pragma unroll
+            for (int s = 0; s < NS_T; ++s) {
+                float lox, hix, loy, hiy;
+                corner_bounds(a, rotb + s * 9, trb + s * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
+                w[s] = make_window(a, lox, hix, loy, hiy);
+                use[s] = (long)w[s].w * w[s].h <= WCAP;
+                fits = fits && use[s];
+            }
+            if (fits || de - ds <= 1) break;
+            de = ds + (de - ds + 1) / 2;
+        }
+        // ---- stage the windows: texel-major, quad-minor => 128-B coalesced global reads ----
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            if (!use[s]) continue;
+            const float* __restrict__ f = a.src[s] + (size_t)b * HW * C;
+            float* __restrict__ ws = win + s * WCAP * CPF;
+            for (int i = tid; i < w[s].w * w[s].h * QUADS; i += 256) {
+                const int t = i / QUADS, qq = i % QUADS;
+                const int wy = t / w[s].w, wx = t - wy * w[s].w;
+                *reinterpret_cast<float4*>(ws + t * CPF + 4 * qq) =
+                    ld4(f + ((size_t)(w[s].y0 + wy) * a.W + w[s].x0 + wx) * C + 4 * qq);
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            for (int d = ds; d < de; ++d) {
+                const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
+                float4 S = a.ms_alias ? r2 : r;
+                float4 Q = r2;
+#pragma unroll
+                for (int s = 0; s < NS_T; ++s) {
+                    float ix, iy;
+                    source_index(rotb + s * 9, trb + s * 3, xf, yf, dep, a, ix, iy);
+                    float4 v = sample4_win<C>(win + s * WCAP * CPF, w[s], use[s], a.src[s] + fbase, make_taps(ix, iy, a.H, a.W),
+                                              a.W, q);
+                    S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
+                    Q.x = fmaf(v.x, v.x, Q.x); Q.y = fmaf(v.y, v.y, Q.y); Q.z = fmaf(v.z, v.z, Q.z); Q.w = fmaf(v.w, v.w, Q.w);
+                }
+                float4 o;
+                float m;
+                m = S.x * inv_n; o.x = Q.x * inv_n - m * m;
+                m = S.y * inv_n; o.y = Q.y * inv_n - m * m;
+                m = S.z * inv_n; o.z = Q.z * inv_n - m * m;
+                m = S.w * inv_n; o.w = Q.w * inv_n - m * m;
+                *reinterpret_cast<float4*>(a.var + (((size_t)b * a.D + d) * HW + pix) * C + 4 * q) = o;
+            }
+        }
+        ds = de;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward.  With Sm = S/N:  dL/dv_i = g*(2/N)*(v_i - Sm);
 //   dL/dr = sum_d g*(2/N)*(r - Sm)            (MVSNet)
@@ -169,43 +343,18 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_kernel(SweepArgs
 // result is always complete.  Device-scope atomics drop from 4 per (voxel, view, channel) to about
 // one per (window texel, channel) per segment (~30x fewer at BASELINE config 2).
 // ------------------------------------------------------------------------------------------------
-template <int C> struct BwdCfg { static constexpr int WCAP = C == 32 ? 240 : (C == 16 ? 480 : 900), CP = C + 1; };
-
-struct Win { int x0, y0, w, h; };
-
-__device__ __forceinline__ void corner_bounds(const SweepArgs& a, const float* R, const float* T, float xa, float xb,
-                                              float ya, float yb, float da, float db, float& lox, float& hix,
-                                              float& loy, float& hiy) {
-    lox = loy = 3.0e38f;
-    hix = hiy = -3.0e38f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float ix, iy;
-        source_index(R, T, (k & 1) ? xb : xa, (k & 2) ? yb : ya, (k & 4) ? db : da, a, ix, iy);
-        lox = fminf(lox, ix); hix = fmaxf(hix, ix); loy = fminf(loy, iy); hiy = fmaxf(hiy, iy);
-    }
-}
-
-__device__ __forceinline__ Win make_window(const SweepArgs& a, float lox, float hix, float loy, float hiy) {
-    // taps touch floor(lo) .. floor(hi)+1; clip to the image (outside taps are dropped anyway)
-    float fx0 = fminf(fmaxf(floorf(lox), 0.0f), (float)(a.W - 1)), fx1 = fminf(fmaxf(floorf(hix) + 1.0f, 0.0f), (float)(a.W - 1));
-    float fy0 = fminf(fmaxf(floorf(loy), 0.0f), (float)(a.H - 1)), fy1 = fminf(fmaxf(floorf(hiy) + 1.0f, 0.0f), (float)(a.H - 1));
-    Win w;
-    if (!(lox == lox) || !(hix == hix) || !(loy == loy) || !(hiy == hiy)) { w.x0 = w.y0 = 0; w.w = w.h = 1 << 14; return w; }
-    w.x0 = (int)fx0; w.y0 = (int)fy0; w.w = (int)fx1 - w.x0 + 1; w.h = (int)fy1 - w.y0 + 1;
-    return w;
-}
-
 template <int C>
 __device__ __forceinline__ void scatter_tap(float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ g,
                                             int xi, int yi, int W, int q, const float4& gv, float wt) {
     const int wx = xi - w.x0, wy = yi - w.y0;
     if (use_win && wx >= 0 && wx < w.w && wy >= 0 && wy < w.h) {
         float* p = win + (wy * w.w + wx) * BwdCfg<C>::CP + 4 * q;
-        atomicAdd(p + 0, gv.x * wt); atomicAdd(p + 1, gv.y * wt); atomicAdd(p + 2, gv.z * wt); atomicAdd(p + 3, gv.w * wt);
+        MVS_LDS_ATOMIC_ADD(p + 0, gv.x * wt); MVS_LDS_ATOMIC_ADD(p + 1, gv.y * wt);
+        MVS_LDS_ATOMIC_ADD(p + 2, gv.z * wt); MVS_LDS_ATOMIC_ADD(p + 3, gv.w * wt);
     } else {
         float* p = g + ((size_t)yi * W + xi) * C;
-        atomicAdd(p + 0, gv.x * wt); atomicAdd(p + 1, gv.y * wt); atomicAdd(p + 2, gv.z * wt); atomicAdd(p + 3, gv.w * wt);
+        MVS_GLOBAL_ATOMIC_ADD(p + 0, gv.x * wt); MVS_GLOBAL_ATOMIC_ADD(p + 1, gv.y * wt);
+        MVS_GLOBAL_ATOMIC_ADD(p + 2, gv.z * wt); MVS_GLOBAL_ATOMIC_ADD(p + 3, gv.w * wt);
     }
 }
 
@@ -348,7 +497,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
             for (int i = tid; i < wA.w * wA.h * C; i += 256) {
                 const int c = i % C, t = i / C;
                 const float v = win[t * CP + c];
-                if (v != 0.f) atomicAdd(gp + ((size_t)(wA.y0 + t / wA.w) * a.W + wA.x0 + t % wA.w) * C + c, v);
+                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wA.y0 + t / wA.w) * a.W + wA.x0 + t % wA.w) * C + c, v);
             }
         }
         if (useB) {
@@ -356,7 +505,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
             for (int i = tid; i < wB.w * wB.h * C; i += 256) {
                 const int c = i % C, t = i / C;
                 const float v = win[(WCAP + t) * CP + c];
-                if (v != 0.f) atomicAdd(gp + ((size_t)(wB.y0 + t / wB.w) * a.W + wB.x0 + t % wB.w) * C + c, v);
+                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wB.y0 + t / wB.w) * a.W + wB.x0 + t % wB.w) * C + c, v);
             }
         }
         ds = de;
@@ -368,11 +517,39 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// MVS_SWEEP_FWD=direct selects the tap-through-L1 kernel (kept for A/B measurements); default: LDS-staged
+static int g_sweep_fwd_variant = -1;
+static bool sweep_fwd_use_lds() {
+    if (g_sweep_fwd_variant < 0) {
+        const char* e = getenv("MVS_SWEEP_FWD");
+        g_sweep_fwd_variant = (e && e[0] == 'd') ? 0 : 1;
+    }
+    return g_sweep_fwd_variant == 1;
+}
+// tuning knob for A/B measurements (tools/bench_kernels.py): "sweep_fwd" -> 0 direct, 1 LDS-staged
+extern "C" int mvs_set_tuning(const char* key, int value) {
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value ? 1 : 0; return MVS_OK; }
+    mvs_set_error("mvs_set_tuning: unknown key");
+    return MVS_ERR_UNSUPPORTED;
+}
+
 template <int C>
 static int launch_fwd(SweepArgs& a, hipStream_t st) {
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);
     a.tiles_y = mvs_cdiv(a.H, Tile<C>::TH);
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
+    if (!a.warp_only && sweep_fwd_use_lds()) {
+        bool done = true;
+        switch (a.NS) {
+            case 1: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 1>), grid, block, 0, st, a); break;
+            case 2: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 2>), grid, block, 0, st, a); break;
+            case 3: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 3>), grid, block, 0, st, a); break;
+            case 4: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 4>), grid, block, 0, st, a); break;
+            case 6: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 6>), grid, block, 0, st, a); break;
+            default: done = false;
+        }
+        if (done) return mvs_check_launch("plane_sweep_variance_fwd_lds");
+    }
     switch (a.warp_only ? 1 : a.NS) {
         case 1: MVS_LAUNCH((plane_sweep_variance_fwd_kernel<C, 1>), grid, block, 0, st, a); break;
         case 2: MVS_LAUNCH((plane_sweep_variance_fwd_kernel<C, 2>), grid, block, 0, st, a); break;

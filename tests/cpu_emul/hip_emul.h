@@ -150,3 +150,6 @@ void launch(dim3 grid, dim3 block, F body) {
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+
+#define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
+#define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at BASELINE config-2 shapes (HIP events, one process, interleaved A/B).
+    python tools/bench_kernels.py [--reps 20]   -> table on stdout + gpurun_out/kernels.json"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+import mvs_amd  # noqa: F401
+from mvs_amd import _lib, ops
+from oracle import ref_torch as R  # synthetic cameras only
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in evs)
+    return ms[len(ms) // 2], ms[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(0)
+    B, C, D, H, W, NS = 1, 32, 192, 128, 160, 2
+    K, E = R.synthetic_cameras(NS + 1, H, W, 4 * W)
+    P = E.clone()
+    P[:, :3, :4] = K @ E[:, :3, :4]
+    rt = [R.relative_projection(P[s:s + 1], P[0:1]) for s in range(1, NS + 1)]
+    rot = torch.stack([r for r, _ in rt], 1).to(dev)
+    trans = torch.stack([t for _, t in rt], 1).to(dev)
+    feats = [F.avg_pool2d(torch.randn(B, C, H, W, generator=g), 3, 1, 1).to(dev).contiguous(memory_format=torch.channels_last)
+             for _ in range(NS + 1)]
+    depth = (425 + 2.65 * torch.arange(D)).unsqueeze(0).to(dev)
+    vox = D * H * W
+    rows = []
+
+    def add(name, fn, bound, amount):
+        med, mn = timeit(fn, args.reps)
+        if bound == "hbm":
+            ach, peak, unit = amount / (med * 1e-3) / 1e9, 8000.0, "GB/s"
+        else:
+            ach, peak, unit = amount / (med * 1e-3) / 1e12, 157.3, "TFLOP/s"
+        rows.append({"kernel": name, "ms_median": med, "ms_min": mn, "bound": bound, "achieved": ach, "unit": unit,
+                     "frac": ach / peak})
+        print("%-34s %8.3f ms (min %7.3f)  %9.1f %-8s %5.1f%% of %s peak" % (name, med, mn, ach, unit, 100 * ach / peak,
+                                                                            bound), flush=True)
+
+    k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
+    with torch.no_grad():
+        for variant, label in ((0, "direct"), (1, "lds")):
+            lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+            add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
+    # backward of the sweep
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    v = ops.plane_sweep_variance(fr[0], fr[1:], rot, trans, depth)
+    gv = torch.randn_like(v)
+    add("sweep_bwd", lambda: torch.autograd.grad(v, fr, gv, retain_graph=True), "hbm", C * vox * 4 + 2 * (NS + 1) * C * H * W * 4)
+    del v, gv, fr
+    # conv0 family
+    w0 = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.05).to(dev)
+    fl0 = 2 * 27 * 32 * 8 * vox
+    with torch.no_grad():
+        add("conv0 fwd 32>8", lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
+        y0, _ = ops.conv3d_forward(var, w0, 1, False)
+        gy0 = torch.randn_like(y0)
+        add("conv0 dgrad", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
+        add("conv0 wgrad", lambda: ops.conv3d_wgrad(var, gy0, tuple(w0.shape), 1, False), "mfma", fl0)
+        # L0 8-channel layers
+        w1 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
+        add("conv1 fwd 8>16 s2", lambda: ops.conv3d_forward(y0, w1, 2, False, want_stats=True), "mfma", 2 * 27 * 8 * 16 * vox / 8)
+        y1, _ = ops.conv3d_forward(y0, w1, 2, False)
+        gy1 = torch.randn_like(y1)
+        add("conv1 dgrad (TR2 16>8)", lambda: ops.conv3d_dgrad(gy1, w1, tuple(y0.shape), 2, False), "mfma", 2 * 27 * 8 * 16 * vox / 8)
+        add("conv1 wgrad", lambda: ops.conv3d_wgrad(y0, gy1, tuple(w1.shape), 2, False), "mfma", 2 * 27 * 8 * 16 * vox / 8)
+        wp = (torch.randn(1, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
+        bp = torch.zeros(1, device=dev)
+        add("prob fwd 8>1", lambda: ops.conv3d_forward(y0, wp, 1, False, shift=bp), "hbm", 9 * vox * 4)
+        gp = torch.randn(1, 1, D, H, W, device=dev)
+        add("prob dgrad 1>8", lambda: ops.conv3d_dgrad(gp, wp, tuple(y0.shape), 1, False), "hbm", 9 * vox * 4)
+        add("prob wgrad", lambda: ops.conv3d_wgrad(y0, gp, tuple(wp.shape), 1, False), "hbm", 9 * vox * 4)
+        # L1 16>16
+        x2 = torch.randn(1, 16, D // 2, H // 2, W // 2, device=dev).contiguous(memory_format=torch.channels_last_3d)
+        w2 = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
+        fl2 = 2 * 27 * 16 * 16 * vox / 8
+        add("conv2 fwd 16>16 @L1", lambda: ops.conv3d_forward(x2, w2, 1, False, want_stats=True), "mfma", fl2)
+        add("conv2 wgrad", lambda: ops.conv3d_wgrad(x2, x2, tuple(w2.shape), 1, False), "mfma", fl2)
+        # BN passes on the L0 activation
+        sc = torch.ones(8, device=dev)
+        sh = torch.zeros(8, device=dev)
+        yb = torch.empty_like(y0)
+        add("bn_relu_fwd L0 (8ch)", lambda: lib.call("mvs_bn_relu_fwd", y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, vox, 8,
+                                                     yb.data_ptr(), None), "hbm", 2 * 8 * vox * 4)
+        # soft-argmin
+        lg = torch.randn(1, D, H, W, device=dev) * 3
+        add("softargmin_conf fwd", lambda: ops.softargmin_conf(lg, depth), "hbm", vox * 4)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernels.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,9 +17,13 @@ if [ "$what" = "bench" ] || [ "$what" = "all" ]; then
   timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; tail -n 60 gpurun_out/bench.err
 fi
+if [ "$what" = "kernels" ] || [ "$what" = "all" ]; then
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; cat gpurun_out/kernels.log | grep -v Warning
+  [ -x tools/mfma_rate.bin ] && timeout 60 tools/mfma_rate.bin | tee gpurun_out/mfma_rate.log
+fi
 if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
       python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
   echo "prof exit $?"
   find gpurun_out/prof -name "*stats*" | head; 
