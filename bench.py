@@ -120,6 +120,15 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.get()
+    roctx = None
+    if os.environ.get("MVS_ROCTX"):  # rocprofv3 --selected-regions: collect the timed region only (no MIOpen find noise)
+        import ctypes
+        try:
+            roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+            roctx.roctxProfilerPause.argtypes = [ctypes.c_uint64]
+            roctx.roctxProfilerResume.argtypes = [ctypes.c_uint64]
+        except OSError:
+            roctx = None
     for _ in range(args.warmup):
         step()
     # live HIP-event timing of the roofline kernels over the timed region, on the launch stream
@@ -134,11 +143,15 @@ def main():
     timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
     lib.profiler = timer
     barrier()
+    if roctx is not None:
+        roctx.roctxProfilerResume(0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    if roctx is not None:
+        roctx.roctxProfilerPause(0)
     lib.profiler = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

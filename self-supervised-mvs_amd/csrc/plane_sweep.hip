@@ -185,6 +185,111 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_kernel(SweepArgs
 }
 
 
+// Forward, register-cached variant (default).  Along a depth sweep the sample point of a pixel moves by a
+// fraction of a source texel per plane (0.05-0.5 px at DTU-like geometry), so the 2x2 texel block under
+// it changes only every few planes.  Each thread keeps that block (4 taps x CPT channels) in registers and
+// re-gathers it only when floor(ix) or floor(iy) changes: vector-L1 traffic drops by the average run
+// length (~3-12x), the kernel is left with the index arithmetic and the one streaming store.
+// CPT = channels per thread (4 or 8): 8 halves the redundancy of the per-pixel index chain.
+template <int C, int CPT> struct TileC {
+    static constexpr int LPP = C / CPT, PPB = 256 / LPP, TW = PPB >= 128 ? 16 : 8, TH = PPB / TW;
+};
+
+template <int C, int NS_T, int CPT>
+__global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
+    constexpr int V = CPT / 4;                     // float4s per tap per thread
+    constexpr int LPP = TileC<C, CPT>::LPP, TW = TileC<C, CPT>::TW, TH = TileC<C, CPT>::TH;
+    const int tid = threadIdx.x;
+    const int q = tid % LPP, pl = tid / LPP;
+    const int x = (blockIdx.x % a.tiles_x) * TW + pl % TW, y = (blockIdx.x / a.tiles_x) * TH + pl / TW;
+    const int b = blockIdx.z;
+    if (x >= a.W || y >= a.H) return;  // no barriers / cross-lane ops below
+    const int HW = a.H * a.W, pix = y * a.W + x;
+    const int d0 = blockIdx.y * a.dslab;
+    const int d1 = min(a.D, d0 + a.dslab);
+    const float xf = (float)x, yf = (float)y;
+    const size_t fbase = (size_t)b * HW * C + CPT * q;
+    float4 r[V], r2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        r[k] = ld4(a.ref + fbase + (size_t)pix * C + 4 * k);
+        r2[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
+    }
+    const float inv_n = 1.0f / (float)(NS_T + 1);
+    const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
+    const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
+    // per view: homography rows applied to (x,y,1) once, cached base texel and its 2x2 block
+    float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
+    int cx[NS_T], cy[NS_T];
+    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
+#pragma unroll
+    for (int s = 0; s < NS_T; ++s) {
+        const float* R = rotb + s * 9;
+        rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
+        ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
+        rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
+        tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
+        cx[s] = -0x40000000; cy[s] = -0x40000000;
+#pragma unroll
+        for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int d = d0; d < d1; ++d) {
+        const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
+        float4 S[V], Q[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            const float iz = 1.0f / fmaf(rz[s], dep, tz[s]);
+            const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
+            const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float wx = ix - fx, wy = iy - fy;
+            const float ex = 1.0f - wx, ey = 1.0f - wy;
+            const float fxc = fminf(fmaxf(fx, -2.0f), (float)a.W), fyc = fminf(fmaxf(fy, -2.0f), (float)a.H);
+            const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;  // NaN -> outside
+            if (x0 != cx[s] || y0 != cy[s]) {
+                cx[s] = x0; cy[s] = y0;
+                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + 4 * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + 4 * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + 4 * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + 4 * k) : z4;
+                }
+            }
+            const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float4 v;
+                v.x = fmaf(t11[s][k].x, w11, fmaf(t10[s][k].x, w10, fmaf(t01[s][k].x, w01, t00[s][k].x * w00)));
+                v.y = fmaf(t11[s][k].y, w11, fmaf(t10[s][k].y, w10, fmaf(t01[s][k].y, w01, t00[s][k].y * w00)));
+                v.z = fmaf(t11[s][k].z, w11, fmaf(t10[s][k].z, w10, fmaf(t01[s][k].z, w01, t00[s][k].z * w00)));
+                v.w = fmaf(t11[s][k].w, w11, fmaf(t10[s][k].w, w10, fmaf(t01[s][k].w, w01, t00[s][k].w * w00)));
+                S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
+                Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
+                Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
+            }
+        }
+        float* __restrict__ outp = a.var + (((size_t)b * a.D + d) * HW + pix) * C + CPT * q;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float4 o;
+            float m;
+            m = S[k].x * inv_n; o.x = Q[k].x * inv_n - m * m;
+            m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
+            m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
+            m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
+            *reinterpret_cast<float4*>(outp + 4 * k) = o;
+        }
+    }
+}
+
 // Forward, LDS-staged variant.  The direct kernel above pulls every bilinear tap through the vector
 // L1 (4 taps x C*4 B per voxel and view ~ 4 GB per launch at config 2, i.e. TA bound at ~64 B/clk/CU).
 // Here the workgroup first copies each source view's footprint window of its (pixel tile x depth
@@ -358,6 +463,66 @@ __device__ __forceinline__ void scatter_tap(float* __restrict__ win, const Win& 
     }
 }
 
+
+// Register-resident 2x2 source texel block of one (pixel, channel quad, view): tap values + grad accumulators.
+struct ViewCache {
+    int cx, cy;
+    float4 t00, t01, t10, t11;   // tap values (zero where the tap is outside the image)
+    float4 g00, g01, g10, g11;   // gradient accumulated since the block was entered
+    __device__ __forceinline__ void reset() {
+        cx = cy = -0x40000000;
+        t00 = t01 = t10 = t11 = g00 = g01 = g10 = g11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    template <int C>
+    __device__ __forceinline__ void flush(int H, int W, float* __restrict__ win, const Win& w, bool use_win,
+                                          float* __restrict__ gp, int q) {
+        if (cx == -0x40000000) return;
+        const bool xin0 = cx >= 0 && cx < W, xin1 = cx + 1 >= 0 && cx + 1 < W;
+        const bool yin0 = cy >= 0 && cy < H, yin1 = cy + 1 >= 0 && cy + 1 < H;
+        if (xin0 && yin0) scatter_tap<C>(win, w, use_win, gp, cx, cy, W, q, g00, 1.0f);
+        if (xin1 && yin0) scatter_tap<C>(win, w, use_win, gp, cx + 1, cy, W, q, g01, 1.0f);
+        if (xin0 && yin1) scatter_tap<C>(win, w, use_win, gp, cx, cy + 1, W, q, g10, 1.0f);
+        if (xin1 && yin1) scatter_tap<C>(win, w, use_win, gp, cx + 1, cy + 1, W, q, g11, 1.0f);
+        g00 = g01 = g10 = g11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // move to the texel block of (ix, iy) (flush + re-gather if it changed); returns the bilinear sample, wt[4] = weights
+    template <int C>
+    __device__ __forceinline__ float4 advance(float ix, float iy, const float* __restrict__ f, int H, int W,
+                                              float* __restrict__ win, const Win& w, bool use_win,
+                                              float* __restrict__ gp, int q, float (&wt)[4]) {
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float wx = ix - fx, wy = iy - fy;
+        const float ex = 1.0f - wx, ey = 1.0f - wy;
+        const float fxc = fminf(fmaxf(fx, -2.0f), (float)W), fyc = fminf(fmaxf(fy, -2.0f), (float)H);
+        const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;
+        if (x0 != cx || y0 != cy) {
+            flush<C>(H, W, win, w, use_win, gp, q);
+            cx = x0; cy = y0;
+            const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+            const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const float* __restrict__ p = f + ((long)y0 * W + x0) * C;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            t00 = (xin0 && yin0) ? ld4(p) : z4;
+            t01 = (xin1 && yin0) ? ld4(p + C) : z4;
+            t10 = (xin0 && yin1) ? ld4(p + W * C) : z4;
+            t11 = (xin1 && yin1) ? ld4(p + W * C + C) : z4;
+        }
+        wt[0] = ey * ex; wt[1] = ey * wx; wt[2] = wy * ex; wt[3] = wy * wx;
+        float4 v;
+        v.x = fmaf(t11.x, wt[3], fmaf(t10.x, wt[2], fmaf(t01.x, wt[1], t00.x * wt[0])));
+        v.y = fmaf(t11.y, wt[3], fmaf(t10.y, wt[2], fmaf(t01.y, wt[1], t00.y * wt[0])));
+        v.z = fmaf(t11.z, wt[3], fmaf(t10.z, wt[2], fmaf(t01.z, wt[1], t00.z * wt[0])));
+        v.w = fmaf(t11.w, wt[3], fmaf(t10.w, wt[2], fmaf(t01.w, wt[1], t00.w * wt[0])));
+        return v;
+    }
+    __device__ __forceinline__ void accumulate(const float4& gv, const float (&wt)[4]) {
+        g00.x = fmaf(gv.x, wt[0], g00.x); g00.y = fmaf(gv.y, wt[0], g00.y); g00.z = fmaf(gv.z, wt[0], g00.z); g00.w = fmaf(gv.w, wt[0], g00.w);
+        g01.x = fmaf(gv.x, wt[1], g01.x); g01.y = fmaf(gv.y, wt[1], g01.y); g01.z = fmaf(gv.z, wt[1], g01.z); g01.w = fmaf(gv.w, wt[1], g01.w);
+        g10.x = fmaf(gv.x, wt[2], g10.x); g10.y = fmaf(gv.y, wt[2], g10.y); g10.z = fmaf(gv.z, wt[2], g10.z); g10.w = fmaf(gv.w, wt[2], g10.w);
+        g11.x = fmaf(gv.x, wt[3], g11.x); g11.y = fmaf(gv.y, wt[3], g11.y); g11.z = fmaf(gv.z, wt[3], g11.z); g11.w = fmaf(gv.w, wt[3], g11.w);
+    }
+};
+
 template <int C>
 __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs a) {
     constexpr int QUADS = C / 4;
@@ -370,7 +535,9 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
     const int q = tid % QUADS, pl = tid / QUADS;
     const int tx0 = (blockIdx.x % a.tiles_x) * TW, ty0 = (blockIdx.x / a.tiles_x) * TH;
     const int x = tx0 + pl % TW, y = ty0 + pl / TW;
-    const int vg = blockIdx.y;            // view group: sources 2*vg, 2*vg+1
+    const int ngroups = (NS + 1) / 2;
+    const int vg = blockIdx.y % ngroups;  // view group: sources 2*vg, 2*vg+1
+    const int slab = blockIdx.y / ngroups;  // depth slab [slab*dslab, +dslab): more workgroups than tiles alone
     const int sA = 2 * vg, sB = (2 * vg + 1 < NS) ? 2 * vg + 1 : -1;
     const int b = blockIdx.z;
     const bool valid = x < a.W && y < a.H;
@@ -387,11 +554,12 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
     const float cxa = (float)tx0, cxb = (float)min(tx0 + TW - 1, a.W - 1);
     const float cya = (float)ty0, cyb = (float)min(ty0 + TH - 1, a.H - 1);
 
-    int ds = 0;
-    while (ds < a.D) {
+    int ds = slab * a.dslab;
+    const int dend = min(a.D, ds + a.dslab);
+    while (ds < dend) {
         // ---- choose the segment [ds, de) and the windows (block-uniform arithmetic) ----
-        int de = a.D;
-        Win wA, wB;
+        int de = dend;
+        Win wA_, wB_;
         bool fits = false;
         for (int it = 0; it < 12; ++it) {
             float da, db;
@@ -416,47 +584,68 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
             }
             float lox, hix, loy, hiy;
             corner_bounds(a, rotb + sA * 9, trb + sA * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
-            wA = make_window(a, lox, hix, loy, hiy);
-            fits = (long)wA.w * wA.h <= WCAP;
+            wA_ = make_window(a, lox, hix, loy, hiy);
+            fits = (long)wA_.w * wA_.h <= WCAP;
             if (sB >= 0) {
                 corner_bounds(a, rotb + sB * 9, trb + sB * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
-                wB = make_window(a, lox, hix, loy, hiy);
-                fits = fits && (long)wB.w * wB.h <= WCAP;
+                wB_ = make_window(a, lox, hix, loy, hiy);
+                fits = fits && (long)wB_.w * wB_.h <= WCAP;
             } else {
-                wB = wA;
+                wB_ = wA_;
             }
             if (fits || de - ds <= 1) break;
             de = ds + (de - ds + 1) / 2;
         }
-        const bool useA = (long)wA.w * wA.h <= WCAP, useB = sB >= 0 && (long)wB.w * wB.h <= WCAP;
+        const bool useA = (long)wA_.w * wA_.h <= WCAP, useB = sB >= 0 && (long)wB_.w * wB_.h <= WCAP;
         // ---- zero the windows ----
         __syncthreads();
-        if (useA) for (int i = tid; i < wA.w * wA.h * CP; i += 256) win[i] = 0.f;
-        if (useB) for (int i = tid; i < wB.w * wB.h * CP; i += 256) win[WCAP * CP + i] = 0.f;
+        if (useA) for (int i = tid; i < wA_.w * wA_.h * CP; i += 256) win[i] = 0.f;
+        if (useB) for (int i = tid; i < wB_.w * wB_.h * CP; i += 256) win[WCAP * CP + i] = 0.f;
         __syncthreads();
         // ---- walk the planes of the segment ----
+        // Per scatter view the thread keeps the 2x2 source texel block under its sample point in
+        // registers -- both the tap VALUES (for v_i) and the gradient ACCUMULATORS -- and touches memory
+        // only when floor(ix)/floor(iy) changes (every ~3-12 planes): LDS float atomics run at about one
+        // lane per clock per CU, so issuing 4 taps x 4 channels of them per plane and view was the bottleneck.
         if (valid) {
+            ViewCache cA, cB;
+            cA.reset();
+            cB.reset();
+            float* const gpA = a.gsrc[sA] + fbase;
+            float* const gpB = sB >= 0 ? a.gsrc[sB] + fbase : gpA;
+            float* const winB = win + WCAP * CP;
             for (int d = ds; d < de; ++d) {
                 const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
                 const float4 g = ld4(a.gvar + (((size_t)b * a.D + d) * HW + pix) * C + 4 * q);
-                Taps tA, tB;
-                float4 vA = make_float4(0.f, 0.f, 0.f, 0.f), vB = vA;
-                if (a.warp_only) {
-                    float ix, iy;
-                    source_index(rotb, trb, xf, yf, dep, a, ix, iy);
-                    tA = make_taps(ix, iy, a.H, a.W);
-                    tB = tA;
-                } else {
-                    float4 S = a.ms_alias ? make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w) : r;
+                float4 S = a.warp_only ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                       : (a.ms_alias ? make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w) : r);
+                if (!a.warp_only)
                     for (int s = 0; s < NS; ++s) {
+                        if (s == sA || s == sB) continue;
                         float ix, iy;
                         source_index(rotb + s * 9, trb + s * 3, xf, yf, dep, a, ix, iy);
-                        Taps t = make_taps(ix, iy, a.H, a.W);
-                        float4 v = sample4(a.src[s] + fbase, t, a.W, C);
+                        float4 v = sample4(a.src[s] + fbase, make_taps(ix, iy, a.H, a.W), a.W, C);
                         S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
-                        if (s == sA) { tA = t; vA = v; }
-                        if (s == sB) { tB = t; vB = v; }
                     }
+                float4 vA, vB = make_float4(0.f, 0.f, 0.f, 0.f);
+                float wtA[4], wtB[4] = {0.f, 0.f, 0.f, 0.f};
+                {
+                    float ix, iy;
+                    source_index(rotb + sA * 9, trb + sA * 3, xf, yf, dep, a, ix, iy);
+                    vA = cA.template advance<C>(ix, iy, a.src[sA] + fbase, a.H, a.W, win, wA_, useA, gpA, q, wtA);
+                    S.x += vA.x; S.y += vA.y; S.z += vA.z; S.w += vA.w;
+                }
+                if (sB >= 0) {
+                    float ix, iy;
+                    source_index(rotb + sB * 9, trb + sB * 3, xf, yf, dep, a, ix, iy);
+                    vB = cB.template advance<C>(ix, iy, a.src[sB] + fbase, a.H, a.W, winB, wB_, useB, gpB, q, wtB);
+                    S.x += vB.x; S.y += vB.y; S.z += vB.z; S.w += vB.w;
+                }
+                float4 gA, gB;
+                if (a.warp_only) {
+                    gA = g;
+                    gB = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
                     const float4 Sm = make_float4(S.x * inv_n, S.y * inv_n, S.z * inv_n, S.w * inv_n);
                     if (vg == 0) {
                         if (a.ms_alias) {
@@ -467,68 +656,59 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
                             gr.z += g.z * two_n * (r.z - Sm.z); gr.w += g.w * two_n * (r.w - Sm.w);
                         }
                     }
-                    vA = make_float4(g.x * two_n * (vA.x - Sm.x), g.y * two_n * (vA.y - Sm.y), g.z * two_n * (vA.z - Sm.z),
+                    gA = make_float4(g.x * two_n * (vA.x - Sm.x), g.y * two_n * (vA.y - Sm.y), g.z * two_n * (vA.z - Sm.z),
                                      g.w * two_n * (vA.w - Sm.w));
-                    vB = make_float4(g.x * two_n * (vB.x - Sm.x), g.y * two_n * (vB.y - Sm.y), g.z * two_n * (vB.z - Sm.z),
+                    gB = make_float4(g.x * two_n * (vB.x - Sm.x), g.y * two_n * (vB.y - Sm.y), g.z * two_n * (vB.z - Sm.z),
                                      g.w * two_n * (vB.w - Sm.w));
                 }
-                if (a.warp_only) vA = g;
-                {
-                    float* gp = a.gsrc[sA] + fbase;
-                    if (tA.v00) scatter_tap<C>(win, wA, useA, gp, tA.x0, tA.y0, a.W, q, vA, tA.w00);
-                    if (tA.v01) scatter_tap<C>(win, wA, useA, gp, tA.x0 + 1, tA.y0, a.W, q, vA, tA.w01);
-                    if (tA.v10) scatter_tap<C>(win, wA, useA, gp, tA.x0, tA.y0 + 1, a.W, q, vA, tA.w10);
-                    if (tA.v11) scatter_tap<C>(win, wA, useA, gp, tA.x0 + 1, tA.y0 + 1, a.W, q, vA, tA.w11);
-                }
-                if (sB >= 0) {
-                    float* gp = a.gsrc[sB] + fbase;
-                    float* wb = win + WCAP * CP;
-                    if (tB.v00) scatter_tap<C>(wb, wB, useB, gp, tB.x0, tB.y0, a.W, q, vB, tB.w00);
-                    if (tB.v01) scatter_tap<C>(wb, wB, useB, gp, tB.x0 + 1, tB.y0, a.W, q, vB, tB.w01);
-                    if (tB.v10) scatter_tap<C>(wb, wB, useB, gp, tB.x0, tB.y0 + 1, a.W, q, vB, tB.w10);
-                    if (tB.v11) scatter_tap<C>(wb, wB, useB, gp, tB.x0 + 1, tB.y0 + 1, a.W, q, vB, tB.w11);
-                }
+                cA.accumulate(gA, wtA);
+                if (sB >= 0) cB.accumulate(gB, wtB);
             }
+            cA.template flush<C>(a.H, a.W, win, wA_, useA, gpA, q);
+            if (sB >= 0) cB.template flush<C>(a.H, a.W, winB, wB_, useB, gpB, q);
         }
         // ---- flush the windows ----
         __syncthreads();
         if (useA) {
             float* gp = a.gsrc[sA] + (size_t)b * HW * C;
-            for (int i = tid; i < wA.w * wA.h * C; i += 256) {
+            for (int i = tid; i < wA_.w * wA_.h * C; i += 256) {
                 const int c = i % C, t = i / C;
                 const float v = win[t * CP + c];
-                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wA.y0 + t / wA.w) * a.W + wA.x0 + t % wA.w) * C + c, v);
+                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wA_.y0 + t / wA_.w) * a.W + wA_.x0 + t % wA_.w) * C + c, v);
             }
         }
         if (useB) {
             float* gp = a.gsrc[sB] + (size_t)b * HW * C;
-            for (int i = tid; i < wB.w * wB.h * C; i += 256) {
+            for (int i = tid; i < wB_.w * wB_.h * C; i += 256) {
                 const int c = i % C, t = i / C;
                 const float v = win[(WCAP + t) * CP + c];
-                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wB.y0 + t / wB.w) * a.W + wB.x0 + t % wB.w) * C + c, v);
+                if (v != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)(wB_.y0 + t / wB_.w) * a.W + wB_.x0 + t % wB_.w) * C + c, v);
             }
         }
         ds = de;
     }
     if (valid && vg == 0 && !a.warp_only) {
-        // every (pixel, channel) of grad_ref is owned by exactly one thread of the vg==0 workgroups
-        *reinterpret_cast<float4*>(a.gref + fbase + (size_t)pix * C) = gr;
+        // one atomic per (pixel, channel, depth slab): grad_ref is zero-filled by the caller
+        float* p = a.gref + fbase + (size_t)pix * C;
+        MVS_GLOBAL_ATOMIC_ADD(p + 0, gr.x); MVS_GLOBAL_ATOMIC_ADD(p + 1, gr.y);
+        MVS_GLOBAL_ATOMIC_ADD(p + 2, gr.z); MVS_GLOBAL_ATOMIC_ADD(p + 3, gr.w);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // MVS_SWEEP_FWD=direct selects the tap-through-L1 kernel (kept for A/B measurements); default: LDS-staged
+// forward variants: 0 taps through L1 every plane, 1 LDS-staged windows, 2 register-cached taps (4 ch/thread),
+// 3 register-cached taps (8 ch/thread).  Default 3; MVS_SWEEP_FWD=<n> or mvs_set_tuning("sweep_fwd", n) for A/B.
 static int g_sweep_fwd_variant = -1;
-static bool sweep_fwd_use_lds() {
+static int sweep_fwd_variant() {
     if (g_sweep_fwd_variant < 0) {
         const char* e = getenv("MVS_SWEEP_FWD");
-        g_sweep_fwd_variant = (e && e[0] == 'd') ? 0 : 1;
+        g_sweep_fwd_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
     }
-    return g_sweep_fwd_variant == 1;
+    return g_sweep_fwd_variant;
 }
-// tuning knob for A/B measurements (tools/bench_kernels.py): "sweep_fwd" -> 0 direct, 1 LDS-staged
 extern "C" int mvs_set_tuning(const char* key, int value) {
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value ? 1 : 0; return MVS_OK; }
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
 }
@@ -538,7 +718,24 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);
     a.tiles_y = mvs_cdiv(a.H, Tile<C>::TH);
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
-    if (!a.warp_only && sweep_fwd_use_lds()) {
+    const int variant = sweep_fwd_variant();
+    if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6)) {
+        constexpr int CPT8 = C >= 16 ? 8 : 4;
+        const bool c8 = variant == 3 && CPT8 == 8;
+        if (c8) { a.tiles_x = mvs_cdiv(a.W, (TileC<C, CPT8>::TW)); a.tiles_y = mvs_cdiv(a.H, (TileC<C, CPT8>::TH)); }
+        dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
+#define MVS_CACHED_CASE(N)                                                                                      \
+    case N:                                                                                                     \
+        if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a);      \
+        else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
+        break;
+        switch (a.NS) {
+            MVS_CACHED_CASE(1) MVS_CACHED_CASE(2) MVS_CACHED_CASE(3) MVS_CACHED_CASE(4) MVS_CACHED_CASE(6)
+        }
+#undef MVS_CACHED_CASE
+        return mvs_check_launch("plane_sweep_variance_fwd_cached");
+    }
+    if (!a.warp_only && variant == 1) {
         bool done = true;
         switch (a.NS) {
             case 1: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 1>), grid, block, 0, st, a); break;
@@ -565,7 +762,14 @@ template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);
     a.tiles_y = mvs_cdiv(a.H, Tile<C>::TH);
-    dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.NS, 2), a.B), block(256);
+    const int ngroups = mvs_cdiv(a.NS, 2);
+    // depth slabs so that the launch has >= ~2048 workgroups (2 resident per CU), each >= 16 planes
+    int nslab = mvs_cdiv(2048, a.tiles_x * a.tiles_y * a.B * ngroups);
+    if (nslab > a.D / 16) nslab = a.D / 16;
+    if (nslab < 1) nslab = 1;
+    a.dslab = mvs_cdiv(a.D, nslab);
+    nslab = mvs_cdiv(a.D, a.dslab);
+    dim3 grid(a.tiles_x * a.tiles_y, ngroups * nslab, a.B), block(256);
     MVS_LAUNCH((plane_sweep_variance_bwd_kernel<C>), grid, block, 0, st, a);
     return mvs_check_launch("plane_sweep_variance_bwd");
 }
@@ -617,7 +821,7 @@ extern "C" int mvs_plane_sweep_variance_fwd(const float* ref, const float* const
     return launch_fwd<8>(a, stream);
 }
 
-// grad_ref is fully written; grad_srcs[i] must be ZERO-FILLED by the caller (accumulated atomically)
+// grad_ref and grad_srcs[i] must be ZERO-FILLED by the caller (accumulated atomically)
 extern "C" int mvs_plane_sweep_variance_bwd(const float* grad_var, const float* ref, const float* const* srcs,
                                             const float* rot, const float* trans, const float* depth,
                                             int depth_is_per_pixel, int B, int N, int C, int D, int H, int W,

@@ -218,3 +218,23 @@ def test_plane_sweep_bwd_segmented_windows(emul_lib):
     for a, t in zip(got, [ref] + srcs):
         assert float(t.grad.abs().max()) > 0
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
+    """All forward variants (taps through L1, LDS windows, register-cached 4/8 channels per thread)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(17)
+    b, c, d, h, w, ns = 1, 32, 20, 16, 24, 2
+    rot, trans = _cams(b, ns, h, w, g)
+    trans = trans * torch.tensor([3.0, 3.0, 1.0])   # several texel crossings along the sweep
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 25.0 * torch.arange(d)).unsqueeze(0)
+    emul_lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+    try:
+        var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"sweep_fwd", 3)
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    assert float((var - exp).abs().max()) < 2e-4

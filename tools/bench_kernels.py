@@ -65,9 +65,10 @@ def main():
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     with torch.no_grad():
-        for variant, label in ((0, "direct"), (1, "lds")):
+        for variant, label in ((0, "direct"), (1, "lds"), (2, "cached4"), (3, "cached8")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        lib.call("mvs_set_tuning", b"sweep_fwd", 3)
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
     # backward of the sweep
     fr = [f.clone().requires_grad_(True) for f in feats]

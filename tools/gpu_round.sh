@@ -23,8 +23,8 @@ if [ "$what" = "kernels" ] || [ "$what" = "all" ]; then
 fi
 if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
-      python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  (cd /tmp && MVS_ROCTX=1 timeout 900 rocprofv3 --kernel-trace --stats --selected-regions --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 10 --warmup 5 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
   echo "prof exit $?"
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 40 "$f"
