@@ -73,6 +73,11 @@ def main():
     ap.add_argument("--gpu-reference", action="store_true",
                     help="also time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, "
                          "MIOpen conv3d) = 'the reference GPU path'; reported as reference_gpu_path")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: replay the whole step from a captured hipGraph (torch.cuda.CUDAGraph); 0: eager launches; "
+                         "-1 (default): try the graph, fall back to eager if capture fails")
+    ap.add_argument("--torch-profile", type=str, default="",
+                    help="write a torch.profiler table (CPU + GPU, 5 steady-state steps) to this file (diagnostics)")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="extra untimed pass bracketing EVERY C-ABI call with HIP events (diagnostics to stderr)")
     args = ap.parse_args()
@@ -98,19 +103,23 @@ def main():
     net = net.to(dev).train()
     mdist.broadcast_parameters(net)
     bucket = mdist.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), capturable=True)
 
     imgs, proj, dv = synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=1 + rank)
     imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
     gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0, device=dev)
     mask = torch.ones_like(gt)
 
-    def step():
+    def fwd_bwd():
         bucket.zero()
         out = net(imgs, proj, dv)
         loss = mvsnet_loss(out["depth"], gt, mask)
         loss.backward()
-        bucket.all_reduce()
+        return loss
+
+    def step():
+        loss = fwd_bwd()
+        bucket.all_reduce()   # one RCCL all-reduce of the flat 1.35 MB bucket (no-op at world size 1)
         opt.step()
         return loss
 
@@ -120,11 +129,46 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.get()
+    eager_step = step
+    graph_mode = False
+    if args.graph != 0:
+        # The step is ~300 short launches (ours + MIOpen + ATen); replaying them from one captured hipGraph
+        # removes the host launch path from the critical path.  Same kernels, same work, same streams' order.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()       # MIOpen find + allocator warm-up must happen before capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            # two graphs with the collective launched eagerly between them, so RCCL is never captured and
+            # the same code path runs at every world size
+            graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_a):
+                static_loss = fwd_bwd()
+            with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+                opt.step()
+
+            def step():  # noqa: F811
+                graph_a.replay()
+                bucket.all_reduce()
+                graph_b.replay()
+                return static_loss
+            step()
+            torch.cuda.synchronize()
+            graph_mode = True
+        except Exception as e:
+            if args.graph == 1:
+                raise
+            sys.stderr.write("hipGraph capture failed (%r); running eager\n" % (e,))
+            step = eager_step
+            torch.cuda.synchronize()
     roctx = None
     if os.environ.get("MVS_ROCTX"):  # rocprofv3 --selected-regions: collect the timed region only (no MIOpen find noise)
         import ctypes
         try:
-            roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+            roctx = ctypes.CDLL("libroctx64.so")
             roctx.roctxProfilerPause.argtypes = [ctypes.c_uint64]
             roctx.roctxProfilerResume.argtypes = [ctypes.c_uint64]
         except OSError:
@@ -141,7 +185,8 @@ def main():
         "conv0_dgrad": ("mvs_conv3d_dgrad", "dgrad:32>8:s1:1x192x128x160"),
     }
     timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
-    lib.profiler = timer
+    if not graph_mode:
+        lib.profiler = timer   # live HIP-event brackets inside the timed region (eager mode)
     barrier()
     if roctx is not None:
         roctx.roctxProfilerResume(0)
@@ -153,6 +198,14 @@ def main():
     if roctx is not None:
         roctx.roctxProfilerPause(0)
     lib.profiler = None
+    if graph_mode:
+        # kernels inside a graph replay cannot be bracketed by events; time the very same launches with HIP
+        # events in an eager pass of the same K steps directly after the timed region (same process, same data)
+        lib.profiler = timer
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        lib.profiler = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -188,6 +241,7 @@ def main():
                        "views": NVIEWS, "image": [IMG_H, IMG_W], "depth_planes": NDEPTH,
                        "global_batch": world, "parallelism": "dp%d" % world},
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
+            "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "grad_bucket_bytes": bucket.nbytes,
         }
         if not args.no_cpu_baseline:
@@ -223,11 +277,21 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 res["reference_gpu_path"] = {"value": None, "error": repr(e)}
+        if args.torch_profile:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for _ in range(5):
+                    eager_step()
+                torch.cuda.synchronize()
+            with open(args.torch_profile, "w") as fh:
+                fh.write(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=90))
+                fh.write("\n\n")
+                fh.write(prof.key_averages().table(sort_by="cpu_time_total", row_limit=40, max_name_column_width=90))
         if args.time_all_kernels:
             t_all = _lib.KernelTimer(None)
             lib.profiler = t_all
             for _ in range(3):
-                step()
+                eager_step()
             torch.cuda.synchronize()
             lib.profiler = None
             rows = sorted(((ms * c / 3.0, n, t, c // 3, ms) for (n, t), (c, ms) in t_all.summary().items()), reverse=True)

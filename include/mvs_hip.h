@@ -35,7 +35,9 @@ typedef struct ihipStream_t* hipStream_t; /* same opaque type as <hip/hip_runtim
 int mvs_version(void);              /* 100 == 0.1.0 */
 const char* mvs_last_error(void);   /* thread-local, valid until the next failing call */
 int mvs_is_emulation(void);         /* 0 in the product library */
-int mvs_set_tuning(const char* key, int value); /* A/B knob: "sweep_fwd" 0 = taps through L1, 1 = LDS-staged (default) */
+/* A/B knobs for measurements/tests: "sweep_fwd" 0 taps through L1 | 1 LDS windows | 2,3 register-cached taps
+ * (default 3); "nt" 1 = non-temporal volume stores; "conv_split" 0 = never split Cout tiles over workgroups */
+int mvs_set_tuning(const char* key, int value);
 
 /* ---- K1/K2: homography warp + variance cost volume -------------------------------------------
  * Replaces homo_warping + the sum / sum-of-squares / variance chain:

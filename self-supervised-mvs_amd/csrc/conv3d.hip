@@ -27,6 +27,7 @@ struct ConvArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout;
     int QD, QH, QW;         // coarse-grid extents
     int ntd, nth, ntw;      // tiles per dim
+    int nb_total;           // 16-wide Cout tiles in the packed weight image; a workgroup handles NB of them from blockIdx.y*NB
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
+    const int nb0 = blockIdx.y * NB;   // first Cout tile of this workgroup (small layers split Cout over blockIdx.y)
 
     int t = blockIdx.x;
     const int tw = t % a.ntw; t /= a.ntw;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)kk0 * NB + nb) * 64 + lane) * 4);
+                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)kk0 * a.nb_total + nb0 + nb) * 64 + lane) * 4);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
             }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        bn[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ksn) * NB + nb) * 64 + lane) * 4);
+                        bn[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ksn) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
                 }
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int co = nb * 16 + l15;
+                    const int co = (nb0 + nb) * 16 + l15;
                     if (co >= a.Cout) continue;
                     float v = acc[mb][nb][r];
                     st1[nb] += v;
@@ -252,10 +254,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         if (tid < 2 * NB * 16) {
             const int stat = tid / (NB * 16), n = tid % (NB * 16);
-            if (n < a.Cout) {
+            if (nb0 * 16 + n < a.Cout) {
                 float s = 0.f;
                 for (int w = 0; w < 4; ++w) s += red[(w * NB * 16 + n) * 2 + stat];
-                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + n] = s;
+                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + nb0 * 16 + n] = s;
             }
         }
     }
@@ -563,13 +565,16 @@ static int pick_cc(int geom, int cin) {
 
 static size_t packed_floats(int geom, int cin, int cout) {
     const int cc = pick_cc(geom, cin);
-    const int nb = mvs_cdiv(cout, 16);
+    int nb = mvs_cdiv(cout, 16);
+    if (nb == 3) nb = 4;
     return (size_t)total_ksteps(geom, cin, cc) * nb * 256;
 }
 
+int g_conv_split = 1;   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
+
 template <int GEOM, int CC>
 static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
-    dim3 grid(nblocks), block(256);
+    dim3 grid(nblocks, a.nb_total / NB), block(256);
     switch (NB) {
         case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1>), grid, block, 0, st, a); break;
         case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2>), grid, block, 0, st, a); break;
@@ -610,11 +615,14 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     const int cc = pick_cc(geom, cin);
     int NB = mvs_cdiv(cout, 16);
     if (NB == 3) NB = 4;
+    a.nb_total = NB;
+    // small volumes (deep U-Net levels): too few tiles to fill 256 CUs -> one 16-wide Cout tile per workgroup
+    if (g_conv_split && nblocks < 512 && NB > 1) NB = 1;
     // pack weights into ws
     {
-        const int total = (int)((size_t)total_ksteps(geom, cin, cc) * NB * 256);
+        const int total = (int)((size_t)total_ksteps(geom, cin, cc) * a.nb_total * 256);
         MVS_LAUNCH(conv_pack_weights_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, wsrc, ws, geom, cc, cin, cout,
-                   NB, wlayout, flip, total);
+                   a.nb_total, wlayout, flip, total);
     }
     a.wp = ws;
     if (geom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)

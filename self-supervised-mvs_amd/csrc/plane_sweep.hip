@@ -36,6 +36,7 @@ struct SweepArgs {
     int warp_only;   // 1: write / back-propagate the warped volume of source 0 itself (homo_warping)
     float sx, ox, sy, oy;  // ix = px*sx + ox, iy = py*sy + oy
     int tiles_x, tiles_y;
+    int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
 struct Taps {
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
             m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
             m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
-            *reinterpret_cast<float4*>(outp + 4 * k) = o;
+            if (a.nt_store) MVS_NT_STORE4(outp + 4 * k, o);
+            else *reinterpret_cast<float4*>(outp + 4 * k) = o;
         }
     }
 }
@@ -707,7 +709,11 @@ static int sweep_fwd_variant() {
     }
     return g_sweep_fwd_variant;
 }
+static int g_sweep_nt = 0;
+extern int g_conv_split;
 extern "C" int mvs_set_tuning(const char* key, int value) {
+    if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
+    if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
@@ -719,6 +725,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     a.tiles_y = mvs_cdiv(a.H, Tile<C>::TH);
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
+    a.nt_store = g_sweep_nt;
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
         const bool c8 = variant == 3 && CPT8 == 8;

@@ -153,3 +153,4 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 
 #define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
+#define MVS_NT_STORE4(ptr, o) (*reinterpret_cast<float4*>(ptr) = (o))

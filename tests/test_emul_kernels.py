@@ -238,3 +238,24 @@ def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
         emul_lib.call("mvs_set_tuning", b"sweep_fwd", 3)
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((var - exp).abs().max()) < 2e-4
+
+
+def test_conv_multi_cout_tiles_per_workgroup(emul_lib):
+    """Large volumes keep all 16-wide Cout tiles in one workgroup (NB = 2 / 4); tiny test volumes would
+    otherwise always take the split path."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(23)
+    emul_lib.call("mvs_set_tuning", b"conv_split", 0)
+    try:
+        for cin, cout, stride, transposed, dims in ((8, 32, 1, False, (4, 4, 16)), (16, 64, 1, False, (4, 4, 16)),
+                                                    (32, 32, 2, True, (2, 4, 8))):
+            x = torch.randn(1, cin, *dims, generator=g)
+            wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+            w = torch.randn(wshape, generator=g) * 0.2
+            yr = (F.conv_transpose3d(x, w, stride=stride, padding=1, output_padding=stride - 1) if transposed
+                  else F.conv3d(x, w, stride=stride, padding=1))
+            y, parts = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
+            assert float((y - yr).abs().max()) < 2e-4
+            assert torch.allclose(parts.sum(0)[0], yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"conv_split", 1)

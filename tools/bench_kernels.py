@@ -69,6 +69,14 @@ def main():
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)
+        lib.call("mvs_set_tuning", b"nt", 1)
+        add("sweep_fwd[cached8+nt store]", lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        lib.call("mvs_set_tuning", b"nt", 0)
+        var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
+        add("calibration: fill_ 503 MB (write only)", lambda: var.fill_(1.0), "hbm", C * vox * 4)
+        tmp = torch.empty_like(var)
+        add("calibration: copy_ 503 MB (read+write)", lambda: tmp.copy_(var), "hbm", 2 * C * vox * 4)
+        del tmp
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
     # backward of the sweep
     fr = [f.clone().requires_grad_(True) for f in feats]

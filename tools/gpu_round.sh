@@ -14,7 +14,7 @@ if [ "$what" = "tests" ] || [ "$what" = "all" ]; then
   tail -n 5 gpurun_out/smoke.log
 fi
 if [ "$what" = "bench" ] || [ "$what" = "all" ]; then
-  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --gpu-reference --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; tail -n 60 gpurun_out/bench.err
 fi
 if [ "$what" = "kernels" ] || [ "$what" = "all" ]; then
