@@ -73,9 +73,11 @@ def main():
     ap.add_argument("--gpu-reference", action="store_true",
                     help="also time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, "
                          "MIOpen conv3d) = 'the reference GPU path'; reported as reference_gpu_path")
-    ap.add_argument("--graph", type=int, default=-1,
+    ap.add_argument("--feature-channels-last", type=int, default=0,
+                    help="1: run the stock-PyTorch FeatureNet in channels-last (MIOpen NHWC kernels)")
+    ap.add_argument("--graph", type=int, default=0,
                     help="1: replay the whole step from a captured hipGraph (torch.cuda.CUDAGraph); 0: eager launches; "
-                         "-1 (default): try the graph, fall back to eager if capture fails")
+                         "-1: try the graph, fall back to eager.  Default 0: the step is GPU-bound (profiles/), a replay buys nothing")
     ap.add_argument("--torch-profile", type=str, default="",
                     help="write a torch.profiler table (CPU + GPU, 5 steady-state steps) to this file (diagnostics)")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -96,14 +98,15 @@ def main():
     torch.backends.cudnn.benchmark = True  # as the reference does (jdacs/train.py:35); FeatureNet uses MIOpen
 
     torch.manual_seed(0)
-    net = MVSNet(refine=False)
+    net = MVSNet(refine=False, channels_last_features=bool(args.feature_channels_last))
     with torch.no_grad():
         net.cost_regularization.prob.weight.mul_(50.0)
     state0 = {k: v.clone() for k, v in net.state_dict().items()}
     net = net.to(dev).train()
     mdist.broadcast_parameters(net)
-    bucket = mdist.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), capturable=True)
+    # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
+    bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
+    opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True)
 
     imgs, proj, dv = synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=1 + rank)
     imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
@@ -115,6 +118,7 @@ def main():
         out = net(imgs, proj, dv)
         loss = mvsnet_loss(out["depth"], gt, mask)
         loss.backward()
+        bucket.gather()
         return loss
 
     def step():

@@ -83,7 +83,7 @@ int mvs_homo_warp_bwd(const float* grad_warped, const float* src, const float* r
 enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
        MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
 long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int W, int Cin, int Cout, int stride);
-int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int stride);
+int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin, int Cout, int stride);
 int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin, int Cout,
                    int stride, const float* scale, const float* shift, const float* skip, int relu,
                    float* stat_partials, hipStream_t stream);

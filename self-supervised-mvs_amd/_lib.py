@@ -28,7 +28,7 @@ SIGNATURES = {
     "mvs_homo_warp_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_homo_warp_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_conv3d_workspace_bytes": (_ll, [_i] * 8),
-    "mvs_conv3d_stat_rows": (_i, [_i] * 6),
+    "mvs_conv3d_stat_rows": (_i, [_i] * 8),
     "mvs_conv3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
     "mvs_conv3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),

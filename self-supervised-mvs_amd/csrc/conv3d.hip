@@ -554,6 +554,238 @@ __global__ __launch_bounds__(256) void conv_wgrad_cg1_kernel(WgradArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 8 (conv0 32->8: 68 % of the regulariser's FLOPs; mvsnet.py:40): a 16-wide MFMA N tile is half
+// empty, so this layer uses the 16-block form v_mfma_f32_4x4x1_16b_f32 instead: every MFMA is 16
+// independent (4 positions) x (4 output channels) outer products over ONE (tap, ci), i.e. 64 positions x 4
+// channels with no padding anywhere; two MFMAs (h = 0, 1) cover the 8 channels.  Measured issue rate on
+// gfx950 is 81 % of the 16x16x4 form (profiles/r01_mfma_rate.log) vs 50 % useful work there.
+// Lane l = position l of a 64-position set for the A operand (block l>>2, row l&3); the B operand is the
+// weight of channel (l&3)+4h broadcast to all blocks; D: lane holds channel (l&3)+4h of the 4 positions
+// 4*(l>>2)+r.  One ds_read_b128 per lane feeds the A operands of 4 consecutive ci (8 MFMAs per set).
+// ------------------------------------------------------------------------------------------------
+template <int CC, int NV>
+__global__ __launch_bounds__(256) void conv_c8_fwd_kernel(ConvArgs a, const float* __restrict__ w, int wlayout, int flip) {
+    constexpr int TQD = 4, TQH = 4 * NV, TQW = 16;
+    constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
+    constexpr int CCP = CC + 4, CQ = CC / 4, NR = RD * RH * RW;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float wl[27 * CQ * 2 * 4 * 4];   // [tap][cq][h][j][kk]
+    __shared__ float red[4 * 8 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * TQD, qh0 = th * TQH, qw0 = tw * TQW;
+    int baseA[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int row = (wave * NV + v) * 4 + (lane >> 4);      // row of the TQD x TQH plane of rows
+        baseA[v] = (((row / TQH) * RH + row % TQH) * RW + (lane & 15)) * CCP;
+    }
+    f32x4 acc[NV][2];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { acc[v][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[v][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nchunks = a.Cin / CC;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        for (int i = tid; i < NR * CQ; i += 256) {
+            const int vox = i / CQ, cq = i % CQ;
+            const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
+            *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
+        }
+        for (int i = tid; i < 27 * CQ * 32; i += 256) {
+            const int kk = i & 3, j = (i >> 2) & 3, h = (i >> 4) & 1, cq = (i >> 5) % CQ, tap = (i >> 5) / CQ;
+            const int co = j + 4 * h, ci = chunk * CC + 4 * cq + kk;
+            const int kidx = flip ? 26 - tap : tap;
+            float v = 0.f;
+            if (co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
+            wl[i] = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 27; ++tap) {
+            const int toff = (((tap / 9) * RH + (tap / 3) % 3) * RW + tap % 3) * CCP;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                const float4 b0 = *reinterpret_cast<const float4*>(&wl[((tap * CQ + cq) * 2 + 0) * 16 + (lane & 3) * 4]);
+                const float4 b1 = *reinterpret_cast<const float4*>(&wl[((tap * CQ + cq) * 2 + 1) * 16 + (lane & 3) * 4]);
+                float4 av[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(&tile[baseA[v] + toff + 4 * cq]);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    acc[v][0] = MVS_MFMA_4x4x1(av[v].x, b0.x, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].x, b1.x, acc[v][1]);
+                    acc[v][0] = MVS_MFMA_4x4x1(av[v].y, b0.y, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].y, b1.y, acc[v][1]);
+                    acc[v][0] = MVS_MFMA_4x4x1(av[v].z, b0.z, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].z, b1.z, acc[v][1]);
+                    acc[v][0] = MVS_MFMA_4x4x1(av[v].w, b0.w, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].w, b1.w, acc[v][1]);
+                }
+            }
+        }
+    }
+    // epilogue: lane (block bl = lane>>2, j = lane&3) holds channel j+4h of positions 4*bl + r of its set
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int bl = lane >> 2, j = lane & 3;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int row = (wave * NV + v) * 4 + (bl >> 2);
+        const int qd = qd0 + row / TQH, qh = qh0 + row % TQH;
+        if (qd >= a.QD || qh >= a.QH) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qw = qw0 + 4 * (bl & 3) + r;
+            if (qw >= a.QW) continue;
+            const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int co = j + 4 * h;
+                if (co >= a.Cout) continue;
+                float val = acc[v][h][r];
+                s1[h] += val;
+                s2[h] += val * val;
+                if (a.scale) val = val * a.scale[co] + a.shift[co];
+                else if (a.shift) val = val + a.shift[co];
+                if (a.relu) val = fmaxf(val, 0.f);
+                if (a.skip) val += a.skip[obase + co];
+                a.y[obase + co] = val;
+            }
+        }
+    }
+    if (a.partials) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float x1 = s1[h], x2 = s2[h];
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) { x1 += __shfl_xor(x1, m); x2 += __shfl_xor(x2, m); }
+            if (lane < 4) { red[(wave * 8 + lane + 4 * h) * 2] = x1; red[(wave * 8 + lane + 4 * h) * 2 + 1] = x2; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int stat = tid >> 3, co = tid & 7;
+            if (co < a.Cout) {
+                float sm = 0.f;
+                for (int wv = 0; wv < 4; ++wv) sm += red[(wv * 8 + co) * 2 + stat];
+                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] = sm;
+            }
+        }
+    }
+}
+
+
+// Weight gradient for CG == 8 (conv0, mvsnet.py:40) with the 16-block 4x4x1 MFMA: per position ONE MFMA
+// accumulates (4 taps x 16 input channels) x (4 output channels); 7 tap groups x 2 channel halves = 14 MFMAs
+// per position, 96 % useful (the 16x16x4 form pads N 8 -> 16 and was 50 % useful).  Each wave takes a
+// quarter of the tile's positions; persistent over tiles, dW kept in accumulators, waves summed through LDS.
+__global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
+    using G = ConvGeom<GEOM_S1>;
+    constexpr int CC = 16, CCP = CC + 4;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int NPOS = G::TQD * G::TQH * G::TQW;   // 256
+    constexpr int NTG = 7;                           // tap groups of 4 (27 -> 28)
+    __shared__ __attribute__((aligned(16))) float xt[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float gt[NPOS * 8];
+    __shared__ int tapoff[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.y;
+    if (tid < 32) tapoff[tid] = tid < 27 ? (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP : 0;
+    __syncthreads();
+    int toff[NTG];
+#pragma unroll
+    for (int tg = 0; tg < NTG; ++tg) toff[tg] = tapoff[4 * tg + (lane >> 4)] + (lane & 15);
+    f32x4 acc[NTG][2];
+#pragma unroll
+    for (int tg = 0; tg < NTG; ++tg) { acc[tg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[tg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw = t % a.ntw; t /= a.ntw;
+        const int th = t % a.nth; t /= a.nth;
+        const int td = t % a.ntd; t /= a.ntd;
+        const int b = t;
+        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+        __syncthreads();
+        for (int i = tid; i < NR * (CC / 4); i += 256) {
+            const int vox = i / (CC / 4), cq = i % (CC / 4);
+            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq);
+            *reinterpret_cast<float4*>(&xt[vox * CCP + 4 * cq]) = v;
+        }
+        for (int i = tid; i < NPOS * 2; i += 256) {
+            const int p = i >> 1, hq = i & 1;
+            const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qd < a.QD && qh < a.QH && qw < a.QW)
+                v = *reinterpret_cast<const float4*>(a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * 8 + 4 * hq);
+            *reinterpret_cast<float4*>(&gt[p * 8 + 4 * hq]) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < NPOS / 4; ++k) {
+            const int p = wave * (NPOS / 4) + k;
+            const int pw_ = p % G::TQW, ph_ = (p / G::TQW) % G::TQH, pd_ = p / (G::TQW * G::TQH);
+            const int xoff = ((pd_ * G::RH + ph_) * G::RW + pw_) * CCP;
+            const float b0 = gt[p * 8 + (lane & 3)], b1 = gt[p * 8 + 4 + (lane & 3)];
+            float av[NTG];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[xoff + toff[tg]];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                acc[tg][0] = MVS_MFMA_4x4x1(av[tg], b0, acc[tg][0]);
+                acc[tg][1] = MVS_MFMA_4x4x1(av[tg], b1, acc[tg][1]);
+            }
+        }
+    }
+    // sum the 4 waves through LDS (reusing xt: 28 taps x 16 cx x 8 co = 3584 floats), then one partial image
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // lane: block bl = lane>>2 -> tap 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
+                        const int bl = lane >> 2;
+                        const int idx = ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
+                        if (wv == 0) xt[idx] = acc[tg][h][r];
+                        else xt[idx] += acc[tg][h][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 27 * 16 * 8; i += 256) {
+        const int co = i & 7, cx = (i >> 3) & 15, tap = i >> 7;
+        a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + chunk * 16 + cx) * 8 + co] = xt[i];
+    }
+}
+
+// first level of a two-level reduction: [nparts][n] -> [nout][n], block y sums parts y, y+nout, ...
+__global__ __launch_bounds__(256) void conv_wgrad_prereduce_kernel(const float* __restrict__ part, int nparts, int n,
+                                                                   int nout, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    int p = blockIdx.y;
+    for (; p + nout < nparts; p += 2 * nout) {
+        s0 += part[(size_t)p * n + e];
+        s1 += part[(size_t)(p + nout) * n + e];
+    }
+    if (p < nparts) s0 += part[(size_t)p * n + e];
+    out[(size_t)blockIdx.y * n + e] = s0 + s1;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -570,7 +802,8 @@ static size_t packed_floats(int geom, int cin, int cout) {
     return (size_t)total_ksteps(geom, cin, cc) * nb * 256;
 }
 
-int g_conv_split = 1;   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
+int g_conv_split = 1;
+int g_conv_c8 = 1;      // tuning knob "k8": 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernel   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
 
 template <int GEOM, int CC>
 static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
@@ -606,6 +839,13 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     } else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
     const int tqd = geom == GEOM_S2 ? 2 : 4;
     a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    if (g_conv_c8 && geom == GEOM_S1 && cout == 8 && cin % 8 == 0) {
+        // 4x4x1 MFMA path, tile 4 x 8 x 16 positions
+        a.nth = mvs_cdiv(a.QH, 8);
+        const int nb8 = B * a.ntd * a.nth * a.ntw;
+        MVS_LAUNCH((conv_c8_fwd_kernel<8, 2>), dim3(nb8), dim3(256), 0, st, a, wsrc, wlayout, flip);
+        return mvs_check_launch("conv_c8_fwd");
+    }
     const int nblocks = B * a.ntd * a.nth * a.ntw;
     if (geom == GEOM_S1 && cout == 1 && wlayout == WL_OIK && !flip && !ep.partials && (cin == 8 || cin == 16)) {
         if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
@@ -634,12 +874,13 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
 }
 
 static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi) {
-    int QD = Di, QH = Hi, QW = Wi;
+    int QD = Di, QH = Hi, QW = Wi;  // upper bound over the tilings a forward call may pick (rows beyond the used ones are never read)
     if (geom == GEOM_S2) { QD = (Di - 1) / 2 + 1; QH = (Hi - 1) / 2 + 1; QW = (Wi - 1) / 2 + 1; }
     return B * mvs_cdiv(QD, geom == GEOM_S2 ? 2 : 4) * mvs_cdiv(QH, 4) * mvs_cdiv(QW, 16);
 }
 
-static const int WGRAD_MAX_GROUPS = 768;   // persistent workgroups per (ci chunk, co chunk): ~3 per CU
+static const int WGRAD_MAX_GROUPS = 768;
+static int wgrad_finish(float* ws, int nparts, int CX, int CG, float* gw, hipStream_t st);   // persistent workgroups per (ci chunk, co chunk): ~3 per CU
 
 template <int GEOM, int CC>
 static void launch_wgrad(const WgradArgs& a, int nbw, dim3 grid, hipStream_t st) {
@@ -663,26 +904,44 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     const int cc = CX % 16 == 0 ? 16 : 8;
     const int nbw = CG > 16 ? 2 : 1;
     const int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+    if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
+        const int g8 = ntiles < 512 ? ntiles : 512;   // 60 KB LDS -> 2 resident workgroups per CU
+        MVS_LAUNCH(conv_c8_wgrad_kernel, dim3(g8, CX / 16), dim3(256), 0, st, a);
+        int rc8 = mvs_check_launch("conv_c8_wgrad");
+        if (rc8) return rc8;
+        return wgrad_finish(ws, g8, CX, CG, gw, st);
+    }
     if (geom == GEOM_S1 && CG == 1 && (CX == 8 || CX == 16)) {
         if (CX == 8) MVS_LAUNCH((conv_wgrad_cg1_kernel<8>), dim3(groups), dim3(256), 0, st, a);
         else MVS_LAUNCH((conv_wgrad_cg1_kernel<16>), dim3(groups), dim3(256), 0, st, a);
         int rc1 = mvs_check_launch("conv_wgrad_cg1");
         if (rc1) return rc1;
-        const int n1 = 27 * CX;
-        MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n1, 256)), dim3(256), 0, st, (const float*)ws, groups, CX, CG, gw);
-        return mvs_check_launch("conv_wgrad_reduce");
+        return wgrad_finish(ws, groups, CX, CG, gw, st);
     }
     dim3 grid(groups, CX / cc, mvs_cdiv(CG, nbw * 16));
     if (geom == GEOM_S1) { if (cc == 16) launch_wgrad<GEOM_S1, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S1, 8>(a, nbw, grid, st); }
     else { if (cc == 16) launch_wgrad<GEOM_S2, 16>(a, nbw, grid, st); else launch_wgrad<GEOM_S2, 8>(a, nbw, grid, st); }
     int rc = mvs_check_launch("conv_wgrad");
     if (rc) return rc;
-    const int n = 27 * CX * CG;
-    MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, groups, CX, CG, gw);
-    return mvs_check_launch("conv_wgrad_reduce");
+    return wgrad_finish(ws, groups, CX, CG, gw, st);
 }
 
-static size_t wgrad_ws_floats(int CX, int CG) { return (size_t)WGRAD_MAX_GROUPS * 27 * CX * CG; }
+static size_t wgrad_ws_floats(int CX, int CG) { return (size_t)(WGRAD_MAX_GROUPS + 16) * 27 * CX * CG; }
+
+// deterministic reduction of the per-workgroup partial images: > 32 images go through 16 intermediate rows first
+// (a single pass has only 27*CX*CG threads, each walking all images serially -> latency bound)
+static int wgrad_finish(float* ws, int nparts, int CX, int CG, float* gw, hipStream_t st) {
+    const int n = 27 * CX * CG;
+    const float* src = ws;
+    if (nparts > 32) {
+        float* mid = ws + (size_t)WGRAD_MAX_GROUPS * n;
+        MVS_LAUNCH(conv_wgrad_prereduce_kernel, dim3(mvs_cdiv(n, 256), 16), dim3(256), 0, st, (const float*)ws, nparts, n, 16, mid);
+        src = mid;
+        nparts = 16;
+    }
+    MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, st, src, nparts, CX, CG, gw);
+    return mvs_check_launch("conv_wgrad_reduce");
+}
 
 static int check_stride(int stride, int D, int H, int W, const char* what) {
     MVS_REQUIRE(stride == 1 || stride == 2, MVS_ERR_UNSUPPORTED, "%s: stride must be 1 or 2, got %d", what, stride);
@@ -711,7 +970,9 @@ extern "C" long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int
 }
 
 // rows of the [rows][2][Cout] BatchNorm partial-sum buffer a forward call writes
-extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int stride) {
+extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin, int Cout, int stride) {
+    if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && g_conv_c8 && Cout == 8 && Cin % 8 == 0)
+        return B * mvs_cdiv(D, 4) * mvs_cdiv(H, 8) * mvs_cdiv(W, 16);   // conv_c8_fwd_kernel tiling
     if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W);
     if (op == MVS_OP_CONVT_FWD) return igemm_blocks(stride == 2 ? GEOM_TR2 : GEOM_S1, B, D, H, W);
     return -1;

@@ -36,6 +36,7 @@ struct SweepArgs {
     int warp_only;   // 1: write / back-propagate the warped volume of source 0 itself (homo_warping)
     float sx, ox, sy, oy;  // ix = px*sx + ox, iy = py*sy + oy
     int tiles_x, tiles_y;
+    int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
@@ -199,7 +200,8 @@ template <int C, int CPT> struct TileC {
 template <int C, int NS_T, int CPT>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     constexpr int V = CPT / 4;                     // float4s per tap per thread
-    constexpr int LPP = TileC<C, CPT>::LPP, TW = TileC<C, CPT>::TW, TH = TileC<C, CPT>::TH;
+    constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
+    const int TW = a.tile_w, TH = PPB / TW;
     const int tid = threadIdx.x;
     const int q = tid % LPP, pl = tid / LPP;
     const int x = (blockIdx.x % a.tiles_x) * TW + pl % TW, y = (blockIdx.x / a.tiles_x) * TH + pl / TW;
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
-            const float iz = 1.0f / fmaf(rz[s], dep, tz[s]);
+            const float zz = fmaf(rz[s], dep, tz[s]);
+            float iz = MVS_RCP(zz);                 // v_rcp_f32 (1 ulp) + one Newton step: < 1 ulp, 3 instructions
+            iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz); // instead of the ~10 of an IEEE division
             const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
             const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
             const float fx = floorf(ix), fy = floorf(iy);
@@ -710,10 +714,14 @@ static int sweep_fwd_variant() {
     return g_sweep_fwd_variant;
 }
 static int g_sweep_nt = 0;
+static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 extern int g_conv_split;
+extern int g_conv_c8;
 extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
+    if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
+    if (key && key[0] == 'k') { g_conv_c8 = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
@@ -729,7 +737,13 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
         const bool c8 = variant == 3 && CPT8 == 8;
-        if (c8) { a.tiles_x = mvs_cdiv(a.W, (TileC<C, CPT8>::TW)); a.tiles_y = mvs_cdiv(a.H, (TileC<C, CPT8>::TH)); }
+        const int ppb = c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB;
+        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c8 ? TileC<C, CPT8>::TW : TileC<C, 4>::TW);
+        if (tw > ppb) tw = ppb;
+        while (ppb % tw) --tw;
+        a.tile_w = tw;
+        a.tiles_x = mvs_cdiv(a.W, tw);
+        a.tiles_y = mvs_cdiv(a.H, ppb / tw);
         dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \

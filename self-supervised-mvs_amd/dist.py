@@ -35,34 +35,45 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 
 
 class FlatGradBucket:
-    """All parameter gradients live as views into one contiguous fp32 buffer; ``all_reduce()`` is a
-    single collective (sum) followed by 1/world (loss = mean over the global batch)."""
+    """One contiguous fp32 gradient buffer for the whole model; ``all_reduce()`` is a single collective
+    (sum) followed by 1/world (loss = mean over the global batch).
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    Per step: ``zero()`` drops the parameters' .grad (so autograd WRITES fresh gradients instead of
+    launching one accumulate-add per parameter), ``gather()`` packs them into the flat buffer with one
+    concatenation, ``all_reduce()`` runs the collective on it.  With ``flatten_params=True`` the parameters
+    themselves become views of one flat tensor (``flat_param``, whose .grad is the bucket), so the
+    optimiser can run as ONE fused update over one tensor instead of 100+ small launches."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], flatten_params: bool = False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradBucket: no trainable parameters")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        self.flat_param = None
+        if flatten_params:
+            store = torch.cat([p.detach().reshape(-1) for p in self.params])
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.data = store[off:off + n].view_as(p)
+                off += n
+            self.flat_param = torch.nn.Parameter(store)
+            self.flat_param.grad = self.flat
 
     @property
     def nbytes(self) -> int:
         return self.flat.numel() * 4
 
     def zero(self) -> None:
-        self.flat.zero_()
-        off = 0
-        for p in self.params:  # re-attach in case an optimiser / zero_grad(set_to_none=True) dropped the views
-            n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p in self.params:
+            p.grad = None
+
+    def gather(self) -> None:
+        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=torch.float32,
+                                                                        device=self.flat.device) for p in self.params]
+        torch.cat(grads, out=self.flat)
 
     def all_reduce(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -84,10 +84,13 @@ class RefineNet(nn.Module):
 
 
 class MVSNet(nn.Module):
-    def __init__(self, refine=True, align_corners=ALIGN_CORNERS):
+    def __init__(self, refine=True, align_corners=ALIGN_CORNERS, channels_last_features=False):
         super().__init__()
         self.refine = refine
         self.align_corners = align_corners
+        # optional: run the (stock PyTorch) 2-D feature extractor in channels-last so MIOpen picks NHWC kernels
+        # and the features arrive in the layout the plane-sweep kernel reads (no NCHW->NHWC transpose)
+        self.channels_last_features = channels_last_features
         self.feature = FeatureNet()
         self.cost_regularization = CostRegNet()
         if self.refine:
@@ -99,6 +102,9 @@ class MVSNet(nn.Module):
         assert len(imgs) == len(proj_matrices), "Different number of images and projection matrices"
 
         # step 1. feature extraction (stock PyTorch)
+        if self.channels_last_features:
+            self.feature.to(memory_format=torch.channels_last)
+            imgs = [img.contiguous(memory_format=torch.channels_last) for img in imgs]
         features = [self.feature(img) for img in imgs]
         ref_feature, src_features = features[0], features[1:]
         ref_proj, src_projs = proj_matrices[0], proj_matrices[1:]
@@ -124,6 +130,8 @@ class MVSNet(nn.Module):
 
 
 def mvsnet_loss(depth_est, depth_gt, mask):
-    """mvsnet.py:164-166."""
-    mask = mask > 0.5
-    return F.smooth_l1_loss(depth_est[mask], depth_gt[mask], reduction='mean')
+    """mvsnet.py:164-166: mean smooth-L1 over the pixels with mask > 0.5.  Same value and gradient as the
+    reference's boolean-index form, written without `tensor[mask]` (which launches nonzero + a host sync)."""
+    m = (mask > 0.5).to(depth_est.dtype)
+    per_pixel = F.smooth_l1_loss(depth_est, depth_gt, reduction='none')
+    return (per_pixel * m).sum() / m.sum()

@@ -190,7 +190,7 @@ def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None
     ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
     parts = None
     if want_stats:
-        rows = lib.raw("mvs_conv3d_stat_rows", op, b, d, h, w, stride)
+        rows = lib.raw("mvs_conv3d_stat_rows", op, b, d, h, w, cin, cout, stride)
         parts = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     if skip is not None:
         skip = as_cl3(skip)

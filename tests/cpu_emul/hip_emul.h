@@ -93,6 +93,21 @@ static inline f32x4 emul_mfma_16x16x4(float a, float b, f32x4 c) {
 }
 #define MVS_MFMA_16x16x4(a, b, c) emul_mfma_16x16x4((a), (b), (c))
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products.  Lane l: block = l>>2; A row i = l&3;
+// B col j = l&3; D: lane (block, col j = l&3), register r = row i.
+static inline f32x4 emul_mfma_4x4x1(float a, float b, f32x4 c) {
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    int l = emul::lane;
+    w->fa[s][l] = a;
+    w->fb[s][l] = b;
+    pthread_barrier_wait(&w->bar);
+    int blk = l >> 2;
+    for (int r = 0; r < 4; ++r) c[r] = fmaf(w->fa[s][blk * 4 + r], w->fb[s][l], c[r]);
+    return c;
+}
+#define MVS_MFMA_4x4x1(a, b, c) emul_mfma_4x4x1((a), (b), (c))
+
 static inline float atomicAdd(float* addr, float v) {
     unsigned* p = (unsigned*)addr;
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED), nw;
@@ -154,3 +169,4 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_NT_STORE4(ptr, o) (*reinterpret_cast<float4*>(ptr) = (o))
+#define MVS_RCP(x) (1.0f / (x))

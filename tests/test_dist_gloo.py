@@ -35,6 +35,7 @@ def _worker(rank, world, port, ret):
     data = torch.randn(world, 2, 3, 8, 8, generator=g)  # one "sample" (mini batch) per rank
     bucket.zero()
     model(data[rank]).mean().backward()
+    bucket.gather()
     bucket.all_reduce()
     if rank == 0:
         ret["flat"] = bucket.flat.clone()

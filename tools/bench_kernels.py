@@ -68,10 +68,13 @@ def main():
         for variant, label in ((0, "direct"), (1, "lds"), (2, "cached4"), (3, "cached8")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        for variant, tw in ((2, 32), (2, 16), (3, 64), (3, 32), (3, 16)):
+            lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+            lib.call("mvs_set_tuning", b"tile_w", tw)
+            add("sweep_fwd[cached%d tile_w=%d]" % (4 if variant == 2 else 8, tw),
+                lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        lib.call("mvs_set_tuning", b"tile_w", 0)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)
-        lib.call("mvs_set_tuning", b"nt", 1)
-        add("sweep_fwd[cached8+nt store]", lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        lib.call("mvs_set_tuning", b"nt", 0)
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
         add("calibration: fill_ 503 MB (write only)", lambda: var.fill_(1.0), "hbm", C * vox * 4)
         tmp = torch.empty_like(var)
@@ -88,11 +91,13 @@ def main():
     w0 = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.05).to(dev)
     fl0 = 2 * 27 * 32 * 8 * vox
     with torch.no_grad():
-        add("conv0 fwd 32>8", lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
         y0, _ = ops.conv3d_forward(var, w0, 1, False)
         gy0 = torch.randn_like(y0)
+        for k8, label in ((0, "16x16x4 padded"), (1, "4x4x1")):
+            lib.call("mvs_set_tuning", b"k8", k8)
+            add("conv0 fwd 32>8 [%s]" % label, lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
+            add("conv0 wgrad [%s]" % label, lambda: ops.conv3d_wgrad(var, gy0, tuple(w0.shape), 1, False), "mfma", fl0)
         add("conv0 dgrad", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
-        add("conv0 wgrad", lambda: ops.conv3d_wgrad(var, gy0, tuple(w0.shape), 1, False), "mfma", fl0)
         # L0 8-channel layers
         w1 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
         add("conv1 fwd 8>16 s2", lambda: ops.conv3d_forward(y0, w1, 2, False, want_stats=True), "mfma", 2 * 27 * 8 * 16 * vox / 8)

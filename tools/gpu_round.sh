@@ -16,6 +16,8 @@ fi
 if [ "$what" = "bench" ] || [ "$what" = "all" ]; then
   timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --gpu-reference --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; tail -n 60 gpurun_out/bench.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --feature-channels-last 1 > gpurun_out/bench_featcl.json 2> gpurun_out/bench_featcl.err
+  echo "bench(feature channels-last) exit $?"; cat gpurun_out/bench_featcl.json | cut -c1-260
 fi
 if [ "$what" = "kernels" ] || [ "$what" = "all" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; cat gpurun_out/kernels.log | grep -v Warning
