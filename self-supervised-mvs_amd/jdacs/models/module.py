@@ -16,13 +16,27 @@ ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >
 
 
 class ConvBnReLU(nn.Module):
+    """module.py:15-22.  The 2-D convolution stays MIOpen (stock PyTorch); BatchNorm2d + ReLU run through the
+    library's BatchNorm kernels when the activation is channels-last on the GPU with C % 4 == 0 (``hip_bn``);
+    otherwise (e.g. RefineNet's 1-channel output layer) the stock modules are used."""
+    hip_bn = True
+
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
 
     def forward(self, x):
-        return F.relu(self.bn(self.conv(x)), inplace=True)
+        y = self.conv(x)
+        bn = self.bn
+        if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 64
+                and y.is_contiguous(memory_format=torch.channels_last)):
+            if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            momentum = bn.momentum if bn.momentum is not None else 0.1
+            return ops.BnReLUFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.eps,
+                                      momentum)
+        return F.relu(bn(y), inplace=True)
 
 
 def homo_warping(src_fea, src_proj, ref_proj, depth_values, align_corners=None):

@@ -84,7 +84,7 @@ class RefineNet(nn.Module):
 
 
 class MVSNet(nn.Module):
-    def __init__(self, refine=True, align_corners=ALIGN_CORNERS, channels_last_features=False):
+    def __init__(self, refine=True, align_corners=ALIGN_CORNERS, channels_last_features=True):
         super().__init__()
         self.refine = refine
         self.align_corners = align_corners
@@ -103,7 +103,9 @@ class MVSNet(nn.Module):
 
         # step 1. feature extraction (stock PyTorch)
         if self.channels_last_features:
-            self.feature.to(memory_format=torch.channels_last)
+            if not getattr(self, "_feature_cl", False):
+                self.feature.to(memory_format=torch.channels_last)
+                self._feature_cl = True
             imgs = [img.contiguous(memory_format=torch.channels_last) for img in imgs]
         features = [self.feature(img) for img in imgs]
         ref_feature, src_features = features[0], features[1:]

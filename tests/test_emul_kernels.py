@@ -259,3 +259,31 @@ def test_conv_multi_cout_tiles_per_workgroup(emul_lib):
             assert torch.allclose(parts.sum(0)[0], yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
     finally:
         emul_lib.call("mvs_set_tuning", b"conv_split", 1)
+
+
+def test_bn_relu_2d(emul_lib):
+    """BatchNorm2d + ReLU of the feature extractor's ConvBnReLU through the library's BN kernels."""
+    import copy
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(31)
+    bn = torch.nn.BatchNorm2d(16)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+    bn_r = copy.deepcopy(bn)
+    x = (torch.randn(2, 16, 12, 20, generator=g) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = ops.BnReLUFn.apply(xa, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, 0.1)
+    yr = F.relu(bn_r(xb))
+    assert float((y - yr).abs().max()) < 1e-5
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy)
+    yr.backward(gy)
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-5
+    assert rel_l1(bn.weight.grad, bn_r.weight.grad) < 1e-5 and rel_l1(bn.bias.grad, bn_r.bias.grad) < 1e-5
+    assert torch.allclose(bn.running_mean, bn_r.running_mean, atol=1e-6)
+    assert torch.allclose(bn.running_var, bn_r.running_var, atol=1e-6, rtol=1e-5)
+    bn_r.eval()
+    with torch.no_grad():
+        ye = ops.BnReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, False, bn.eps, 0.1)
+    assert float((ye - F.relu(bn_r(x))).abs().max()) < 1e-5
