@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpu-reference", action="store_true",
                     help="also time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, "
                          "MIOpen conv3d) = 'the reference GPU path'; reported as reference_gpu_path")
-    ap.add_argument("--feature-channels-last", type=int, default=0,
+    ap.add_argument("--feature-channels-last", type=int, default=1,
                     help="1: run the stock-PyTorch FeatureNet in channels-last (MIOpen NHWC kernels)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: replay the whole step from a captured hipGraph (torch.cuda.CUDAGraph); 0: eager launches; "
@@ -248,7 +248,7 @@ def main():
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "grad_bucket_bytes": bucket.nbytes,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
             try:
                 res["cpu_baseline"] = cpu_baseline(state0, 1)
             except Exception as e:  # the bench line must still come out

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...nn3d import ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d  # noqa: F401
+from ...nn3d import ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, count_batch  # noqa: F401
 
 ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >= 1.3
 
@@ -31,8 +31,7 @@ class ConvBnReLU(nn.Module):
         bn = self.bn
         if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 64
                 and y.is_contiguous(memory_format=torch.channels_last)):
-            if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            count_batch(bn, self.training)
             momentum = bn.momentum if bn.momentum is not None else 0.1
             return ops.BnReLUFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.eps,
                                       momentum)

@@ -9,6 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ...nn3d import batched_bn_counters
 from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d
 
 
@@ -97,6 +98,10 @@ class MVSNet(nn.Module):
             self.refine_network = RefineNet()
 
     def forward(self, imgs, proj_matrices, depth_values):
+        with batched_bn_counters():
+            return self._forward(imgs, proj_matrices, depth_values)
+
+    def _forward(self, imgs, proj_matrices, depth_values):
         imgs = torch.unbind(imgs, 1)
         proj_matrices = torch.unbind(proj_matrices, 1)
         assert len(imgs) == len(proj_matrices), "Different number of images and projection matrices"

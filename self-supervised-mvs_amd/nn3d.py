@@ -11,9 +11,41 @@ import torch.nn as nn
 from . import ops
 
 
-def _bn_step(bn: nn.BatchNorm3d, training: bool):
+_DEFERRED = None  # {id: [tensor, count]} while a model forward batches the num_batches_tracked increments
+
+
+class batched_bn_counters:
+    """Context manager: BatchNorm ``num_batches_tracked += 1`` of every block executed inside is applied as ONE
+    multi-tensor launch at exit instead of one tiny kernel per BatchNorm layer (31 per MVSNet step)."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer = _DEFERRED
+        if _DEFERRED is None:
+            _DEFERRED = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        if self.outer is None:
+            pending, _DEFERRED = _DEFERRED, None
+            if pending and exc[0] is None:
+                torch._foreach_add_([t for t, _ in pending.values()], [n for _, n in pending.values()])
+        return False
+
+
+def count_batch(bn, training: bool):
+    """num_batches_tracked bookkeeping of nn.BatchNorm*.forward (torch/nn/modules/batchnorm.py)."""
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _DEFERRED is None:
+            bn.num_batches_tracked.add_(1)
+        else:
+            ent = _DEFERRED.setdefault(id(bn.num_batches_tracked), [bn.num_batches_tracked, 0])
+            ent[1] += 1
+
+
+def _bn_step(bn: nn.BatchNorm3d, training: bool):
+    count_batch(bn, training)
     return bn.momentum if bn.momentum is not None else 0.1
 
 

@@ -6,6 +6,10 @@ what=${1:-all}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
+if [ "$what" = "b" ]; then
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -12
+fi
 if [ "$what" = "tb" ]; then
   timeout 1200 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED" gpurun_out/pytest_gpu.log | tail -5
