@@ -119,6 +119,16 @@ int mvs_bn_relu_bwd(const float* dy, const float* x, const float* mean, const fl
                     const float* shift, int relu, long long V, int C, float* ws, float* dx, float* dgamma,
                     float* dbeta, hipStream_t stream);
 
+/* Grouped BatchNorm(+ReLU): G independent statistics groups of Vg contiguous rows each, shared affine parameters,
+ * running statistics updated group after group == G successive nn.BatchNorm2d calls.  Lets the N views of a
+ * sample go through the shared-weight feature extractor as one batch (jdacs/models/mvsnet.py:115) with the
+ * reference's per-view statistics.  stats [G][4][C]; ws: fwd >= G*512*2*C floats, bwd >= G*512*2*C + G*2*C. */
+int mvs_bn_group_relu_fwd(const float* x, int G, long long Vg, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, int training, int relu, float* ws,
+                          float* stats, float* y, hipStream_t stream);
+int mvs_bn_group_relu_bwd(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg, int C,
+                          float* ws, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
+
 /* ---- K9/K10: softmax over depth + soft-argmin regression + photometric confidence --------------
  * Replace F.softmax(dim=1) + depth_regression + the pad/avg_pool3d/gather confidence:
  *   jdacs/models/mvsnet.py:141-151, jdacs/models/module.py:145-148;

@@ -41,6 +41,8 @@ SIGNATURES = {
     "mvs_bn_eval_affine": (_i, [_f, _f, _f, _f, _fl, _i, _f, _f, _s]),
     "mvs_bn_relu_fwd": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _s]),
     "mvs_bn_relu_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f, _f, _f, _s]),
+    "mvs_bn_group_relu_fwd": (_i, [_f, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _i, _i, _f, _f, _f, _s]),
+    "mvs_bn_group_relu_bwd": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
 }

@@ -31,19 +31,25 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* sm) 
 }
 
 // partials: [nparts][2][C] (sum, sum of squares).  One block per channel.
+// groups > 1: independent statistics per group g (rows [g*count, (g+1)*count) of x), e.g. the N views pushed
+// through a shared-weight feature extractor as one batch; running statistics are updated group after group,
+// exactly like N successive BatchNorm calls.  partials [G][nparts][2][C]; *_out [G][gs] with the 4 arrays gs apart.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, int C,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           float* mean_out, float* invstd_out, float* scale_out,
-                                                          float* shift_out) {
+                                                          float* shift_out, int groups, int gs) {
     __shared__ double sm[512];
     const int c = blockIdx.x;
+    for (int g = 0; g < groups; ++g, partials += (size_t)nparts * 2 * C, mean_out += gs, invstd_out += gs, scale_out += gs,
+             shift_out += gs) {
     double s1 = 0.0, s2 = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 256) {
         s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
         s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
     }
+    __syncthreads();
     block_reduce2(s1, s2, sm);
     if (threadIdx.x == 0) {
         double mean = s1 / count;
@@ -61,6 +67,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
+    }
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -77,8 +84,11 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ skip, float* __restrict__ y,
-                                                            size_t n4, int C, int relu) {
+                                                            size_t n4, int C, int relu, int gs) {
     const int cq = C / 4;
+    x += (size_t)blockIdx.y * n4 * 4; y += (size_t)blockIdx.y * n4 * 4;
+    if (skip) skip += (size_t)blockIdx.y * n4 * 4;
+    scale += blockIdx.y * gs; shift += blockIdx.y * gs;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cq) * 4;
         float4 v = ld4g(x + i * 4);
@@ -103,11 +113,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, size_t n4, int C, int relu,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, int gs) {
     __shared__ float red[256 * 8];
     const int cq = C / 4;
     const int tid = threadIdx.x;
     const int c = (tid % cq) * 4;
+    dy += (size_t)blockIdx.y * n4 * 4; x += (size_t)blockIdx.y * n4 * 4;
+    partials += (size_t)blockIdx.y * gridDim.x * 2 * C;
+    mean += blockIdx.y * gs; invstd += blockIdx.y * gs; scale += blockIdx.y * gs; shift += blockIdx.y * gs;
     const float4 mu = ld4g(mean + c), is = ld4g(invstd + c), sc = ld4g(scale + c), sh = ld4g(shift + c);
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
@@ -137,21 +150,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // reduce [nparts][2][C] -> sums[2][C] (fp64 accumulate); also emits dgamma = sum dyh*xhat, dbeta = sum dyh
+// sums [G][2][C]; dgamma / dbeta are summed over the groups (the affine parameters are shared)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C,
-                                                              float* sums, float* dgamma, float* dbeta) {
+                                                              float* sums, float* dgamma, float* dbeta, int groups) {
     __shared__ double sm[512];
     const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 256) {
-        s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
-        s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
+    double t1 = 0.0, t2 = 0.0;
+    for (int g = 0; g < groups; ++g, partials += (size_t)nparts * 2 * C, sums += 2 * C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = threadIdx.x; p < nparts; p += 256) {
+            s1 += (double)partials[((size_t)p * 2 + 0) * C + c];
+            s2 += (double)partials[((size_t)p * 2 + 1) * C + c];
+        }
+        __syncthreads();
+        block_reduce2(s1, s2, sm);
+        if (threadIdx.x == 0) {
+            sums[c] = (float)s1;
+            sums[C + c] = (float)s2;
+            t1 += s1; t2 += s2;
+        }
     }
-    block_reduce2(s1, s2, sm);
     if (threadIdx.x == 0) {
-        sums[c] = (float)s1;
-        sums[C + c] = (float)s2;
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = (float)t1;
+        if (dgamma) dgamma[c] = (float)t2;
     }
 }
 
@@ -162,8 +183,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ sums, float inv_count, size_t n4,
-                                                           int C, int relu, float* __restrict__ dx) {
+                                                           int C, int relu, float* __restrict__ dx, int gs) {
     const int cq = C / 4;
+    dy += (size_t)blockIdx.y * n4 * 4; x += (size_t)blockIdx.y * n4 * 4; dx += (size_t)blockIdx.y * n4 * 4;
+    sums += (size_t)blockIdx.y * 2 * C;
+    mean += blockIdx.y * gs; invstd += blockIdx.y * gs; scale += blockIdx.y * gs; shift += blockIdx.y * gs;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cq) * 4;
         const float4 mu = ld4g(mean + c), is = ld4g(invstd + c), sc = ld4g(scale + c), sh = ld4g(shift + c);
@@ -191,6 +215,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     __shared__ float red[256 * 8];
     const int cq = C / 4;
     const int tid = threadIdx.x;
+    x += (size_t)blockIdx.y * n4 * 4;
+    partials += (size_t)blockIdx.y * gridDim.x * 2 * C;
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = ld4g(x + i * 4);
@@ -235,7 +261,7 @@ extern "C" int mvs_bn_finalize(const float* partials, int nparts, int C, long lo
                 "bn_finalize: null pointer argument");
     MVS_REQUIRE(nparts > 0 && C > 0 && count > 0, MVS_ERR_SHAPE, "bn_finalize: bad sizes");
     MVS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partials, nparts, C, (double)count, gamma, beta, eps,
-               momentum, running_mean, running_var, mean, invstd, scale, shift);
+               momentum, running_mean, running_var, mean, invstd, scale, shift, 1, 0);
     return mvs_check_launch("bn_finalize");
 }
 
@@ -254,7 +280,7 @@ extern "C" int mvs_bn_relu_fwd(const float* x, const float* scale, const float* 
     MVS_REQUIRE(x && scale && shift && y, MVS_ERR_NULL, "bn_relu_fwd: null pointer argument");
     MVS_REQUIRE(bn_c_ok(C), MVS_ERR_UNSUPPORTED, "bn: C must be 4/8/16/32/64, got %d", C);
     size_t n4 = (size_t)V * C / 4;
-    MVS_LAUNCH(bn_apply_relu_kernel, dim3(ew_grid(n4)), dim3(256), 0, stream, x, scale, shift, skip, y, n4, C, relu);
+    MVS_LAUNCH(bn_apply_relu_kernel, dim3(ew_grid(n4)), dim3(256), 0, stream, x, scale, shift, skip, y, n4, C, relu, 0);
     return mvs_check_launch("bn_relu_fwd");
 }
 
@@ -270,9 +296,57 @@ extern "C" int mvs_bn_relu_bwd(const float* dy, const float* x, const float* mea
     if (g > 1024) g = 1024;
     float* partials = ws;
     float* sums = ws + (size_t)1024 * 2 * C;
-    MVS_LAUNCH(bn_bwd_reduce_kernel, dim3(g), dim3(256), 0, stream, dy, x, mean, invstd, scale, shift, n4, C, relu, partials);
-    MVS_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, (const float*)partials, g, C, sums, dgamma, dbeta);
+    MVS_LAUNCH(bn_bwd_reduce_kernel, dim3(g), dim3(256), 0, stream, dy, x, mean, invstd, scale, shift, n4, C, relu, partials, 0);
+    MVS_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, (const float*)partials, g, C, sums, dgamma, dbeta, 1);
     MVS_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, stream, dy, x, mean, invstd, scale, shift,
-               (const float*)sums, 1.0f / (float)V, n4, C, relu, dx);
+               (const float*)sums, 1.0f / (float)V, n4, C, relu, dx, 0);
     return mvs_check_launch("bn_relu_bwd");
+}
+
+// ---- grouped BatchNorm(+ReLU): G independent statistics groups of Vg rows each (rows of group g are contiguous) ----
+// The N views of an MVS sample go through the shared-weight 2-D feature extractor as ONE batch while BatchNorm keeps
+// the reference's per-view statistics and its view-after-view running-stat updates (jdacs/models/mvsnet.py:115).
+// stats: [G][4][C] (mean, invstd, scale, shift) written by fwd, read by bwd.
+// ws: fwd >= G*512*2*C floats; bwd >= G*512*2*C + G*2*C floats.
+#define MVS_BN_GROUP_BLOCKS 512
+extern "C" int mvs_bn_group_relu_fwd(const float* x, int G, long long Vg, int C, const float* gamma, const float* beta,
+                                     float eps, float momentum, float* running_mean, float* running_var, int training,
+                                     int relu, float* ws, float* stats, float* y, hipStream_t stream) {
+    MVS_REQUIRE(x && gamma && beta && stats && y && ws, MVS_ERR_NULL, "bn_group_relu_fwd: null pointer argument");
+    MVS_REQUIRE(bn_c_ok(C), MVS_ERR_UNSUPPORTED, "bn: C must be 4/8/16/32/64, got %d", C);
+    MVS_REQUIRE(G >= 1 && G <= 64 && Vg > 0, MVS_ERR_SHAPE, "bn_group_relu_fwd: bad group shape G=%d", G);
+    const size_t n4 = (size_t)Vg * C / 4;
+    if (training) {
+        int g = ew_grid(n4);
+        if (g > MVS_BN_GROUP_BLOCKS) g = MVS_BN_GROUP_BLOCKS;
+        MVS_LAUNCH(bn_stats_kernel, dim3(g, G), dim3(256), 0, stream, x, n4, C, ws);
+        MVS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, (const float*)ws, g, C, (double)Vg, gamma, beta, eps, momentum,
+                   running_mean, running_var, stats, stats + C, stats + 2 * C, stats + 3 * C, G, 4 * C);
+    } else {
+        MVS_REQUIRE(running_mean && running_var, MVS_ERR_NULL, "bn_group_relu_fwd: eval mode needs running statistics");
+        for (int gi = 0; gi < G; ++gi)
+            MVS_LAUNCH(bn_eval_affine_kernel, dim3(mvs_cdiv(C, 64)), dim3(64), 0, stream, gamma, beta, (const float*)running_mean,
+                       (const float*)running_var, eps, C, stats + (size_t)gi * 4 * C + 2 * C, stats + (size_t)gi * 4 * C + 3 * C);
+    }
+    MVS_LAUNCH(bn_apply_relu_kernel, dim3(ew_grid(n4), G), dim3(256), 0, stream, x, (const float*)(stats + 2 * C),
+               (const float*)(stats + 3 * C), (const float*)nullptr, y, n4, C, relu, 4 * C);
+    return mvs_check_launch("bn_group_relu_fwd");
+}
+
+extern "C" int mvs_bn_group_relu_bwd(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg,
+                                     int C, float* ws, float* dx, float* dgamma, float* dbeta, hipStream_t stream) {
+    MVS_REQUIRE(dy && x && stats && ws && dx, MVS_ERR_NULL, "bn_group_relu_bwd: null pointer argument");
+    MVS_REQUIRE(bn_c_ok(C), MVS_ERR_UNSUPPORTED, "bn: C must be 4/8/16/32/64, got %d", C);
+    MVS_REQUIRE(G >= 1 && G <= 64 && Vg > 0, MVS_ERR_SHAPE, "bn_group_relu_bwd: bad group shape G=%d", G);
+    const size_t n4 = (size_t)Vg * C / 4;
+    int g = ew_grid(n4);
+    if (g > MVS_BN_GROUP_BLOCKS) g = MVS_BN_GROUP_BLOCKS;
+    float* partials = ws;
+    float* sums = ws + (size_t)G * MVS_BN_GROUP_BLOCKS * 2 * C;
+    const float *mean = stats, *invstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
+    MVS_LAUNCH(bn_bwd_reduce_kernel, dim3(g, G), dim3(256), 0, stream, dy, x, mean, invstd, scale, shift, n4, C, relu, partials, 4 * C);
+    MVS_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, (const float*)partials, g, C, sums, dgamma, dbeta, G);
+    MVS_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(n4), G), dim3(256), 0, stream, dy, x, mean, invstd, scale, shift,
+               (const float*)sums, 1.0f / (float)Vg, n4, C, relu, dx, 4 * C);
+    return mvs_check_launch("bn_group_relu_bwd");
 }

@@ -26,15 +26,20 @@ class ConvBnReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
+        """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one
+        after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
         y = self.conv(x)
         bn = self.bn
         if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 64
                 and y.is_contiguous(memory_format=torch.channels_last)):
-            count_batch(bn, self.training)
+            for _ in range(groups):
+                count_batch(bn, self.training)
             momentum = bn.momentum if bn.momentum is not None else 0.1
             return ops.BnReLUFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.eps,
-                                      momentum)
+                                      momentum, groups)
+        if groups > 1:
+            return torch.cat([F.relu(bn(c)) for c in y.chunk(groups, 0)], 0)
         return F.relu(bn(y), inplace=True)
 
 

@@ -293,47 +293,46 @@ class BnReLUFn(torch.autograd.Function):
     """BatchNorm (+ReLU) over the channel dim of a channels-last tensor [B,C,H,W] / [B,C,D,H,W] with the same
     HIP kernels as the 3-D regulariser (statistics partials -> fp64 finalize -> one apply pass; two-pass
     backward).  Used by the 2-D ConvBnReLU blocks of the feature extractors (jdacs/models/module.py:15-22),
-    where MIOpen's BatchNorm kernels take ~40 us per call at B=1 with 8-32 channels."""
+    where MIOpen's BatchNorm kernels take ~40 us per call at B=1 with 8-32 channels.
+
+    ``groups`` > 1: the batch holds `groups` equal chunks (the N views of a sample pushed through the
+    shared-weight extractor as one batch); statistics are taken per chunk and the running statistics are
+    updated chunk after chunk, i.e. exactly what `groups` successive BatchNorm calls do."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, groups):
         lib = _lib_for(x)
         st = _stream(x)
         c = x.shape[1]
+        if x.shape[0] % groups:
+            raise ValueError("batch %d not divisible into %d BatchNorm groups" % (x.shape[0], groups))
         fmt = CL2 if x.dim() == 4 else CL3
         x = x.contiguous(memory_format=fmt)
-        v = x.numel() // c
+        vg = x.numel() // c // groups
         dev = x.device
-        stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        if training:
-            parts = torch.empty((lib.raw("mvs_bn_reduce_blocks"), 2, c), dtype=torch.float32, device=dev)
-            nparts = C.c_int(0)
-            lib.call("mvs_bn_stats", _p(x), v, c, _p(parts), C.byref(nparts), st)
-            lib.call("mvs_bn_finalize", _p(parts), nparts.value, c, v, _p(gamma), _p(beta), float(eps), float(momentum),
-                     _p(running_mean), _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), st)
-        else:
-            lib.call("mvs_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), c,
-                     _p(stats[2]), _p(stats[3]), st)
+        stats = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        ws = torch.empty(groups * 512 * 2 * c, dtype=torch.float32, device=dev)
         y = torch.empty_like(x, memory_format=fmt)
-        lib.call("mvs_bn_relu_fwd", _p(x), _p(stats[2]), _p(stats[3]), None, 1, v, c, _p(y), st)
+        lib.call("mvs_bn_group_relu_fwd", _p(x), groups, vg, c, _p(gamma), _p(beta), float(eps), float(momentum),
+                 _p(running_mean), _p(running_var), int(training), 1, _p(ws), _p(stats), _p(y), st)
         ctx.save_for_backward(x, stats)
-        ctx.cfg = (training, v, c, fmt)
+        ctx.cfg = (training, vg, c, fmt, groups)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, stats = ctx.saved_tensors
-        training, v, c, fmt = ctx.cfg
+        training, vg, c, fmt, groups = ctx.cfg
         if not training:
             raise NotImplementedError("mvs_amd: backward through eval-mode BatchNorm is not supported")
         lib = _lib_for(x)
         gy = gy.contiguous(memory_format=fmt)
-        ws = torch.empty(1024 * 2 * c + 2 * c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(groups * 512 * 2 * c + groups * 2 * c, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x, memory_format=fmt)
         dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        lib.call("mvs_bn_relu_bwd", _p(gy), _p(x), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, v, c,
-                 _p(ws), _p(dx), _p(dgb[0]), _p(dgb[1]), _stream(x))
-        return dx, dgb[0], dgb[1], None, None, None, None, None
+        lib.call("mvs_bn_group_relu_bwd", _p(gy), _p(x), _p(stats), 1, groups, vg, c, _p(ws), _p(dx), _p(dgb[0]),
+                 _p(dgb[1]), _stream(x))
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 class ConvBias3dFn(torch.autograd.Function):

@@ -273,7 +273,7 @@ def test_bn_relu_2d(emul_lib):
     bn_r = copy.deepcopy(bn)
     x = (torch.randn(2, 16, 12, 20, generator=g) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    y = ops.BnReLUFn.apply(xa, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, 0.1)
+    y = ops.BnReLUFn.apply(xa, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, 0.1, 1)
     yr = F.relu(bn_r(xb))
     assert float((y - yr).abs().max()) < 1e-5
     gy = torch.randn(yr.shape, generator=g)
@@ -285,5 +285,31 @@ def test_bn_relu_2d(emul_lib):
     assert torch.allclose(bn.running_var, bn_r.running_var, atol=1e-6, rtol=1e-5)
     bn_r.eval()
     with torch.no_grad():
-        ye = ops.BnReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, False, bn.eps, 0.1)
+        ye = ops.BnReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, False, bn.eps, 0.1, 1)
     assert float((ye - F.relu(bn_r(x))).abs().max()) < 1e-5
+
+
+def test_bn_relu_2d_grouped_equals_successive_calls(emul_lib):
+    """3 views stacked along the batch dim with groups=3 == three successive BatchNorm2d calls (statistics,
+    running stats, gradients of the shared affine parameters)."""
+    import copy
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(37)
+    bn = torch.nn.BatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+    bn_r = copy.deepcopy(bn)
+    views = [(torch.randn(2, 8, 10, 12, generator=g) * (1 + i) + 0.3 * i) for i in range(3)]
+    x = torch.cat(views, 0).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    vr = [v.clone().requires_grad_(True) for v in views]
+    y = ops.BnReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, 0.1, 3)
+    yr = torch.cat([F.relu(bn_r(v)) for v in vr], 0)
+    assert float((y - yr).abs().max()) < 1e-5
+    gy = torch.randn(yr.shape, generator=g)
+    y.backward(gy)
+    yr.backward(gy)
+    assert float((x.grad - torch.cat([v.grad for v in vr], 0)).abs().max()) < 1e-5
+    assert rel_l1(bn.weight.grad, bn_r.weight.grad) < 1e-5 and rel_l1(bn.bias.grad, bn_r.bias.grad) < 1e-5
+    assert torch.allclose(bn.running_mean, bn_r.running_mean, atol=1e-6)
+    assert torch.allclose(bn.running_var, bn_r.running_var, atol=1e-6, rtol=1e-5)

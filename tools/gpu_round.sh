@@ -6,6 +6,14 @@ what=${1:-all}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
+if [ "$what" = "tbk" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED" gpurun_out/pytest_gpu.log | tail -5
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -12
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
+  [ -x tools/valu_rate.bin ] && timeout 60 tools/valu_rate.bin | tee gpurun_out/valu_rate.log
+fi
 if [ "$what" = "b" ]; then
   timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -12
@@ -32,6 +40,7 @@ fi
 if [ "$what" = "kernels" ] || [ "$what" = "all" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; cat gpurun_out/kernels.log | grep -v Warning
   [ -x tools/mfma_rate.bin ] && timeout 60 tools/mfma_rate.bin | tee gpurun_out/mfma_rate.log
+  [ -x tools/valu_rate.bin ] && timeout 60 tools/valu_rate.bin | tee gpurun_out/valu_rate.log
 fi
 if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
   rm -rf gpurun_out/prof
