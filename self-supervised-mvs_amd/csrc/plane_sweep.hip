@@ -221,12 +221,11 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const float inv_n = 1.0f / (float)(NS_T + 1);
     const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
     const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
-    // per view: homography rows applied to (x,y,1) once, cached base texel, its 2x2 block and the 0/1
-    // in-image masks of its columns / rows (zero padding is applied through the weights, so the re-gather
-    // is branch-free: clamped addresses, 4 unconditional taps)
+    // (a branch-free re-gather -- clamped addresses, zero padding folded into the weights -- measured 5 % slower:
+    //  profiles/r01_run10_kernels.log vs r01_run7_kernels.log; the kernel waits on the re-gather, not on issue slots)
+    // per view: homography rows applied to (x,y,1) once, cached base texel and its 2x2 block
     float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
     int cx[NS_T], cy[NS_T];
-    float mx0[NS_T], mx1[NS_T], my0[NS_T], my1[NS_T];
     float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
@@ -236,19 +235,15 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
         tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
         cx[s] = -0x40000000; cy[s] = -0x40000000;
-        mx0[s] = mx1[s] = my0[s] = my1[s] = 0.f;
 #pragma unroll
         for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 S0[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) S0[k] = a.ms_alias ? r2[k] : r[k];
 
     for (int d = d0; d < d1; ++d) {
         const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
         float4 S[V], Q[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) { S[k] = S0[k]; Q[k] = r2[k]; }
+        for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
             const float zz = fmaf(rz[s], dep, tz[s]);
@@ -258,28 +253,24 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
             const float fx = floorf(ix), fy = floorf(iy);
             const float wx = ix - fx, wy = iy - fy;
-            // clamp in float (robust for huge / non-finite coordinates), NaN -> far outside
+            const float ex = 1.0f - wx, ey = 1.0f - wy;
             const float fxc = fminf(fmaxf(fx, -2.0f), (float)a.W), fyc = fminf(fmaxf(fy, -2.0f), (float)a.H);
-            const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;
+            const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;  // NaN -> outside
             if (x0 != cx[s] || y0 != cy[s]) {
                 cx[s] = x0; cy[s] = y0;
-                mx0[s] = (x0 >= 0 && x0 < a.W) ? 1.f : 0.f; mx1[s] = (x0 + 1 >= 0 && x0 + 1 < a.W) ? 1.f : 0.f;
-                my0[s] = (y0 >= 0 && y0 < a.H) ? 1.f : 0.f; my1[s] = (y0 + 1 >= 0 && y0 + 1 < a.H) ? 1.f : 0.f;
-                const int xa = min(max(x0, 0), a.W - 1), xb = min(max(x0 + 1, 0), a.W - 1);
-                const int ya = min(max(y0, 0), a.H - 1), yb = min(max(y0 + 1, 0), a.H - 1);
-                const float* __restrict__ f = a.src[s] + fbase;
-                const float* __restrict__ p00 = f + (ya * a.W + xa) * C;
-                const float* __restrict__ p01 = f + (ya * a.W + xb) * C;
-                const float* __restrict__ p10 = f + (yb * a.W + xa) * C;
-                const float* __restrict__ p11 = f + (yb * a.W + xb) * C;
+                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    t00[s][k] = ld4(p00 + 4 * k); t01[s][k] = ld4(p01 + 4 * k);
-                    t10[s][k] = ld4(p10 + 4 * k); t11[s][k] = ld4(p11 + 4 * k);
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + 4 * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + 4 * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + 4 * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + 4 * k) : z4;
                 }
             }
-            const float exm = (1.0f - wx) * mx0[s], wxm = wx * mx1[s], eym = (1.0f - wy) * my0[s], wym = wy * my1[s];
-            const float w00 = eym * exm, w01 = eym * wxm, w10 = wym * exm, w11 = wym * wxm;
+            const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 float4 v;
