@@ -317,7 +317,10 @@ struct WgradArgs {
 template <int GEOM, int CC, int NBW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     using G = ConvGeom<GEOM>;
-    constexpr int CCP = CC + 4;
+    // voxel stride in LDS: a half-wave of the A read (ds_read_b32) covers two consecutive positions x 16 channels;
+    // the two 16-bank windows are disjoint iff the position stride is 16 mod 32 floats: 16 for stride 1 (stride 2
+    // would need 24, which does not fit the 160 KB LDS next to the G tile, so it keeps the padded 20)
+    constexpr int CCP = (CC == 16 && G::IS == 1) ? 16 : CC + 4;
     constexpr int NR = G::RD * G::RH * G::RW;
     constexpr int NPOS = G::TQD * G::TQH * G::TQW;
     constexpr int COP = NBW * 16 + ((NBW % 2 == 0) ? 16 : 0);
@@ -686,16 +689,36 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_kernel(ConvArgs a, const floa
 // quarter of the tile's positions; persistent over tiles, dW kept in accumulators, waves summed through LDS.
 __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     using G = ConvGeom<GEOM_S1>;
-    constexpr int CC = 16, CCP = CC + 4;
-    constexpr int NR = G::RD * G::RH * G::RW;
+    // LDS image of the X halo region: 16 floats per voxel, ODD row / plane strides (RHP x RWP = 7 x 19), so the
+    // bank window (16 of 32 banks) of a voxel is selected by the parity of rd+rh+rw.  Each MFMA's four lane groups
+    // read four different taps; pairing an even-parity tap with an odd-parity tap in each half-wave makes every
+    // ds_read_b32 of the A operand conflict-free (with the natural tap order 1/3 of the reads were 2-way).
+    constexpr int CC = 16, CCP = 16;
+    constexpr int RHP = 7, RWP = 19;
+    constexpr int NRP = G::RD * RHP * RWP;
     constexpr int NPOS = G::TQD * G::TQH * G::TQW;   // 256
     constexpr int NTG = 7;                           // tap groups of 4 (27 -> 28)
-    __shared__ __attribute__((aligned(16))) float xt[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float xt[NRP * CCP];
     __shared__ __attribute__((aligned(16))) float gt[NPOS * 8];
-    __shared__ int tapoff[32];
+    __shared__ int tapmap[32];   // slot (tg, lane group) -> tap id (27 = dummy)
+    __shared__ int tapoff[32];   // slot -> LDS offset of that tap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.y;
-    if (tid < 32) tapoff[tid] = tid < 27 ? (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP : 0;
+    if (tid == 0) {
+        int ne = 0, no = 0;
+        int ev[16], od[16];
+        for (int t = 0; t < 27; ++t) {
+            if (((t / 9) + (t / 3) % 3 + t % 3) & 1) od[no++] = t; else ev[ne++] = t;   // 14 even, 13 odd
+        }
+        od[no++] = 27;   // dummy partner of the 14th even tap
+        for (int tg = 0; tg < NTG; ++tg)
+            for (int grp = 0; grp < 4; ++grp) {
+                const int t = (grp & 1) ? od[2 * tg + (grp >> 1)] : ev[2 * tg + (grp >> 1)];
+                const int tt = t < 27 ? t : od[0];   // dummy reads a valid odd-parity location, result discarded
+                tapmap[4 * tg + grp] = t;
+                tapoff[4 * tg + grp] = (((tt / 9) * RHP + (tt / 3) % 3) * RWP + tt % 3) * CCP;
+            }
+    }
     __syncthreads();
     int toff[NTG];
 #pragma unroll
@@ -713,14 +736,14 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
         const int b = t;
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
         __syncthreads();
-        for (int i = tid; i < NR * (CC / 4); i += 256) {
+        for (int i = tid; i < G::RD * G::RH * G::RW * (CC / 4); i += 256) {
             const int vox = i / (CC / 4), cq = i % (CC / 4);
             const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
             const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
                 v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq);
-            *reinterpret_cast<float4*>(&xt[vox * CCP + 4 * cq]) = v;
+            *reinterpret_cast<float4*>(&xt[((rd * RHP + rh) * RWP + rw) * CCP + 4 * cq]) = v;
         }
         for (int i = tid; i < NPOS * 2; i += 256) {
             const int p = i >> 1, hq = i & 1;
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
         for (int k = 0; k < NPOS / 4; ++k) {
             const int p = wave * (NPOS / 4) + k;
             const int pw_ = p % G::TQW, ph_ = (p / G::TQW) % G::TQH, pd_ = p / (G::TQW * G::TQH);
-            const int xoff = ((pd_ * G::RH + ph_) * G::RW + pw_) * CCP;
+            const int xoff = ((pd_ * RHP + ph_) * RWP + pw_) * CCP;
             const float b0 = gt[p * 8 + (lane & 3)], b1 = gt[p * 8 + 4 + (lane & 3)];
             float av[NTG];
 #pragma unroll
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
             }
         }
     }
-    // sum the 4 waves through LDS (reusing xt: 28 taps x 16 cx x 8 co = 3584 floats), then one partial image
+    // sum the 4 waves through LDS (reusing xt: 28 slots x 16 cx x 8 co = 3584 floats), then one partial image
     __syncthreads();
     for (int wv = 0; wv < 4; ++wv) {
         if (wave == wv) {
@@ -757,7 +780,7 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        // lane: block bl = lane>>2 -> tap 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
+                        // lane: block bl = lane>>2 -> slot 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
                         const int bl = lane >> 2;
                         const int idx = ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
                         if (wv == 0) xt[idx] = acc[tg][h][r];
@@ -766,9 +789,9 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
     }
-    for (int i = tid; i < 27 * 16 * 8; i += 256) {
-        const int co = i & 7, cx = (i >> 3) & 15, tap = i >> 7;
-        a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + chunk * 16 + cx) * 8 + co] = xt[i];
+    for (int i = tid; i < 28 * 16 * 8; i += 256) {
+        const int co = i & 7, cx = (i >> 3) & 15, tap = tapmap[i >> 7];
+        if (tap < 27) a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + chunk * 16 + cx) * 8 + co] = xt[i];
     }
 }
 
