@@ -75,6 +75,48 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     wp[idx] = v;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS staging helpers.  A plain `for (i = tid; i < N; i += 256) lds[..] = global[..]` loop makes hipcc wait for each
+// load before the next one (load -> s_waitcnt -> ds_write per iteration): at ~1-2 us of HBM latency per round
+// trip and ~10 round trips per tile that serialised latency was the largest term of every conv kernel here.
+// These helpers issue ALL loads of a batch first (registers), and write LDS afterwards; the split load / store
+// form lets a kernel keep the next tile's loads in flight while the MFMAs of the current tile run.
+// ------------------------------------------------------------------------------------------------
+template <int NIT, class Map>
+__device__ __forceinline__ void stage_load(float4 (&v)[NIT], int (&off)[NIT], int tid, int nitems, Map map) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        off[k] = -1;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nitems) {
+            const float* src = nullptr;
+            map(i, src, off[k]);
+            if (src) v[k] = *reinterpret_cast<const float4*>(src);
+        }
+    }
+}
+template <int NIT>
+__device__ __forceinline__ void stage_store(float* __restrict__ lds, const float4 (&v)[NIT], const int (&off)[NIT]) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+        if (off[k] >= 0) *reinterpret_cast<float4*>(lds + off[k]) = v[k];
+}
+// one-shot: batches of <= 12 float4 per thread
+template <int NITEMS, class Map>
+__device__ __forceinline__ void stage_batched(float* __restrict__ lds, int tid, Map map) {
+    constexpr int NIT = (NITEMS + 255) / 256;
+    constexpr int BATCH = NIT < 12 ? NIT : 12;
+#pragma unroll
+    for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+        float4 v[BATCH];
+        int off[BATCH];
+        stage_load<BATCH>(v, off, tid, NITEMS - 256 * k0, [&](int i, const float*& src, int& o) { map(i + 256 * k0, src, o); });
+        stage_store<BATCH>(lds, v, off);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM forward-style kernel (conv s1/s2, transposed s2; dgrads map onto these)
 // ------------------------------------------------------------------------------------------------
@@ -146,17 +188,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (cls == 0) {
                 // ---- stage the input halo region (channels [chunk*CC, +CC)) into LDS ----
                 __syncthreads();
-                for (int i = tid; i < NR * CQ; i += 256) {
+                stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
                     const int vox = i / CQ, cq = i % CQ;
                     const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
                     const int id = qd0 * G::IS + rd - G::PAD, ih = qh0 * G::IS + rh - G::PAD,
                               iw = qw0 * G::IS + rw - G::PAD;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o = vox * CCP + 4 * cq;
                     if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                        v = *reinterpret_cast<const float4*>(
-                            a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
-                    *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
-                }
+                        src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq;
+                });
                 __syncthreads();
             }
             int KS, kk0, tapbase;
@@ -360,16 +400,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int b = t;
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
         __syncthreads();
-        for (int i = tid; i < NR * CQ; i += 256) {
+        stage_batched<NR * CQ>(xt, tid, [&](int i, const float*& src, int& o) {
             const int vox = i / CQ, cq = i % CQ;
             const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
             const int id = qd0 * G::IS + rd - 1, ih = qh0 * G::IS + rh - 1, iw = qw0 * G::IS + rw - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            o = vox * CCP + 4 * cq;
             if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                v = *reinterpret_cast<const float4*>(
-                    a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq);
-            *reinterpret_cast<float4*>(&xt[vox * CCP + 4 * cq]) = v;
-        }
+                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq;
+        });
         for (int i = tid; i < NPOS * NBW * 16; i += 256) {
             const int p = i / (NBW * 16), n = i % (NBW * 16);
             const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
@@ -460,15 +498,14 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     const int b = t;
     const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
     for (int i = tid; i < 27 * CIN; i += 256) wl[i] = w[(size_t)(i % CIN) * 27 + i / CIN];   // W[0][ci][tap]
-    for (int i = tid; i < NR * CQ; i += 256) {
+    stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
         const int vox = i / CQ, cq = i % CQ;
         const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
         const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        o = vox * CCP + 4 * cq;
         if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-            v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CIN + 4 * cq);
-        *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
-    }
+            src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CIN + 4 * cq;
+    });
     __syncthreads();
     const int pw = tid % G::TQW, ph = (tid / G::TQW) % G::TQH, pd = tid / (G::TQW * G::TQH);
     const int base = ((pd * G::RH + ph) * G::RW + pw) * CCP;
@@ -594,26 +631,41 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_kernel(ConvArgs a, const floa
     for (int v = 0; v < NV; ++v) { acc[v][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[v][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int nchunks = a.Cin / CC;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();
-        for (int i = tid; i < NR * CQ; i += 256) {
+    constexpr int XIT = (NR * CQ + 255) / 256;          // float4 of the input halo tile per thread
+    constexpr int WIT = (27 * CQ * 32 + 255) / 256;     // weight floats per thread
+    float4 xv[XIT];
+    int xo[XIT];
+    float wv[WIT];
+    auto load_chunk = [&](int chunk) {
+        stage_load<XIT>(xv, xo, tid, NR * CQ, [&](int i, const float*& src, int& o) {
             const int vox = i / CQ, cq = i % CQ;
             const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
             const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            o = vox * CCP + 4 * cq;
             if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
-            *reinterpret_cast<float4*>(&tile[vox * CCP + 4 * cq]) = v;
-        }
-        for (int i = tid; i < 27 * CQ * 32; i += 256) {
-            const int kk = i & 3, j = (i >> 2) & 3, h = (i >> 4) & 1, cq = (i >> 5) % CQ, tap = (i >> 5) / CQ;
-            const int co = j + 4 * h, ci = chunk * CC + 4 * cq + kk;
-            const int kidx = flip ? 26 - tap : tap;
+                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq;
+        });
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int i = tid + 256 * k;
             float v = 0.f;
-            if (co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
-            wl[i] = v;
+            if (i < 27 * CQ * 32) {
+                const int kk = i & 3, j = (i >> 2) & 3, h = (i >> 4) & 1, cq = (i >> 5) % CQ, tap = (i >> 5) / CQ;
+                const int co = j + 4 * h, ci = chunk * CC + 4 * cq + kk;
+                const int kidx = flip ? 26 - tap : tap;
+                if (co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
+            }
+            wv[k] = v;
         }
+    };
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();                                   // previous chunk's MFMAs have read the LDS image
+        stage_store<XIT>(tile, xv, xo);
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) { const int i = tid + 256 * k; if (i < 27 * CQ * 32) wl[i] = wv[k]; }
         __syncthreads();
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);    // in flight while this chunk's MFMAs run
         for (int tap = 0; tap < 27; ++tap) {
             const int toff = (((tap / 9) * RH + (tap / 3) % 3) * RW + tap % 3) * CCP;
 #pragma unroll
@@ -728,32 +780,40 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     for (int tg = 0; tg < NTG; ++tg) { acc[tg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[tg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int ntiles = a.B * a.ntd * a.nth * a.ntw;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    constexpr int NXI = G::RD * G::RH * G::RW * (CC / 4);
+    constexpr int XIT = (NXI + 255) / 256, GIT = (NPOS * 2 + 255) / 256;
+    float4 xv[XIT], gv[GIT];
+    int xo[XIT], go[GIT];
+    auto load_tile = [&](int tile) {
         int t = tile;
         const int tw = t % a.ntw; t /= a.ntw;
         const int th = t % a.nth; t /= a.nth;
         const int td = t % a.ntd; t /= a.ntd;
         const int b = t;
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-        __syncthreads();
-        for (int i = tid; i < G::RD * G::RH * G::RW * (CC / 4); i += 256) {
+        stage_load<XIT>(xv, xo, tid, NXI, [&](int i, const float*& src, int& o) {
             const int vox = i / (CC / 4), cq = i % (CC / 4);
             const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
             const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            o = ((rd * RHP + rh) * RWP + rw) * CCP + 4 * cq;
             if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                v = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq);
-            *reinterpret_cast<float4*>(&xt[((rd * RHP + rh) * RWP + rw) * CCP + 4 * cq]) = v;
-        }
-        for (int i = tid; i < NPOS * 2; i += 256) {
+                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq;
+        });
+        stage_load<GIT>(gv, go, tid, NPOS * 2, [&](int i, const float*& src, int& o) {
             const int p = i >> 1, hq = i & 1;
             const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            o = p * 8 + 4 * hq;
             if (qd < a.QD && qh < a.QH && qw < a.QW)
-                v = *reinterpret_cast<const float4*>(a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * 8 + 4 * hq);
-            *reinterpret_cast<float4*>(&gt[p * 8 + 4 * hq]) = v;
-        }
+                src = a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * 8 + 4 * hq;
+        });
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                     // previous tile's MFMAs have read the LDS images
+        stage_store<XIT>(xt, xv, xo);
+        stage_store<GIT>(gt, gv, go);
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);   // in flight during this tile's MFMAs
 #pragma unroll 2
         for (int k = 0; k < NPOS / 4; ++k) {
             const int p = wave * (NPOS / 4) + k;

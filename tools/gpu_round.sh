@@ -14,6 +14,11 @@ if [ "$what" = "tbk" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
   [ -x tools/valu_rate.bin ] && timeout 60 tools/valu_rate.bin | tee gpurun_out/valu_rate.log
 fi
+if [ "$what" = "kb" ]; then
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -14
+fi
 if [ "$what" = "k" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
 fi
