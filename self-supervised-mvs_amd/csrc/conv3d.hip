@@ -392,22 +392,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 
     const int ntiles = a.B * a.ntd * a.nth * a.ntw;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // next tile's X region and G tile are fetched into registers while this tile's MFMAs run (when they fit: the
+    // stride-2 / 16-channel case needs 24 float4 per thread and stages without the overlap)
+    constexpr int XIT = (NR * CQ + 255) / 256;
+    constexpr int NG4 = NPOS * NBW * 4;                 // float4 of the G tile (CG % 4 == 0 path)
+    constexpr int GIT = (NG4 + 255) / 256;
+    constexpr bool PREFETCH = XIT <= 12;
+    constexpr int XR = PREFETCH ? XIT : 1, GR = PREFETCH ? GIT : 1;
+    float4 xv[XR], gv[GR];
+    int xo[XR], go[GR];
+    const bool g_vec = (a.CG % 4) == 0;
+    auto tile_origin = [&](int tile, int& b, int& qd0, int& qh0, int& qw0) {
         int t = tile;
         const int tw = t % a.ntw; t /= a.ntw;
         const int th = t % a.nth; t /= a.nth;
         const int td = t % a.ntd; t /= a.ntd;
-        const int b = t;
-        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-        __syncthreads();
-        stage_batched<NR * CQ>(xt, tid, [&](int i, const float*& src, int& o) {
+        b = t; qd0 = td * G::TQD; qh0 = th * G::TQH; qw0 = tw * G::TQW;
+    };
+    auto xmap = [&](int b, int qd0, int qh0, int qw0) {
+        return [=, &a](int i, const float*& src, int& o) {
             const int vox = i / CQ, cq = i % CQ;
             const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
             const int id = qd0 * G::IS + rd - 1, ih = qh0 * G::IS + rh - 1, iw = qw0 * G::IS + rw - 1;
             o = vox * CCP + 4 * cq;
             if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
                 src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq;
-        });
+        };
+    };
+    auto gmap = [&](int b, int qd0, int qh0, int qw0) {
+        return [=, &a](int i, const float*& src, int& o) {
+            const int p = i / (NBW * 4), n4 = i % (NBW * 4);
+            const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
+            const int co = cobase + 4 * n4;
+            o = p * COP + 4 * n4;
+            if (qd < a.QD && qh < a.QH && qw < a.QW && co < a.CG)
+                src = a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * a.CG + co;
+        };
+    };
+    auto stage_g_scalar = [&](int b, int qd0, int qh0, int qw0) {   // CG not a multiple of 4
         for (int i = tid; i < NPOS * NBW * 16; i += 256) {
             const int p = i / (NBW * 16), n = i % (NBW * 16);
             const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
@@ -417,7 +439,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 v = a.g[((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * a.CG + co];
             gt[p * COP + n] = v;
         }
+    };
+    if (PREFETCH && g_vec && (int)blockIdx.x < ntiles) {
+        int b, qd0, qh0, qw0;
+        tile_origin(blockIdx.x, b, qd0, qh0, qw0);
+        stage_load<XR>(xv, xo, tid, NR * CQ, xmap(b, qd0, qh0, qw0));
+        stage_load<GR>(gv, go, tid, NG4, gmap(b, qd0, qh0, qw0));
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b, qd0, qh0, qw0;
+        tile_origin(tile, b, qd0, qh0, qw0);
         __syncthreads();
+        if (PREFETCH && g_vec) {
+            stage_store<XR>(xt, xv, xo);
+            stage_store<GR>(gt, gv, go);
+            __syncthreads();
+            if (tile + (int)gridDim.x < ntiles) {
+                int b2, d2, h2, w2;
+                tile_origin(tile + gridDim.x, b2, d2, h2, w2);
+                stage_load<XR>(xv, xo, tid, NR * CQ, xmap(b2, d2, h2, w2));
+                stage_load<GR>(gv, go, tid, NG4, gmap(b2, d2, h2, w2));
+            }
+        } else {
+            stage_batched<NR * CQ>(xt, tid, xmap(b, qd0, qh0, qw0));
+            if (g_vec) stage_batched<NG4>(gt, tid, gmap(b, qd0, qh0, qw0));
+            else stage_g_scalar(b, qd0, qh0, qw0);
+            __syncthreads();
+        }
         for (int ks = 0; ks < NPOS / 4; ++ks) {
             const int p = 4 * ks + kpos;
             const int pw_ = p % G::TQW, ph_ = (p / G::TQW) % G::TQH, pd_ = p / (G::TQW * G::TQH);
@@ -563,19 +611,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_cg1_kernel(WgradArgs a) {
         const int b = t;
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
         __syncthreads();
-        for (int i = tid; i < NR * CX; i += 256) {
-            const int vox = i / CX, c = i % CX;
-            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
-            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            float v = 0.f;
-            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                v = a.x[((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CX + c];
-            xt[vox * CCP + c] = v;
-        }
         {
+            // all loads of the tile first (float4), then the LDS writes (odd voxel stride -> 4 scalar writes each)
+            constexpr int XIT = (NR * (CX / 4) + 255) / 256;
+            float4 xv[XIT];
+            int xo[XIT];
+            stage_load<XIT>(xv, xo, tid, NR * (CX / 4), [&](int i, const float*& src, int& o) {
+                const int vox = i / (CX / 4), cq = i % (CX / 4);
+                const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                o = vox * CCP + 4 * cq;
+                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CX + 4 * cq;
+            });
             const int pw = tid % G::TQW, ph = (tid / G::TQW) % G::TQH, pd = tid / (G::TQW * G::TQH);
             const int qd = qd0 + pd, qh = qh0 + ph, qw = qw0 + pw;
-            gt[tid] = (qd < a.QD && qh < a.QH && qw < a.QW) ? a.g[(((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw] : 0.f;
+            const float gval = (qd < a.QD && qh < a.QH && qw < a.QW) ? a.g[(((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw] : 0.f;
+#pragma unroll
+            for (int k = 0; k < XIT; ++k)
+                if (xo[k] >= 0) { xt[xo[k]] = xv[k].x; xt[xo[k] + 1] = xv[k].y; xt[xo[k] + 2] = xv[k].z; xt[xo[k] + 3] = xv[k].w; }
+            gt[tid] = gval;
         }
         __syncthreads();
 #pragma unroll 4

@@ -622,9 +622,13 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
             float* const gpA = a.gsrc[sA] + fbase;
             float* const gpB = sB >= 0 ? a.gsrc[sB] + fbase : gpA;
             float* const winB = win + WCAP * CP;
+            // the upstream gradient streams from HBM (one float4 per plane and thread): fetch plane d+1 while plane d
+            // is processed, otherwise every iteration eats a full HBM round trip at 2 waves/SIMD
+            float4 g_next = ld4(a.gvar + (((size_t)b * a.D + ds) * HW + pix) * C + 4 * q);
             for (int d = ds; d < de; ++d) {
                 const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
-                const float4 g = ld4(a.gvar + (((size_t)b * a.D + d) * HW + pix) * C + 4 * q);
+                const float4 g = g_next;
+                if (d + 1 < de) g_next = ld4(a.gvar + (((size_t)b * a.D + d + 1) * HW + pix) * C + 4 * q);
                 float4 S = a.warp_only ? make_float4(0.f, 0.f, 0.f, 0.f)
                                        : (a.ms_alias ? make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w) : r);
                 if (!a.warp_only)
