@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             const float fx = floorf(ix), fy = floorf(iy);
             const float wx = ix - fx, wy = iy - fy;
             const float ex = 1.0f - wx, ey = 1.0f - wy;
-            const float fxc = fminf(fmaxf(fx, -2.0f), (float)a.W), fyc = fminf(fmaxf(fy, -2.0f), (float)a.H);
-            const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;  // NaN -> outside
+            // v_cvt_i32_f32 saturates (huge -> INT_MAX/INT_MIN: every tap outside the image; NaN -> 0 with NaN
+            // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
+            const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
             if (x0 != cx[s] || y0 != cy[s]) {
                 cx[s] = x0; cy[s] = y0;
                 const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
@@ -715,7 +716,7 @@ static int g_sweep_fwd_variant = -1;
 static int sweep_fwd_variant() {
     if (g_sweep_fwd_variant < 0) {
         const char* e = getenv("MVS_SWEEP_FWD");
-        g_sweep_fwd_variant = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
+        g_sweep_fwd_variant = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 3;
     }
     return g_sweep_fwd_variant;
 }
@@ -728,7 +729,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return MVS_OK; }
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
 }
@@ -740,11 +741,13 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
     a.nt_store = g_sweep_nt;
-    if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6)) {
+    if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6) && !(variant == 4 && a.NS > 2)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
-        const bool c8 = variant == 3 && CPT8 == 8;
-        const int ppb = c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB;
-        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c8 ? TileC<C, CPT8>::TW : TileC<C, 4>::TW);
+        constexpr int CPT16 = C >= 32 ? 16 : CPT8;
+        const bool c16 = variant == 4 && CPT16 == 16;
+        const bool c8 = !c16 && variant >= 3 && CPT8 == 8;
+        const int ppb = c16 ? TileC<C, CPT16>::PPB : (c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB);
+        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? TileC<C, CPT8>::TW : TileC<C, 4>::TW));
         if (tw > ppb) tw = ppb;
         while (ppb % tw) --tw;
         a.tile_w = tw;
@@ -753,7 +756,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
-        if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a);      \
+        if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
+        else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;
         switch (a.NS) {

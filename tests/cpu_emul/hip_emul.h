@@ -170,3 +170,5 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_NT_STORE4(ptr, o) (*reinterpret_cast<float4*>(ptr) = (o))
 #define MVS_RCP(x) (1.0f / (x))
+static inline int emul_f2i(float x) { return x != x ? 0 : (x >= 2147483647.0f ? 2147483647 : (x <= -2147483648.0f ? (-2147483647 - 1) : (int)x)); }
+#define MVS_F2I(x) emul_f2i(x)

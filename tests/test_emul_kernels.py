@@ -220,7 +220,7 @@ def test_plane_sweep_bwd_segmented_windows(emul_lib):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
     """All forward variants (taps through L1, LDS windows, register-cached 4/8 channels per thread)."""
     from mvs_amd import ops

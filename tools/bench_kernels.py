@@ -65,13 +65,13 @@ def main():
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     with torch.no_grad():
-        for variant, label in ((0, "direct"), (1, "lds"), (2, "cached4"), (3, "cached8")):
+        for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (4, "cached16")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        for variant, tw in ((2, 32), (2, 16), (3, 64), (3, 32), (3, 16)):
+        for variant, tw in ((3, 16), (4, 32), (4, 8)):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             lib.call("mvs_set_tuning", b"tile_w", tw)
-            add("sweep_fwd[cached%d tile_w=%d]" % (4 if variant == 2 else 8, tw),
+            add("sweep_fwd[cached%d tile_w=%d]" % ({2: 4, 3: 8, 4: 16}[variant], tw),
                 lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
         lib.call("mvs_set_tuning", b"tile_w", 0)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)
