@@ -722,11 +722,13 @@ static int sweep_fwd_variant() {
 }
 static int g_sweep_nt = 0;
 static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
+static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
 extern int g_conv_split;
 extern int g_conv_c8;
 extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
+    if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }
@@ -741,6 +743,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
     a.nt_store = g_sweep_nt;
+    if (g_sweep_dslab > 0) a.dslab = g_sweep_dslab;
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6) && !(variant == 4 && a.NS > 2)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
         constexpr int CPT16 = C >= 32 ? 16 : CPT8;
@@ -753,6 +756,14 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         a.tile_w = tw;
         a.tiles_x = mvs_cdiv(a.W, tw);
         a.tiles_y = mvs_cdiv(a.H, ppb / tw);
+        if (g_sweep_dslab <= 0) {
+            // >= ~5000 workgroups, >= 8 planes each: measured optimum 12-16 planes at config 2
+            // (profiles/r01_run16_k1_depth_slab_sweep.log); fewer, longer workgroups lose to load imbalance
+            const long tiles = (long)a.tiles_x * a.tiles_y * a.B;
+            int slab = a.D;
+            while (slab > 8 && tiles * mvs_cdiv(a.D, slab) < 5000) slab = (slab + 1) / 2;
+            a.dslab = slab;
+        }
         dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \

@@ -378,3 +378,66 @@ def test_cvp_three_level_train_step_vs_gpu_oracle(dev):
         if e > 5e-2:
             bad.append((k, e))
     assert not bad, bad
+
+
+def test_config3_shape_batch2_five_views_vs_gpu_oracle(dev):
+    """BASELINE config 3 shape class: N=5 views, batch 2 per rank (reduced 128x160, D=32): exercises batch > 1 in
+    every kernel and the grouped BatchNorm path (5 view groups x 2 samples) against the oracle on the same GPU."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(2, 5, 128, 160, 32, seed=3)
+    imgs[1] = imgs[1] * 0.7 + 0.2
+    net = net.to(dev).train()
+    oracle = oracle.to(dev).train()
+    o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+    r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
+    assert o["depth"].shape == (2, 32, 40)
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    o["depth"].mean().backward()
+    r["depth"].mean().backward()
+    bad = []
+    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
+        if k.endswith("prob.bias"):
+            continue
+        e = rel_l1(p.grad, q.grad)
+        if e > 5e-2:
+            bad.append((k, e))
+    assert not bad, bad
+    sd, so = net.state_dict(), oracle.state_dict()
+    for k in sd:
+        if "running" in k:
+            assert torch.allclose(sd[k], so[k], atol=1e-4, rtol=1e-3), k
+        if "num_batches" in k:
+            assert int(sd[k]) == int(so[k]), k
+
+
+def test_config5_shape_seven_views_eval(dev):
+    """BASELINE config 5 shape class (N=7, large image, D=128) in fp32 eval mode at 800x592 vs the GPU oracle."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 7, 592, 800, 128, seed=5)
+    net = net.to(dev)
+    oracle = oracle.to(dev)
+    net.train()
+    oracle.train()
+    with torch.no_grad():   # one calibration pass each so the eval pass is not degenerate
+        net(imgs.to(dev), proj.to(dev), dv.to(dev))
+        oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
+    net.eval()
+    oracle.eval()
+    with torch.no_grad():
+        o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+        r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
+    assert o["depth"].shape == (1, 148, 200)
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    assert float((o["photometric_confidence"] - r["photometric_confidence"]).abs().mean()) < 5e-3

@@ -68,11 +68,18 @@ def main():
         for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (4, "cached16")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        for variant, tw in ((3, 16), (4, 32), (4, 8)):
+        for variant, tw in ():
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             lib.call("mvs_set_tuning", b"tile_w", tw)
             add("sweep_fwd[cached%d tile_w=%d]" % ({2: 4, 3: 8, 4: 16}[variant], tw),
                 lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        for variant in (2, 3):
+            for ds in (12, 24):
+                lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+                lib.call("mvs_set_tuning", b"dslab", ds)
+                add("sweep_fwd[cached%d dslab=%d]" % ({2: 4, 3: 8}[variant], ds),
+                    lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        lib.call("mvs_set_tuning", b"dslab", 0)
         lib.call("mvs_set_tuning", b"tile_w", 0)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
@@ -81,6 +88,8 @@ def main():
         add("calibration: copy_ 503 MB (read+write)", lambda: tmp.copy_(var), "hbm", 2 * C * vox * 4)
         del tmp
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
+    if os.environ.get('MVS_BENCH_SWEEP_ONLY'):
+        return
     # backward of the sweep
     fr = [f.clone().requires_grad_(True) for f in feats]
     v = ops.plane_sweep_variance(fr[0], fr[1:], rot, trans, depth)

@@ -19,6 +19,19 @@ if [ "$what" = "kb" ]; then
   timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -14
 fi
+if [ "$what" = "pmc" ] || [ "$what" = "final" ]; then
+  # HBM traffic of the roofline kernels: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_$c" -o pmc -- \
+        python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_$c.log" 2>&1); echo "pmc $c exit $?"
+  done
+  python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json; cat gpurun_out/pmc_summary.json
+  rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+fi
+if [ "$what" = "ks" ]; then
+  MVS_BENCH_SWEEP_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_sweep.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_sweep.log
+fi
 if [ "$what" = "k" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
 fi
