@@ -13,43 +13,42 @@ from ...nn3d import batched_bn_counters
 from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d
 
 
+# (name, Cin, Cout, kernel, stride, pad) in registration order == the reference's (same seed => same init)
+_FEATURE_LAYERS = (("conv0", 3, 8, 3, 1, 1), ("conv1", 8, 8, 3, 1, 1), ("conv2", 8, 16, 5, 2, 2), ("conv3", 16, 16, 3, 1, 1),
+                   ("conv4", 16, 16, 3, 1, 1), ("conv5", 16, 32, 5, 2, 2), ("conv6", 32, 32, 3, 1, 1))
+# (name, Cin, Cout, stride) of the encoder, then (name, Cin, Cout, skip source) of the decoder
+_REG_ENCODER = (("conv0", 32, 8, 1), ("conv1", 8, 16, 2), ("conv2", 16, 16, 1), ("conv3", 16, 32, 2), ("conv4", 32, 32, 1),
+                ("conv5", 32, 64, 2), ("conv6", 64, 64, 1))
+_REG_DECODER = (("conv7", 64, 32, "conv4"), ("conv9", 32, 16, "conv2"), ("conv11", 16, 8, "conv0"))
+
+
 class FeatureNet(nn.Module):
-    """mvsnet.py:17-34 -- 3 -> 32 channels at 1/4 resolution."""
+    """mvsnet.py:17-34 -- 2-D CNN, 3 -> 32 channels at 1/4 resolution (stock PyTorch convolutions)."""
 
     def __init__(self):
         super().__init__()
         self.inplanes = 32
-        self.conv0 = ConvBnReLU(3, 8, 3, 1, 1)
-        self.conv1 = ConvBnReLU(8, 8, 3, 1, 1)
-        self.conv2 = ConvBnReLU(8, 16, 5, 2, 2)
-        self.conv3 = ConvBnReLU(16, 16, 3, 1, 1)
-        self.conv4 = ConvBnReLU(16, 16, 3, 1, 1)
-        self.conv5 = ConvBnReLU(16, 32, 5, 2, 2)
-        self.conv6 = ConvBnReLU(32, 32, 3, 1, 1)
+        for name, cin, cout, k, stride, pad in _FEATURE_LAYERS:
+            setattr(self, name, ConvBnReLU(cin, cout, k, stride, pad))
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
 
     def forward(self, x, groups=1):
         """groups: number of views stacked along the batch dim (per-view BatchNorm statistics are kept)."""
-        x = self.conv1(self.conv0(x, groups), groups)
-        x = self.conv4(self.conv3(self.conv2(x, groups), groups), groups)
-        return self.feature(self.conv6(self.conv5(x, groups), groups))
+        for name, *_ in _FEATURE_LAYERS:
+            x = getattr(self, name)(x, groups)
+        return self.feature(x)
 
 
 class CostRegNet(nn.Module):
-    """mvsnet.py:37-74: 3-D U-Net 32 -> 8 -> 16 -> 32 -> 64 -> ... -> 1; D, H, W divisible by 8."""
+    """mvsnet.py:37-74: 3-D U-Net 32 -> 8 -> 16 -> 32 -> 64 -> ... -> 1; D, H, W divisible by 8.  Decoder blocks
+    add their skip AFTER the ReLU (mvsnet.py:70-72), fused into the block's BatchNorm-apply kernel."""
 
     def __init__(self):
         super().__init__()
-        self.conv0 = ConvBnReLU3D(32, 8)
-        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
-        self.conv2 = ConvBnReLU3D(16, 16)
-        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
-        self.conv4 = ConvBnReLU3D(32, 32)
-        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
-        self.conv6 = ConvBnReLU3D(64, 64)
-        self.conv7 = DeconvBnReLU3D(64, 32, stride=2)
-        self.conv9 = DeconvBnReLU3D(32, 16, stride=2)
-        self.conv11 = DeconvBnReLU3D(16, 8, stride=2)
+        for name, cin, cout, stride in _REG_ENCODER:
+            setattr(self, name, ConvBnReLU3D(cin, cout, stride=stride))
+        for name, cin, cout, _ in _REG_DECODER:
+            setattr(self, name, DeconvBnReLU3D(cin, cout, stride=2))
         self.prob = ProbConv3d(8)
 
     def forward(self, x):
@@ -57,32 +56,30 @@ class CostRegNet(nn.Module):
             raise ValueError("CostRegNet expects [B,32,D,H,W], got %s" % (tuple(x.shape),))
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("CostRegNet needs D,H,W divisible by 8, got %s" % (tuple(x.shape[2:]),))
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        x = self.conv6(self.conv5(conv4))
-        x = self.conv7(x, skip=conv4)    # conv4 + relu(bn(deconv(x)))   (mvsnet.py:70)
-        x = self.conv9(x, skip=conv2)
-        x = self.conv11(x, skip=conv0)
+        keep = {}
+        for name, *_ in _REG_ENCODER:
+            x = getattr(self, name)(x)
+            keep[name] = x
+        for name, _, _, skip in _REG_DECODER:
+            x = getattr(self, name)(x, skip=keep[skip])
         return self.prob(x)
 
 
 class RefineNet(nn.Module):
-    """mvsnet.py:77-92 (off by default in the reference, config.py:48)."""
+    """mvsnet.py:77-92 (off by default in the reference, config.py:48): residual on the 1/4-resolution image + depth."""
 
     def __init__(self):
         super().__init__()
-        self.conv1 = ConvBnReLU(4, 32)
-        self.conv2 = ConvBnReLU(32, 32)
-        self.conv3 = ConvBnReLU(32, 32)
-        self.res = ConvBnReLU(32, 1)
+        for name, cin, cout in (("conv1", 4, 32), ("conv2", 32, 32), ("conv3", 32, 32), ("res", 32, 1)):
+            setattr(self, name, ConvBnReLU(cin, cout))
 
     def forward(self, img, depth_init):
-        img = F.interpolate(img, scale_factor=0.25, mode='bilinear')
-        depth_init = depth_init.unsqueeze(dim=1)
-        concat = torch.cat((img, depth_init), dim=1)
-        depth_residual = self.res(self.conv3(self.conv2(self.conv1(concat))))
-        return (depth_init + depth_residual).squeeze(dim=1)
+        small = F.interpolate(img, scale_factor=0.25, mode='bilinear')
+        d = depth_init.unsqueeze(1)
+        x = torch.cat((small, d), dim=1)
+        for name in ("conv1", "conv2", "conv3", "res"):
+            x = getattr(self, name)(x)
+        return (d + x).squeeze(1)
 
 
 class MVSNet(nn.Module):

@@ -10,47 +10,41 @@ from .modules import (ALIGN_CORNERS, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, _
                       calSweepingDepthHypo, conditionIntrinsics, conv, proj_cost)
 
 
+_PYRAMID_LAYERS = (("conv0aa", 3, 64), ("conv0ba", 64, 64), ("conv0bb", 64, 64), ("conv0bc", 64, 32), ("conv0bd", 32, 32),
+                   ("conv0be", 32, 32), ("conv0bf", 32, 16), ("conv0bg", 16, 16), ("conv0bh", 16, 16))
+_CVP_ENCODER = (("conv0", 16, 16, 1), ("conv0a", 16, 16, 1), ("conv1", 16, 32, 2), ("conv2", 32, 32, 1), ("conv2a", 32, 32, 1),
+                ("conv3", 32, 64, 1), ("conv4", 64, 64, 1), ("conv4a", 64, 64, 1))
+
+
 class FeaturePyramid(nn.Module):
     """network.py:16-41 -- 9 conv+LeakyReLU blocks, shared over a x0.5 image pyramid (stock PyTorch)."""
 
     def __init__(self):
         super().__init__()
-        self.conv0aa = conv(3, 64, kernel_size=3, stride=1)
-        self.conv0ba = conv(64, 64, kernel_size=3, stride=1)
-        self.conv0bb = conv(64, 64, kernel_size=3, stride=1)
-        self.conv0bc = conv(64, 32, kernel_size=3, stride=1)
-        self.conv0bd = conv(32, 32, kernel_size=3, stride=1)
-        self.conv0be = conv(32, 32, kernel_size=3, stride=1)
-        self.conv0bf = conv(32, 16, kernel_size=3, stride=1)
-        self.conv0bg = conv(16, 16, kernel_size=3, stride=1)
-        self.conv0bh = conv(16, 16, kernel_size=3, stride=1)
+        for name, cin, cout in _PYRAMID_LAYERS:
+            setattr(self, name, conv(cin, cout, kernel_size=3, stride=1))
 
     def _trunk(self, img):
-        f = self.conv0aa(img)
-        return self.conv0bh(self.conv0bg(self.conv0bf(self.conv0be(self.conv0bd(self.conv0bc(self.conv0bb(
-            self.conv0ba(f))))))))
+        for name, *_ in _PYRAMID_LAYERS:
+            img = getattr(self, name)(img)
+        return img
 
     def forward(self, img, scales=5):
-        fp = [self._trunk(img)]
+        levels = [self._trunk(img)]
         for _ in range(scales - 1):
             img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=None).detach()
-            fp.append(self._trunk(img))
-        return fp
+            levels.append(self._trunk(img))
+        return levels
 
 
 class CostRegNet(nn.Module):
-    """network.py:44-74; one down-sampling, even D/H/W required; weights shared by all pyramid levels."""
+    """network.py:44-74; one down-sampling, even D/H/W required; weights shared by all pyramid levels.
+    conv5 is a STRIDE-1 transposed convolution, conv6 stride 2; both add their skip after the ReLU (network.py:71-72)."""
 
     def __init__(self):
         super().__init__()
-        self.conv0 = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
-        self.conv0a = ConvBnReLU3D(16, 16, kernel_size=3, pad=1)
-        self.conv1 = ConvBnReLU3D(16, 32, stride=2, kernel_size=3, pad=1)
-        self.conv2 = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
-        self.conv2a = ConvBnReLU3D(32, 32, kernel_size=3, pad=1)
-        self.conv3 = ConvBnReLU3D(32, 64, kernel_size=3, pad=1)
-        self.conv4 = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
-        self.conv4a = ConvBnReLU3D(64, 64, kernel_size=3, pad=1)
+        for name, cin, cout, stride in _CVP_ENCODER:
+            setattr(self, name, ConvBnReLU3D(cin, cout, stride=stride, kernel_size=3, pad=1))
         self.conv5 = DeconvBnReLU3D(64, 32, stride=1)
         self.conv6 = DeconvBnReLU3D(32, 16, stride=2)
         self.prob0 = ProbConv3d(16)
@@ -60,12 +54,13 @@ class CostRegNet(nn.Module):
             raise ValueError("CVP CostRegNet expects [B,16,D,H,W], got %s" % (tuple(x.shape),))
         if any(s % 2 for s in x.shape[2:]):
             raise ValueError("CVP CostRegNet needs even D,H,W, got %s" % (tuple(x.shape[2:]),))
-        conv0 = self.conv0a(self.conv0(x))
-        conv2 = self.conv2a(self.conv2(self.conv1(conv0)))
-        conv4 = self.conv4a(self.conv4(self.conv3(conv2)))
-        conv5 = self.conv5(conv4, skip=conv2)   # conv2 + relu(bn(deconv_s1(conv4)))  (network.py:71)
-        conv6 = self.conv6(conv5, skip=conv0)
-        return self.prob0(conv6).squeeze(1)
+        keep = {}
+        for name, *_ in _CVP_ENCODER:
+            x = getattr(self, name)(x)
+            keep[name] = x
+        x = self.conv5(x, skip=keep["conv2a"])
+        x = self.conv6(x, skip=keep["conv0a"])
+        return self.prob0(x).squeeze(1)
 
 
 class CVPMVSNet(nn.Module):

@@ -417,7 +417,7 @@ def test_config3_shape_batch2_five_views_vs_gpu_oracle(dev):
 
 
 def test_config5_shape_seven_views_eval(dev):
-    """BASELINE config 5 shape class (N=7, large image, D=128) in fp32 eval mode at 800x592 vs the GPU oracle."""
+    """BASELINE config 5 shape class (N=7, large image, D=128) in fp32 eval mode at 800x608 vs the GPU oracle."""
     from mvs_amd.jdacs.models.mvsnet import MVSNet
     torch.manual_seed(0)
     net = MVSNet(refine=False)
@@ -425,7 +425,7 @@ def test_config5_shape_seven_views_eval(dev):
         net.cost_regularization.prob.weight.mul_(50.0)
     oracle = R.OracleMVSNet(refine=False)
     oracle.load_state_dict(net.state_dict())
-    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 7, 592, 800, 128, seed=5)
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 7, 608, 800, 128, seed=5)
     net = net.to(dev)
     oracle = oracle.to(dev)
     net.train()
@@ -438,6 +438,6 @@ def test_config5_shape_seven_views_eval(dev):
     with torch.no_grad():
         o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
         r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
-    assert o["depth"].shape == (1, 148, 200)
+    assert o["depth"].shape == (1, 152, 200)
     assert rel_l1(o["depth"], r["depth"]) < 1e-3
     assert float((o["photometric_confidence"] - r["photometric_confidence"]).abs().mean()) < 5e-3
