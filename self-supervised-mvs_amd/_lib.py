@@ -92,11 +92,19 @@ class MvsLib:
 
 _INSTANCE = None
 
+# library defaults of the measurement knobs (csrc: g_conv_c8, g_conv_xcd); MVS_TUNING="k8=2,xcd=0" overrides them
+# for A/B runs of bench.py / tools without touching code
+DEFAULT_TUNING = {"k8": 1, "xcd": 1}
+
 
 def get() -> MvsLib:
     global _INSTANCE
     if _INSTANCE is None:
         _INSTANCE = MvsLib()
+        for item in filter(None, os.environ.get("MVS_TUNING", "").split(",")):
+            key, _, val = item.partition("=")
+            DEFAULT_TUNING[key.strip()] = int(val)
+            _INSTANCE.call("mvs_set_tuning", key.strip().encode(), int(val))
     return _INSTANCE
 
 

@@ -77,6 +77,35 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
 
 
 // ------------------------------------------------------------------------------------------------
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
+// xcd_block() gives every XCD one contiguous range of the tile order, and brick_tile() makes that order bricks
+// of (all W tiles) x (4 H tiles) marching along D: tiles resident together on an XCD share their halos in L2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_block(int bid, int nb) {
+    const int per = nb >> 3, rem = nb & 7, x = bid & 7, idx = bid >> 3;
+    return x * per + (x < rem ? x : rem) + idx;
+}
+__device__ __forceinline__ void brick_tile(int t, int ntw, int nth, int ntd, int& b, int& td, int& th, int& tw) {
+    const int per_b = ntw * nth * ntd;
+    b = t / per_b;
+    int r = t - b * per_b;
+    const int full = ntw * 4 * ntd;
+    int g = r / full, gh = 4;
+    if (g >= (nth >> 2)) { g = nth >> 2; gh = nth & 3; }
+    r -= g * full;
+    td = r / (ntw * gh);
+    r -= td * (ntw * gh);
+    th = g * 4 + r / ntw;
+    tw = r % ntw;
+}
+__device__ __forceinline__ void linear_tile(int t, int ntw, int nth, int ntd, int& b, int& td, int& th, int& tw) {
+    tw = t % ntw; t /= ntw;
+    th = t % nth; t /= nth;
+    td = t % ntd; t /= ntd;
+    b = t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS staging helpers.  A plain `for (i = tid; i < N; i += 256) lds[..] = global[..]` loop makes hipcc wait for each
 // load before the next one (load -> s_waitcnt -> ds_write per iteration): at ~1-2 us of HBM latency per round
 // trip and ~10 round trips per tile that serialised latency was the largest term of every conv kernel here.
@@ -352,6 +381,7 @@ struct WgradArgs {
     float* part;         // [gridDim.x][27][CX][CG]
     int B, Di, Hi, Wi, CX, CG;
     int QD, QH, QW, ntd, nth, ntw;
+    int xcd;             // XCD-aware tile order (conv_c8_wgrad_kernel)
 };
 
 template <int GEOM, int CC, int NBW>
@@ -789,11 +819,199 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_kernel(ConvArgs a, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cout == 8 forward, second form: the WEIGHTS are the broadcast operand and never touch LDS.
+// v_mfma_f32_4x4x1_16b_f32 has a block-broadcast control on its A operand (cbsz = 4, abid = k: all 16 blocks
+// use the A values of block k).  One VGPR per (tap, channel half h) therefore carries the weights of 16 input
+// channels: lane (k = l>>2, i = l&3) holds w[ci = k][co = 4h + i], and `abid` selects the input channel.
+// The B operand is the voxel value of the lane's own position, so D leaves each lane with 4 (x2) consecutive
+// output channels of ITS position -> float4 stores.  LDS carries only the halo tile (one ds_read_b128 per 8
+// MFMAs); the channel chunk is 16 floats = one 64-byte segment per voxel (the 8-channel chunks of the first
+// form fetched every 128-byte line four times, 32 bytes at a time: profiles/r01_run17_pmc_summary.json).
+// Tile 4 x 4 x 16 positions, 4 waves, one row group per wave.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma_4x4x1_bc(float a, float b, f32x4 c, int k) {
+    switch (k) {   // folded after unrolling: abid must be an immediate
+        case 0: return MVS_MFMA_4x4x1_BC(a, b, c, 0);
+        case 1: return MVS_MFMA_4x4x1_BC(a, b, c, 1);
+        case 2: return MVS_MFMA_4x4x1_BC(a, b, c, 2);
+        case 3: return MVS_MFMA_4x4x1_BC(a, b, c, 3);
+        case 4: return MVS_MFMA_4x4x1_BC(a, b, c, 4);
+        case 5: return MVS_MFMA_4x4x1_BC(a, b, c, 5);
+        case 6: return MVS_MFMA_4x4x1_BC(a, b, c, 6);
+        case 7: return MVS_MFMA_4x4x1_BC(a, b, c, 7);
+        case 8: return MVS_MFMA_4x4x1_BC(a, b, c, 8);
+        case 9: return MVS_MFMA_4x4x1_BC(a, b, c, 9);
+        case 10: return MVS_MFMA_4x4x1_BC(a, b, c, 10);
+        case 11: return MVS_MFMA_4x4x1_BC(a, b, c, 11);
+        case 12: return MVS_MFMA_4x4x1_BC(a, b, c, 12);
+        case 13: return MVS_MFMA_4x4x1_BC(a, b, c, 13);
+        case 14: return MVS_MFMA_4x4x1_BC(a, b, c, 14);
+        default: return MVS_MFMA_4x4x1_BC(a, b, c, 15);
+    }
+}
+
+template <int CC, int NCH>
+__global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const float* __restrict__ w, int wlayout, int flip, int xcd) {
+    constexpr int TQD = 4, TQH = 4, TQW = 16;
+    constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
+    constexpr int CCP = CC + 4, CQ = CC / 4, NR = RD * RH * RW;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ float red[4 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b, td, th, tw;
+    if (xcd) brick_tile(xcd_block(blockIdx.x, gridDim.x), a.ntw, a.nth, a.ntd, b, td, th, tw);
+    else linear_tile(blockIdx.x, a.ntw, a.nth, a.ntd, b, td, th, tw);
+    const int qd0 = td * TQD, qh0 = th * TQH, qw0 = tw * TQW;
+    // this lane's position: plane `wave` of the tile, row lane>>4, column lane&15
+    const int baseB = ((wave * RH + (lane >> 4)) * RW + (lane & 15)) * CCP;
+
+    constexpr int XIT = (NR * CQ + 255) / 256;
+    float4 xv[XIT];
+    int xo[XIT];
+    auto load_chunk = [&](int chunk) {
+        stage_load<XIT>(xv, xo, tid, NR * CQ, [&](int i, const float*& src, int& o) {
+            const int vox = i / CQ, cq = i % CQ;
+            const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+            o = vox * CCP + 4 * cq;
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq;
+        });
+    };
+    load_chunk(0);
+    // weights: wr[ch][tap][h] = w[ci = ch*CC + (lane>>2)][co = 4h + (lane&3)][tap]
+    float wr[NCH][27][2];
+    {
+        const int k = lane >> 2, i = lane & 3;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ci = ch * CC + k, co = 4 * h + i;
+                const bool ok = k < CC && co < a.Cout;
+                const float* wp = wlayout == WL_OIK ? w + ((size_t)co * a.Cin + ci) * 27 : w + ((size_t)ci * a.Cout + co) * 27;
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) wr[ch][tap][h] = ok ? wp[flip ? 26 - tap : tap] : 0.f;
+            }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { acc[p][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch) __syncthreads();                          // previous chunk's reads of the LDS image are done
+        stage_store<XIT>(tile, xv, xo);
+        __syncthreads();
+        if (ch + 1 < NCH) load_chunk(ch + 1);              // in flight while this chunk's MFMAs run
+        // the tile reads run one tap ahead of the MFMAs that consume them
+        float4 xq[2][CQ];
+        auto read_tap = [&](int tap, float4 (&dst)[CQ]) {
+            const int toff = (((tap / 9) * RH + (tap / 3) % 3) * RW + tap % 3) * CCP;
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) dst[cq] = *reinterpret_cast<const float4*>(&tile[baseB + toff + 4 * cq]);
+        };
+        read_tap(0, xq[0]);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) read_tap(tap + 1, xq[(tap + 1) & 1]);
+            MVS_SCHED_FENCE();   // (hipcc otherwise sinks the reads to just before their first use)
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+                const float4 x4 = xq[tap & 1][cq];
+                const int p = cq & 1;
+                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.x, acc[p][0], 4 * cq + 0);
+                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.x, acc[p][1], 4 * cq + 0);
+                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.y, acc[p][0], 4 * cq + 1);
+                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.y, acc[p][1], 4 * cq + 1);
+                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.z, acc[p][0], 4 * cq + 2);
+                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.z, acc[p][1], 4 * cq + 2);
+                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.w, acc[p][0], 4 * cq + 3);
+                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.w, acc[p][1], 4 * cq + 3);
+            }
+        }
+    }
+    // epilogue: the lane owns position (qd0 + wave, qh0 + lane>>4, qw0 + lane&15) and channels 4h + r
+    const int qd = qd0 + wave, qh = qh0 + (lane >> 4), qw = qw0 + (lane & 15);
+    const bool inside = qd < a.QD && qh < a.QH && qw < a.QW;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * h + r;
+            float val = acc[0][h][r] + acc[1][h][r];
+            if (!inside || co >= a.Cout) val = 0.f;
+            s1[co] = val;
+            s2[co] = val * val;
+            if (co < a.Cout) {
+                if (a.scale) val = val * a.scale[co] + a.shift[co];
+                else if (a.shift) val = val + a.shift[co];
+                if (a.relu) val = fmaxf(val, 0.f);
+            }
+            o[r] = val;
+        }
+        if (inside) {
+            const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout + 4 * h;
+            if (a.Cout == 8) {
+                float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+                if (a.skip) {
+                    const float4 sk = *reinterpret_cast<const float4*>(a.skip + obase);
+                    ov.x += sk.x; ov.y += sk.y; ov.z += sk.z; ov.w += sk.w;
+                }
+                *reinterpret_cast<float4*>(a.y + obase) = ov;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * h + r < a.Cout) a.y[obase + r] = o[r] + (a.skip ? a.skip[obase + r] : 0.f);
+            }
+        }
+    }
+    if (a.partials) {
+        // 16 per-lane values -> wave sums by a halving butterfly: after the step with mask m a lane keeps the
+        // half of its values selected by its bit m, so the exchange count is 8+4+2+1 (+2 full steps) instead of 16*6
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v[c] = s1[c]; v[8 + c] = s2[c]; }
+#pragma unroll
+        for (int n = 8, m = 32; n >= 1; n >>= 1, m >>= 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int q = 0; q < n; ++q) {
+                const float keep = up ? v[n + q] : v[q];
+                const float send = up ? v[q] : v[n + q];
+                v[q] = keep + __shfl_xor(send, m);
+            }
+        }
+        // lane now holds value index (bit5,bit4,bit3,bit2 of lane) summed over the lanes that share those bits
+        float r = v[0];
+        r += __shfl_xor(r, 2);
+        r += __shfl_xor(r, 1);
+        if ((lane & 3) == 0) {
+            const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            red[wave * 16 + idx] = r;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int stat = tid >> 3, co = tid & 7;
+            if (co < a.Cout)
+                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] =
+                    red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+        }
+    }
+}
+
 
 // Weight gradient for CG == 8 (conv0, mvsnet.py:40) with the 16-block 4x4x1 MFMA: per position ONE MFMA
 // accumulates (4 taps x 16 input channels) x (4 output channels); 7 tap groups x 2 channel halves = 14 MFMAs
 // per position, 96 % useful (the 16x16x4 form pads N 8 -> 16 and was 50 % useful).  Each wave takes a
 // quarter of the tile's positions; persistent over tiles, dW kept in accumulators, waves summed through LDS.
+// BC = true: the output gradient is the MFMA's broadcast operand instead (cbsz = 4: one VGPR pair carries g of 16
+// consecutive W positions, abid selects the position), so g costs 2 LDS reads per 16 positions instead of 2 per
+// position and each lane ends up owning its (tap, input channel) for 4 output channels.
+template <bool BC>
 __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     using G = ConvGeom<GEOM_S1>;
     // LDS image of the X halo region: 16 floats per voxel, ODD row / plane strides (RHP x RWP = 7 x 19), so the
@@ -840,11 +1058,9 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     float4 xv[XIT], gv[GIT];
     int xo[XIT], go[GIT];
     auto load_tile = [&](int tile) {
-        int t = tile;
-        const int tw = t % a.ntw; t /= a.ntw;
-        const int th = t % a.nth; t /= a.nth;
-        const int td = t % a.ntd; t /= a.ntd;
-        const int b = t;
+        int b, td, th, tw;
+        if (a.xcd) brick_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        else linear_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
         stage_load<XIT>(xv, xo, tid, NXI, [&](int i, const float*& src, int& o) {
             const int vox = i / (CC / 4), cq = i % (CC / 4);
@@ -862,13 +1078,34 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
                 src = a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * 8 + 4 * hq;
         });
     };
-    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int vb = a.xcd ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // co-resident workgroups of an XCD take neighbouring tiles
+    if (vb < ntiles) load_tile(vb);
+    for (int tile = vb; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                     // previous tile's MFMAs have read the LDS images
         stage_store<XIT>(xt, xv, xo);
         stage_store<GIT>(gt, gv, go);
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);   // in flight during this tile's MFMAs
+        if (BC) {
+            static_assert(G::TQW == 16 && G::TQH == 4, "one group of 16 positions = one W row of the tile");
+#pragma unroll 1
+            for (int g16 = 0; g16 < 4; ++g16) {                 // wave = plane of the tile, g16 = row
+                const int p0 = wave * 64 + g16 * 16;
+                const int xoff0 = ((wave * RHP + g16) * RWP) * CCP;
+                const float ga0 = gt[(p0 + (lane >> 2)) * 8 + (lane & 3)], ga1 = gt[(p0 + (lane >> 2)) * 8 + 4 + (lane & 3)];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float av[NTG];
+#pragma unroll
+                    for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[xoff0 + k * CCP + toff[tg]];
+#pragma unroll
+                    for (int tg = 0; tg < NTG; ++tg) {
+                        acc[tg][0] = mfma_4x4x1_bc(ga0, av[tg], acc[tg][0], k);
+                        acc[tg][1] = mfma_4x4x1_bc(ga1, av[tg], acc[tg][1], k);
+                    }
+                }
+            }
+        } else {
 #pragma unroll 2
         for (int k = 0; k < NPOS / 4; ++k) {
             const int p = wave * (NPOS / 4) + k;
@@ -884,6 +1121,7 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
                 acc[tg][1] = MVS_MFMA_4x4x1(av[tg], b1, acc[tg][1]);
             }
         }
+        }
     }
     // sum the 4 waves through LDS (reusing xt: 28 slots x 16 cx x 8 co = 3584 floats), then one partial image
     __syncthreads();
@@ -896,8 +1134,10 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // lane: block bl = lane>>2 -> slot 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
+                        // (BC: the lane is (slot, cx) = (lane>>4, lane&15) and reg r -> co = 4h + r)
                         const int bl = lane >> 2;
-                        const int idx = ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
+                        const int idx = BC ? ((4 * tg + (lane >> 4)) * 16 + (lane & 15)) * 8 + 4 * h + r
+                                           : ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
                         if (wv == 0) xt[idx] = acc[tg][h][r];
                         else xt[idx] += acc[tg][h][r];
                     }
@@ -942,7 +1182,8 @@ static size_t packed_floats(int geom, int cin, int cout) {
 }
 
 int g_conv_split = 1;
-int g_conv_c8 = 1;      // tuning knob "k8": 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernel   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
+int g_conv_c8 = 1;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
+int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
 
 template <int GEOM, int CC>
 static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
@@ -978,6 +1219,14 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     } else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
     const int tqd = geom == GEOM_S2 ? 2 : 4;
     a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    if ((g_conv_c8 & 2) && geom == GEOM_S1 && cout == 8 && (cin == 8 || cin == 16 || cin == 32)) {
+        // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions
+        const int nbc = B * a.ntd * a.nth * a.ntw;
+        if (cin == 32) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 2>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
+        else if (cin == 16) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
+        else MVS_LAUNCH((conv_c8_fwd_bc_kernel<8, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
+        return mvs_check_launch("conv_c8_fwd_bc");
+    }
     if (g_conv_c8 && geom == GEOM_S1 && cout == 8 && cin % 8 == 0) {
         // 4x4x1 MFMA path, tile 4 x 8 x 16 positions
         a.nth = mvs_cdiv(a.QH, 8);
@@ -1035,7 +1284,7 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
                 "conv wgrad: X channels must be 8/16/32/64, got %d", CX);
     MVS_REQUIRE(CG >= 1 && CG <= 64, MVS_ERR_UNSUPPORTED, "conv wgrad: G channels must be <= 64, got %d", CG);
     WgradArgs a = {};
-    a.x = X; a.g = Gt; a.part = ws; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.CX = CX; a.CG = CG;
+    a.x = X; a.g = Gt; a.part = ws; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.CX = CX; a.CG = CG; a.xcd = g_conv_xcd;
     if (geom == GEOM_S1) { a.QD = Di; a.QH = Hi; a.QW = Wi; }
     else { a.QD = (Di - 1) / 2 + 1; a.QH = (Hi - 1) / 2 + 1; a.QW = (Wi - 1) / 2 + 1; }
     a.ntd = mvs_cdiv(a.QD, geom == GEOM_S2 ? 2 : 4); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
@@ -1045,7 +1294,8 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     const int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
     if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
         const int g8 = ntiles < 512 ? ntiles : 512;   // 60 KB LDS -> 2 resident workgroups per CU
-        MVS_LAUNCH(conv_c8_wgrad_kernel, dim3(g8, CX / 16), dim3(256), 0, st, a);
+        if (g_conv_c8 & 4) MVS_LAUNCH(conv_c8_wgrad_kernel<true>, dim3(g8, CX / 16), dim3(256), 0, st, a);
+        else MVS_LAUNCH(conv_c8_wgrad_kernel<false>, dim3(g8, CX / 16), dim3(256), 0, st, a);
         int rc8 = mvs_check_launch("conv_c8_wgrad");
         if (rc8) return rc8;
         return wgrad_finish(ws, g8, CX, CG, gw, st);
@@ -1110,6 +1360,9 @@ extern "C" long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int
 
 // rows of the [rows][2][Cout] BatchNorm partial-sum buffer a forward call writes
 extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin, int Cout, int stride) {
+    if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && (g_conv_c8 & 2) && Cout == 8 &&
+        (Cin == 8 || Cin == 16 || Cin == 32))
+        return igemm_blocks(GEOM_S1, B, D, H, W);                        // conv_c8_fwd_bc_kernel tiling
     if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && g_conv_c8 && Cout == 8 && Cin % 8 == 0)
         return B * mvs_cdiv(D, 4) * mvs_cdiv(H, 8) * mvs_cdiv(W, 16);   // conv_c8_fwd_kernel tiling
     if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W);

@@ -17,8 +17,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #define MVS_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define MVS_RCP(x) __builtin_amdgcn_rcpf(x)
+#define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating
 #define MVS_MFMA_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+// cbsz = 4: the A operand of block `abid` (lanes 4*abid .. 4*abid+3) is broadcast to all 16 blocks
+#define MVS_MFMA_4x4x1_BC(a, b, c, abid) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (abid), 0)
 #define MVS_NT_STORE4(ptr, o) \
     __builtin_nontemporal_store((f32x4){(o).x, (o).y, (o).z, (o).w}, reinterpret_cast<f32x4*>(ptr))
 // Address-space-explicit float atomics: a generic (flat) pointer makes hipcc emit flat_atomic_add_f32 even

@@ -107,6 +107,19 @@ static inline f32x4 emul_mfma_4x4x1(float a, float b, f32x4 c) {
     return c;
 }
 #define MVS_MFMA_4x4x1(a, b, c) emul_mfma_4x4x1((a), (b), (c))
+// same with cbsz = 4 / abid: every block takes its A rows from block `abid`
+static inline f32x4 emul_mfma_4x4x1_bc(float a, float b, f32x4 c, int abid) {
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    int l = emul::lane;
+    w->fa[s][l] = a;
+    w->fb[s][l] = b;
+    pthread_barrier_wait(&w->bar);
+    for (int r = 0; r < 4; ++r) c[r] = fmaf(w->fa[s][abid * 4 + r], w->fb[s][l], c[r]);
+    return c;
+}
+#define MVS_SCHED_FENCE() ((void)0)
+#define MVS_MFMA_4x4x1_BC(a, b, c, abid) emul_mfma_4x4x1_bc((a), (b), (c), (abid))
 
 static inline float atomicAdd(float* addr, float v) {
     unsigned* p = (unsigned*)addr;

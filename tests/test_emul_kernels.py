@@ -329,3 +329,42 @@ def test_costregnet_cvp_golden(emul_lib):
     assert rel_l1(x.grad, g["grad_x"]) < 5e-3
     for k, p in net.named_parameters():
         assert rel_l1(p.grad, g["grad." + k]) < 5e-3, k
+
+
+@pytest.mark.parametrize("cin,dims,xcd", [(32, (5, 9, 18), 1), (16, (4, 22, 16), 1), (8, (3, 4, 33), 0), (32, (4, 4, 16), 0)])
+def test_conv_c8_broadcast_operand_forward(emul_lib, cin, dims, xcd):
+    """Cout == 8 stride-1 forward with the weights as the MFMA broadcast operand (tuning k8 = 7): conv, epilogue
+    (scale/shift/relu/skip), BN stat partials and both tile orders vs F.conv3d (mvsnet.py:40 conv0, network.py:47)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + dims[1])
+    x = torch.randn(2, cin, *dims, generator=g)
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    yr = F.conv3d(x, w, padding=1)
+    emul_lib.call("mvs_set_tuning", b"k8", 7)
+    emul_lib.call("mvs_set_tuning", b"xcd", xcd)
+    try:
+        y, parts = ops.conv3d_forward(x, w, 1, False, want_stats=True)
+        assert float((y - yr).abs().max()) < 2e-4
+        s = parts.sum(0)
+        assert torch.allclose(s[0], yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+        assert torch.allclose(s[1], (yr ** 2).sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+        scale = torch.rand(8, generator=g) + 0.5
+        shift = torch.randn(8, generator=g)
+        skip = torch.randn(yr.shape, generator=g)
+        y2, _ = ops.conv3d_forward(x, w, 1, False, scale=scale, shift=shift, relu=True, skip=skip)
+        ref2 = F.relu(yr * scale.view(1, 8, 1, 1, 1) + shift.view(1, 8, 1, 1, 1)) + skip
+        assert float((y2 - ref2).abs().max()) < 3e-4
+        gy = torch.randn(yr.shape, generator=g)
+        wr = w.clone().requires_grad_(True)
+        F.conv3d(x, wr, padding=1).backward(gy)
+        gw = ops.conv3d_wgrad(x, gy, tuple(w.shape), 1, False)   # cin 16/32: output gradient as the broadcast operand
+        assert float((gw - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+        # transposed stride-1 weights (dgrad of a 8 -> cin conv maps onto this path only for cout == 8, i.e. cin == 8)
+        if cin == 8:
+            gx = ops.conv3d_dgrad(yr, w, tuple(x.shape), 1, False)
+            xr = x.clone().requires_grad_(True)
+            F.conv3d(xr, w, padding=1).backward(yr)
+            assert float((gx - xr.grad).abs().max()) < 2e-3
+    finally:
+        emul_lib.call("mvs_set_tuning", b"k8", 1)
+        emul_lib.call("mvs_set_tuning", b"xcd", 1)

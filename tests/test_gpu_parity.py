@@ -159,6 +159,43 @@ def test_conv3d_family_vs_torch(dev, cin, cout, stride, transposed, dims):
     assert float((gw.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("cin,dims", [(32, (9, 18, 40)), (16, (8, 22, 16)), (8, (5, 4, 33))])
+@pytest.mark.parametrize("k8,xcd", [(7, 1), (7, 0), (1, 1), (1, 0)])
+def test_conv_cout8_forms_and_tile_orders(dev, cin, dims, k8, xcd):
+    """The Cout == 8 stride-1 layer (conv0, mvsnet.py:40 / network.py:47) in both 4x4x1-MFMA forms (k8 = 1: both operands
+    through LDS; k8 = 7: weights / output gradient as the broadcast operand) and both tile orders: forward + epilogue + stat partials + wgrad vs ATen."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(cin + dims[1])
+    x = torch.randn(2, cin, *dims, generator=g)
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    yr = yr.detach()
+    lib.call("mvs_set_tuning", b"k8", k8)
+    lib.call("mvs_set_tuning", b"xcd", xcd)
+    try:
+        y, parts = ops.conv3d_forward(x.to(dev), w.to(dev), 1, False, want_stats=True)
+        assert float((y.cpu() - yr).abs().max()) < 3e-4
+        s = parts.sum(0).cpu()
+        assert torch.allclose(s[0], yr.sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
+        assert torch.allclose(s[1], (yr ** 2).sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
+        scale = torch.rand(8, generator=g) + 0.5
+        shift = torch.randn(8, generator=g)
+        skip = torch.randn(yr.shape, generator=g)
+        y2, _ = ops.conv3d_forward(x.to(dev), w.to(dev), 1, False, scale=scale.to(dev), shift=shift.to(dev), relu=True,
+                                   skip=skip.to(dev))
+        ref2 = F.relu(yr * scale.view(1, 8, 1, 1, 1) + shift.view(1, 8, 1, 1, 1)) + skip
+        assert float((y2.cpu() - ref2).abs().max()) < 5e-4
+        gw = ops.conv3d_wgrad(x.to(dev), gy.to(dev), tuple(w.shape), 1, False)
+        assert float((gw.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+    finally:
+        lib.call("mvs_set_tuning", b"k8", _lib.DEFAULT_TUNING["k8"])
+        lib.call("mvs_set_tuning", b"xcd", _lib.DEFAULT_TUNING["xcd"])
+
+
 def _run_regnet_golden(dev, net, g, has_second):
     net.load_state_dict(state_dict_from(g))
     net = net.to(dev).train()

@@ -102,10 +102,15 @@ def main():
     with torch.no_grad():
         y0, _ = ops.conv3d_forward(var, w0, 1, False)
         gy0 = torch.randn_like(y0)
-        for k8, label in ((0, "16x16x4 padded"), (1, "4x4x1")):
+        for k8, xcd, label in ((0, 1, "16x16x4 padded"), (1, 0, "4x4x1, linear tile order"), (1, 1, "4x4x1, XCD bricks"),
+                               (7, 0, "4x4x1 broadcast operand, linear"), (7, 1, "4x4x1 broadcast operand, XCD bricks")):
             lib.call("mvs_set_tuning", b"k8", k8)
-            add("conv0 fwd 32>8 [%s]" % label, lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
+            lib.call("mvs_set_tuning", b"xcd", xcd)
+            if not (k8 == 1 and xcd == 0):   # the first-form forward has no tile-order switch
+                add("conv0 fwd 32>8 [%s]" % label, lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
             add("conv0 wgrad [%s]" % label, lambda: ops.conv3d_wgrad(var, gy0, tuple(w0.shape), 1, False), "mfma", fl0)
+        lib.call("mvs_set_tuning", b"k8", _lib.DEFAULT_TUNING["k8"])
+        lib.call("mvs_set_tuning", b"xcd", _lib.DEFAULT_TUNING["xcd"])
         add("conv0 dgrad", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
         # L0 8-channel layers
         w1 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.05).to(dev)

@@ -29,6 +29,27 @@ if [ "$what" = "pmc" ] || [ "$what" = "final" ]; then
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json; cat gpurun_out/pmc_summary.json
   rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 fi
+if [ "$what" = "x" ]; then
+  # A/B of the Cout==8 forward forms and tile orders: parity, kernel timings, HBM traffic (+ FETCH_SIZE calibration), bench
+  timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider -k "cout8 or conv3d_family or costregnet" > gpurun_out/pytest_x.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_x.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_x.log | tail -8
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -E "conv0|calibration" gpurun_out/kernels.log
+  rm -rf gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/pmc_C
+  (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_F" -o pmc -- \
+      python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_F.log" 2>&1); echo "pmc F exit $?"
+  (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_W" -o pmc -- \
+      python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_W.log" 2>&1); echo "pmc W exit $?"
+  (cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_C" -o pmc -- \
+      "$OLDPWD/tools/fetch_calib.bin" > "$OLDPWD/gpurun_out/fetch_calib.log" 2>&1); echo "calib exit $?"; cat gpurun_out/fetch_calib.log | grep SEG
+  python tools/pmc_summary.py gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/pmc_C > gpurun_out/pmc_summary.json; python -c "
+import json; d=json.load(open('gpurun_out/pmc_summary.json'))
+for k,v in d.items(): print(k, {c:x['per_dispatch'] for c,x in v.items()})"
+  rm -rf gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/pmc_C
+  for t in "k8=1,xcd=1" "k8=7,xcd=1"; do
+    MVS_TUNING=$t timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$t.json 2> gpurun_out/bench_$t.err
+    echo "bench $t exit $?"; cut -c1-200 gpurun_out/bench_$t.json
+  done
+fi
 if [ "$what" = "ks" ]; then
   MVS_BENCH_SWEEP_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_sweep.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_sweep.log
 fi
