@@ -857,78 +857,106 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
     constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
     constexpr int CCP = CC + 4, CQ = CC / 4, NR = RD * RH * RW;
     __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ float wl[NCH * 27 * 2 * 64];   // the broadcast-operand image: [chunk][tap][h][lane], read back as one ds_read_b32 per (tap, h)
     __shared__ float red[4 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b, td, th, tw;
-    if (xcd) brick_tile(xcd_block(blockIdx.x, gridDim.x), a.ntw, a.nth, a.ntd, b, td, th, tw);
-    else linear_tile(blockIdx.x, a.ntw, a.nth, a.ntd, b, td, th, tw);
-    const int qd0 = td * TQD, qh0 = th * TQH, qw0 = tw * TQW;
+    // persistent workgroups (2 per CU): the weight image is built once, and the first chunk of the next tile is
+    // fetched while the last chunk of the current one is in the MFMAs
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    const int vb = xcd ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     // this lane's position: plane `wave` of the tile, row lane>>4, column lane&15
     const int baseB = ((wave * RH + (lane >> 4)) * RW + (lane & 15)) * CCP;
 
     constexpr int XIT = (NR * CQ + 255) / 256;
     float4 xv[XIT];
-    int xo[XIT];
-    auto load_chunk = [&](int chunk) {
-        stage_load<XIT>(xv, xo, tid, NR * CQ, [&](int i, const float*& src, int& o) {
-            const int vox = i / CQ, cq = i % CQ;
-            const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
-            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            o = vox * CCP + 4 * cq;
-            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq;
-        });
+    auto tile_origin = [&](int t, int& b, int& qd0, int& qh0, int& qw0) {
+        int td, th, tw;
+        if (xcd) brick_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        else linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        qd0 = td * TQD; qh0 = th * TQH; qw0 = tw * TQW;
     };
-    load_chunk(0);
-    // weights: wr[ch][tap][h] = w[ci = ch*CC + (lane>>2)][co = 4h + (lane&3)][tap]
-    float wr[NCH][27][2];
-    {
-        const int k = lane >> 2, i = lane & 3;
+    // halo tile -> registers (all loads issued back to back; zero outside the volume), registers -> LDS
+    auto load_chunk = [&](int b, int qd0, int qh0, int qw0, int chunk) {
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ci = ch * CC + k, co = 4 * h + i;
-                const bool ok = k < CC && co < a.Cout;
-                const float* wp = wlayout == WL_OIK ? w + ((size_t)co * a.Cin + ci) * 27 : w + ((size_t)ci * a.Cout + co) * 27;
-#pragma unroll
-                for (int tap = 0; tap < 27; ++tap) wr[ch][tap][h] = ok ? wp[flip ? 26 - tap : tap] : 0.f;
+        for (int k = 0; k < XIT; ++k) {
+            const int i = tid + 256 * k;
+            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NR * CQ) {
+                const int vox = i / CQ, cq = i % CQ;
+                const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    xv[k] = *reinterpret_cast<const float4*>(
+                        a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
             }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NR * CQ) *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = xv[k];
+        }
+    };
+    int b, qd0, qh0, qw0;
+    if (vb < ntiles) {
+        tile_origin(vb, b, qd0, qh0, qw0);
+        load_chunk(b, qd0, qh0, qw0, 0);
     }
+    // wl[ch][tap][h][l] = w[ci = ch*CC + (l>>2)][co = 4h + (l&3)][tap]
+    for (int i = tid; i < NCH * 27 * 2 * 64; i += 256) {
+        const int l = i & 63, h = (i >> 6) & 1, tap = (i >> 7) % 27, ch = (i >> 7) / 27;
+        const int k = l >> 2, ci = ch * CC + k, co = 4 * h + (l & 3);
+        const int kidx = flip ? 26 - tap : tap;
+        float v = 0.f;
+        if (k < CC && co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
+        wl[i] = v;
+    }
+    for (int t = vb; t < ntiles; t += gridDim.x) {
+    tile_origin(t, b, qd0, qh0, qw0);
     f32x4 acc[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) { acc[p][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch) __syncthreads();                          // previous chunk's reads of the LDS image are done
-        stage_store<XIT>(tile, xv, xo);
+        __syncthreads();                                   // previous chunk's / tile's reads of the LDS image are done
+        store_chunk();
         __syncthreads();
-        if (ch + 1 < NCH) load_chunk(ch + 1);              // in flight while this chunk's MFMAs run
-        // the tile reads run one tap ahead of the MFMAs that consume them
+        if (ch + 1 < NCH) load_chunk(b, qd0, qh0, qw0, ch + 1);   // in flight while this chunk's MFMAs run
+        else if (t + (int)gridDim.x < ntiles) {
+            int b2, d2, h2, w2;
+            tile_origin(t + gridDim.x, b2, d2, h2, w2);
+            load_chunk(b2, d2, h2, w2, 0);
+        }
+        // the LDS reads run one tap ahead of the MFMAs that consume them
         float4 xq[2][CQ];
-        auto read_tap = [&](int tap, float4 (&dst)[CQ]) {
+        float wq[2][2];
+        auto read_tap = [&](int tap, float4 (&dst)[CQ], float (&wd)[2]) {
             const int toff = (((tap / 9) * RH + (tap / 3) % 3) * RW + tap % 3) * CCP;
 #pragma unroll
             for (int cq = 0; cq < CQ; ++cq) dst[cq] = *reinterpret_cast<const float4*>(&tile[baseB + toff + 4 * cq]);
+            wd[0] = wl[((ch * 27 + tap) * 2 + 0) * 64 + lane];
+            wd[1] = wl[((ch * 27 + tap) * 2 + 1) * 64 + lane];
         };
-        read_tap(0, xq[0]);
+        read_tap(0, xq[0], wq[0]);
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) read_tap(tap + 1, xq[(tap + 1) & 1]);
+            if (tap + 1 < 27) read_tap(tap + 1, xq[(tap + 1) & 1], wq[(tap + 1) & 1]);
             MVS_SCHED_FENCE();   // (hipcc otherwise sinks the reads to just before their first use)
+            const float w0 = wq[tap & 1][0], w1 = wq[tap & 1][1];
 #pragma unroll
             for (int cq = 0; cq < CQ; ++cq) {
                 const float4 x4 = xq[tap & 1][cq];
                 const int p = cq & 1;
-                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.x, acc[p][0], 4 * cq + 0);
-                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.x, acc[p][1], 4 * cq + 0);
-                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.y, acc[p][0], 4 * cq + 1);
-                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.y, acc[p][1], 4 * cq + 1);
-                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.z, acc[p][0], 4 * cq + 2);
-                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.z, acc[p][1], 4 * cq + 2);
-                acc[p][0] = mfma_4x4x1_bc(wr[ch][tap][0], x4.w, acc[p][0], 4 * cq + 3);
-                acc[p][1] = mfma_4x4x1_bc(wr[ch][tap][1], x4.w, acc[p][1], 4 * cq + 3);
+                acc[p][0] = mfma_4x4x1_bc(w0, x4.x, acc[p][0], 4 * cq + 0);
+                acc[p][1] = mfma_4x4x1_bc(w1, x4.x, acc[p][1], 4 * cq + 0);
+                acc[p][0] = mfma_4x4x1_bc(w0, x4.y, acc[p][0], 4 * cq + 1);
+                acc[p][1] = mfma_4x4x1_bc(w1, x4.y, acc[p][1], 4 * cq + 1);
+                acc[p][0] = mfma_4x4x1_bc(w0, x4.z, acc[p][0], 4 * cq + 2);
+                acc[p][1] = mfma_4x4x1_bc(w1, x4.z, acc[p][1], 4 * cq + 2);
+                acc[p][0] = mfma_4x4x1_bc(w0, x4.w, acc[p][0], 4 * cq + 3);
+                acc[p][1] = mfma_4x4x1_bc(w1, x4.w, acc[p][1], 4 * cq + 3);
             }
         }
     }
@@ -997,10 +1025,11 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
         if (tid < 16) {
             const int stat = tid >> 3, co = tid & 7;
             if (co < a.Cout)
-                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] =
+                a.partials[((size_t)t * 2 + stat) * a.Cout + co] =
                     red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
         }
     }
+    }   // tile loop
 }
 
 
@@ -1221,7 +1250,8 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
     if ((g_conv_c8 & 2) && geom == GEOM_S1 && cout == 8 && (cin == 8 || cin == 16 || cin == 32)) {
         // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions
-        const int nbc = B * a.ntd * a.nth * a.ntw;
+        const int ntl = B * a.ntd * a.nth * a.ntw;
+        const int nbc = ntl < 512 ? ntl : 512;            // 80 KB of LDS -> 2 resident workgroups per CU
         if (cin == 32) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 2>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
         else if (cin == 16) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
         else MVS_LAUNCH((conv_c8_fwd_bc_kernel<8, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);

@@ -37,6 +37,7 @@ struct SweepArgs {
     float sx, ox, sy, oy;  // ix = px*sx + ox, iy = py*sy + oy
     int tiles_x, tiles_y;
     int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
+    int ch_il;       // channel interleave: float4 k of lane q covers channels 4q + 4*LPP*k (one store instruction then writes whole 64-byte segments) instead of CPT*q + 4k
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
@@ -211,11 +212,12 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const int d0 = blockIdx.y * a.dslab;
     const int d1 = min(a.D, d0 + a.dslab);
     const float xf = (float)x, yf = (float)y;
-    const size_t fbase = (size_t)b * HW * C + CPT * q;
+    const int cq = a.ch_il ? 4 * q : CPT * q, ck = a.ch_il ? 4 * LPP : 4;   // channel of float4 k: cq + ck * k
+    const size_t fbase = (size_t)b * HW * C + cq;
     float4 r[V], r2[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        r[k] = ld4(a.ref + fbase + (size_t)pix * C + 4 * k);
+        r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
         r2[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
     }
     const float inv_n = 1.0f / (float)(NS_T + 1);
@@ -265,10 +267,10 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    t00[s][k] = (xin0 && yin0) ? ld4(f + 4 * k) : z4;
-                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + 4 * k) : z4;
-                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + 4 * k) : z4;
-                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + 4 * k) : z4;
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
                 }
             }
             const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
             }
         }
-        float* __restrict__ outp = a.var + (((size_t)b * a.D + d) * HW + pix) * C + CPT * q;
+        float* __restrict__ outp = a.var + (((size_t)b * a.D + d) * HW + pix) * C + cq;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float4 o;
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
             m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
             m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
-            if (a.nt_store) MVS_NT_STORE4(outp + 4 * k, o);
-            else *reinterpret_cast<float4*>(outp + 4 * k) = o;
+            if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
+            else *reinterpret_cast<float4*>(outp + ck * k) = o;
         }
     }
 }
@@ -721,12 +723,14 @@ static int sweep_fwd_variant() {
     return g_sweep_fwd_variant;
 }
 static int g_sweep_nt = 0;
+static int g_sweep_il = 1;   // tuning knob "il": channel interleave of the register-cached forward
 static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
 extern int g_conv_split;
 extern int g_conv_c8;
 extern int g_conv_xcd;
 extern "C" int mvs_set_tuning(const char* key, int value) {
+    if (key && key[0] == 'i') { g_sweep_il = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
     if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
@@ -745,6 +749,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
     a.nt_store = g_sweep_nt;
+    a.ch_il = g_sweep_il;
     if (g_sweep_dslab > 0) a.dslab = g_sweep_dslab;
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6) && !(variant == 4 && a.NS > 2)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;

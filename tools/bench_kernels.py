@@ -65,20 +65,13 @@ def main():
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     with torch.no_grad():
-        for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (4, "cached16")):
+        for variant, il, label in ((0, 0, "direct"), (2, 0, "cached4"), (3, 0, "cached8, channels 8q+4k"),
+                                   (3, 1, "cached8, channels 4q+16k"), (3, 0, "cached8, channels 8q+4k"),
+                                   (3, 1, "cached8, channels 4q+16k"), (4, 1, "cached16 il")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+            lib.call("mvs_set_tuning", b"il", il)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        for variant, tw in ():
-            lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-            lib.call("mvs_set_tuning", b"tile_w", tw)
-            add("sweep_fwd[cached%d tile_w=%d]" % ({2: 4, 3: 8, 4: 16}[variant], tw),
-                lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        for variant in (2, 3):
-            for ds in (12, 24):
-                lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-                lib.call("mvs_set_tuning", b"dslab", ds)
-                add("sweep_fwd[cached%d dslab=%d]" % ({2: 4, 3: 8}[variant], ds),
-                    lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
+        lib.call("mvs_set_tuning", b"il", 1)
         lib.call("mvs_set_tuning", b"dslab", 0)
         lib.call("mvs_set_tuning", b"tile_w", 0)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)

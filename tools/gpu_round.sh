@@ -33,7 +33,7 @@ if [ "$what" = "x" ]; then
   # A/B of the Cout==8 forward forms and tile orders: parity, kernel timings, HBM traffic (+ FETCH_SIZE calibration), bench
   timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider -k "cout8 or conv3d_family or costregnet" > gpurun_out/pytest_x.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_x.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_x.log | tail -8
-  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -E "conv0|calibration" gpurun_out/kernels.log
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -E "conv0|calibration|sweep_fwd" gpurun_out/kernels.log
   rm -rf gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/pmc_C
   (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_F" -o pmc -- \
       python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_F.log" 2>&1); echo "pmc F exit $?"
@@ -45,7 +45,7 @@ if [ "$what" = "x" ]; then
 import json; d=json.load(open('gpurun_out/pmc_summary.json'))
 for k,v in d.items(): print(k, {c:x['per_dispatch'] for c,x in v.items()})"
   rm -rf gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/pmc_C
-  for t in "k8=1,xcd=1" "k8=7,xcd=1"; do
+  for t in "k8=1,xcd=1" "k8=5,xcd=1" "k8=7,xcd=1"; do
     MVS_TUNING=$t timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$t.json 2> gpurun_out/bench_$t.err
     echo "bench $t exit $?"; cut -c1-200 gpurun_out/bench_$t.json
   done
