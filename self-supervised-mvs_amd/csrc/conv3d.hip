@@ -875,19 +875,36 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
         else linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
         qd0 = td * TQD; qh0 = th * TQH; qw0 = tw * TQW;
     };
-    // halo tile -> registers (all loads issued back to back; zero outside the volume), registers -> LDS
-    auto load_chunk = [&](int b, int qd0, int qh0, int qw0, int chunk) {
+    // halo tile -> registers (all loads issued back to back; zero outside the volume), registers -> LDS.
+    // The offset of item k relative to the tile's origin voxel does not depend on the tile, so it is computed once
+    // per (persistent) workgroup; tiles that do not touch the volume boundary skip the per-item bounds checks.
+    int rel[XIT];
 #pragma unroll
-        for (int k = 0; k < XIT; ++k) {
-            const int i = tid + 256 * k;
-            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < NR * CQ) {
-                const int vox = i / CQ, cq = i % CQ;
-                const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
-                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                    xv[k] = *reinterpret_cast<const float4*>(
-                        a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq);
+    for (int k = 0; k < XIT; ++k) {
+        const int i = tid + 256 * k, vox = i / CQ, cq = i % CQ;
+        const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+        rel[k] = (((rd - 1) * a.Hi + (rh - 1)) * a.Wi + (rw - 1)) * a.Cin + 4 * cq;
+    }
+    auto load_chunk = [&](int b, int qd0, int qh0, int qw0, int chunk) {
+        const float* __restrict__ base = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.Cin + chunk * CC;
+        const bool interior = qd0 >= 1 && qd0 + TQD + 1 <= a.Di && qh0 >= 1 && qh0 + TQH + 1 <= a.Hi &&
+                              qw0 >= 1 && qw0 + TQW + 1 <= a.Wi;
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k)
+                if (tid + 256 * k < NR * CQ) xv[k] = *reinterpret_cast<const float4*>(base + rel[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k) {
+                const int i = tid + 256 * k;
+                xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < NR * CQ) {
+                    const int vox = i / CQ;
+                    const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+                    const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                    if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                        xv[k] = *reinterpret_cast<const float4*>(base + rel[k]);
+                }
             }
         }
     };
@@ -1003,16 +1020,22 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
         float v[16];
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[c] = s1[c]; v[8 + c] = s2[c]; }
-#pragma unroll
-        for (int n = 8, m = 32; n >= 1; n >>= 1, m >>= 1) {
-            const bool up = (lane & m) != 0;
-#pragma unroll
-            for (int q = 0; q < n; ++q) {
-                const float keep = up ? v[n + q] : v[q];
-                const float send = up ? v[q] : v[n + q];
-                v[q] = keep + __shfl_xor(send, m);
-            }
+        // (written out per step: with a loop over n the array index is not a compile-time constant and hipcc
+        //  falls back to 16-way v_cndmask selection chains, ~900 VALU instructions per tile)
+#define MVS_BFLY_STEP(N, M)                                              \
+        {                                                                \
+            const bool up = (lane & (M)) != 0;                           \
+            _Pragma("unroll") for (int q = 0; q < (N); ++q) {            \
+                const float keep = up ? v[(N) + q] : v[q];               \
+                const float send = up ? v[q] : v[(N) + q];               \
+                v[q] = keep + __shfl_xor(send, (M));                     \
+            }                                                            \
         }
+        MVS_BFLY_STEP(8, 32)
+        MVS_BFLY_STEP(4, 16)
+        MVS_BFLY_STEP(2, 8)
+        MVS_BFLY_STEP(1, 4)
+#undef MVS_BFLY_STEP
         // lane now holds value index (bit5,bit4,bit3,bit2 of lane) summed over the lanes that share those bits
         float r = v[0];
         r += __shfl_xor(r, 2);
@@ -1085,34 +1108,72 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     constexpr int NXI = G::RD * G::RH * G::RW * (CC / 4);
     constexpr int XIT = (NXI + 255) / 256, GIT = (NPOS * 2 + 255) / 256;
     float4 xv[XIT], gv[GIT];
-    int xo[XIT], go[GIT];
+    // per-item offsets relative to the tile's origin voxel / position and their LDS slots: tile-invariant, computed
+    // once per persistent workgroup; tiles that do not touch the volume boundary skip the per-item bounds checks
+    int xrel[XIT], xlo[XIT], grel[GIT], glo[GIT];
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+        const int i = tid + 256 * k, vox = i / (CC / 4), cq = i % (CC / 4);
+        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+        xrel[k] = (((rd - 1) * a.Hi + (rh - 1)) * a.Wi + (rw - 1)) * a.CX + 4 * cq;
+        xlo[k] = ((rd * RHP + rh) * RWP + rw) * CCP + 4 * cq;
+    }
+#pragma unroll
+    for (int k = 0; k < GIT; ++k) {
+        const int i = tid + 256 * k, p = i >> 1, hq = i & 1;
+        const int pw = p % G::TQW, ph = (p / G::TQW) % G::TQH, pd = p / (G::TQW * G::TQH);
+        grel[k] = ((pd * a.QH + ph) * a.QW + pw) * 8 + 4 * hq;
+        glo[k] = p * 8 + 4 * hq;
+    }
     auto load_tile = [&](int tile) {
         int b, td, th, tw;
         if (a.xcd) brick_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
         else linear_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-        stage_load<XIT>(xv, xo, tid, NXI, [&](int i, const float*& src, int& o) {
-            const int vox = i / (CC / 4), cq = i % (CC / 4);
-            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
-            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            o = ((rd * RHP + rh) * RWP + rw) * CCP + 4 * cq;
-            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.CX + chunk * CC + 4 * cq;
-        });
-        stage_load<GIT>(gv, go, tid, NPOS * 2, [&](int i, const float*& src, int& o) {
-            const int p = i >> 1, hq = i & 1;
-            const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
-            o = p * 8 + 4 * hq;
-            if (qd < a.QD && qh < a.QH && qw < a.QW)
-                src = a.g + ((((size_t)b * a.QD + qd) * a.QH + qh) * a.QW + qw) * 8 + 4 * hq;
-        });
+        const float* __restrict__ xb = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.CX + chunk * CC;
+        const float* __restrict__ gb = a.g + ((((size_t)b * a.QD + qd0) * a.QH + qh0) * a.QW + qw0) * 8;
+        const bool interior = qd0 >= 1 && qd0 + G::TQD + 1 <= a.Di && qh0 >= 1 && qh0 + G::TQH + 1 <= a.Hi &&
+                              qw0 >= 1 && qw0 + G::TQW + 1 <= a.Wi;
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k)
+                if (tid + 256 * k < NXI) xv[k] = *reinterpret_cast<const float4*>(xb + xrel[k]);
+#pragma unroll
+            for (int k = 0; k < GIT; ++k)
+                if (tid + 256 * k < NPOS * 2) gv[k] = *reinterpret_cast<const float4*>(gb + grel[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k) {
+                const int i = tid + 256 * k, vox = i / (CC / 4);
+                const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < NXI && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    xv[k] = *reinterpret_cast<const float4*>(xb + xrel[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < GIT; ++k) {
+                const int i = tid + 256 * k, p = i >> 1;
+                const int qw = qw0 + p % G::TQW, qh = qh0 + (p / G::TQW) % G::TQH, qd = qd0 + p / (G::TQW * G::TQH);
+                gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < NPOS * 2 && qd < a.QD && qh < a.QH && qw < a.QW)
+                    gv[k] = *reinterpret_cast<const float4*>(gb + grel[k]);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < XIT; ++k)
+            if (tid + 256 * k < NXI) *reinterpret_cast<float4*>(xt + xlo[k]) = xv[k];
+#pragma unroll
+        for (int k = 0; k < GIT; ++k)
+            if (tid + 256 * k < NPOS * 2) *reinterpret_cast<float4*>(gt + glo[k]) = gv[k];
     };
     const int vb = a.xcd ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // co-resident workgroups of an XCD take neighbouring tiles
     if (vb < ntiles) load_tile(vb);
     for (int tile = vb; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                     // previous tile's MFMAs have read the LDS images
-        stage_store<XIT>(xt, xv, xo);
-        stage_store<GIT>(gt, gv, go);
+        store_tile();
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);   // in flight during this tile's MFMAs
         if (BC) {

@@ -50,6 +50,21 @@ for k,v in d.items(): print(k, {c:x['per_dispatch'] for c,x in v.items()})"
     echo "bench $t exit $?"; cut -c1-200 gpurun_out/bench_$t.json
   done
 fi
+if [ "$what" = "sq" ]; then
+  # where the cycles of the big kernels go: SQ busy / wait / MFMA-busy / LDS counters + effective clock (GRBM_GUI_ACTIVE)
+  (cd /tmp && timeout 120 rocprofv3 -L > "$OLDPWD/gpurun_out/rocprof_counters.txt" 2>&1); grep -c . gpurun_out/rocprof_counters.txt
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES"; do
+    i=$((i+1)); rm -rf gpurun_out/pmc_S$i
+    (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_S$i" -o pmc -- \
+        python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_S$i.log" 2>&1); echo "pmc S$i exit $?"; tail -n 2 gpurun_out/pmc_S$i.log
+  done
+  python tools/pmc_summary.py gpurun_out/pmc_S1 gpurun_out/pmc_S2 > gpurun_out/pmc_sq_summary.json; python -c "
+import json; d=json.load(open('gpurun_out/pmc_sq_summary.json'))
+for k,v in d.items(): print(k, {c:round(x['mean']) for c,x in v.items()})"
+  rm -rf gpurun_out/pmc_S1 gpurun_out/pmc_S2
+fi
 if [ "$what" = "ks" ]; then
   MVS_BENCH_SWEEP_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_sweep.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_sweep.log
 fi
