@@ -94,7 +94,7 @@ _INSTANCE = None
 
 # library defaults of the measurement knobs (csrc: g_conv_c8, g_conv_xcd); MVS_TUNING="k8=2,xcd=0" overrides them
 # for A/B runs of bench.py / tools without touching code
-DEFAULT_TUNING = {"k8": 1, "xcd": 1}
+DEFAULT_TUNING = {"k8": 7, "xcd": 1}
 
 
 def get() -> MvsLib:

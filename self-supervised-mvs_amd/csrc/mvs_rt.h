@@ -17,6 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #define MVS_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define MVS_RCP(x) __builtin_amdgcn_rcpf(x)
+#define MVS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget 512 / n per wave
 #define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating
 #define MVS_MFMA_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)

@@ -119,6 +119,7 @@ static inline f32x4 emul_mfma_4x4x1_bc(float a, float b, f32x4 c, int abid) {
     return c;
 }
 #define MVS_SCHED_FENCE() ((void)0)
+#define MVS_WAVES_PER_SIMD(n)
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) emul_mfma_4x4x1_bc((a), (b), (c), (abid))
 
 static inline float atomicAdd(float* addr, float v) {

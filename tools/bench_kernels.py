@@ -65,13 +65,13 @@ def main():
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     with torch.no_grad():
-        for variant, il, label in ((0, 0, "direct"), (2, 0, "cached4"), (3, 0, "cached8, channels 8q+4k"),
-                                   (3, 1, "cached8, channels 4q+16k"), (3, 0, "cached8, channels 8q+4k"),
-                                   (3, 1, "cached8, channels 4q+16k"), (4, 1, "cached16 il")):
+        for variant, shift, label in ((0, 1, "direct"), (2, 1, "cached4"), (3, 0, "cached8, full re-gather"),
+                                      (3, 1, "cached8, shifted block"), (3, 0, "cached8, full re-gather"),
+                                      (3, 1, "cached8, shifted block"), (2, 0, "cached4, full re-gather"), (4, 1, "cached16")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-            lib.call("mvs_set_tuning", b"il", il)
+            lib.call("mvs_set_tuning", b"hshift", shift)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
-        lib.call("mvs_set_tuning", b"il", 1)
+        lib.call("mvs_set_tuning", b"hshift", 1)
         lib.call("mvs_set_tuning", b"dslab", 0)
         lib.call("mvs_set_tuning", b"tile_w", 0)
         lib.call("mvs_set_tuning", b"sweep_fwd", 3)
