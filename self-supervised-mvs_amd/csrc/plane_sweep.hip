@@ -37,7 +37,6 @@ struct SweepArgs {
     float sx, ox, sy, oy;  // ix = px*sx + ox, iy = py*sy + oy
     int tiles_x, tiles_y;
     int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
-    int shift_cache; // register-cached forward: on a one-texel step keep the two texels that stay in the 2x2 block
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
@@ -198,8 +197,8 @@ template <int C, int CPT> struct TileC {
     static constexpr int LPP = C / CPT, PPB = 256 / LPP, TW = PPB >= 128 ? 16 : 8, TH = PPB / TW;
 };
 
-template <int C, int NS_T, int CPT>
-__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(CPT <= 8 ? 4 : 2)
+template <int C, int NS_T, int CPT, int OCC = (CPT <= 8 ? 4 : 2)>
+__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(OCC)
 void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     constexpr int V = CPT / 4;                     // float4s per tap per thread
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
@@ -218,12 +217,9 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     const int cq = 4 * q;
     constexpr int ck = 4 * LPP;
     const size_t fbase = (size_t)b * HW * C + cq;
-    float4 r[V], r2[V];
+    float4 r[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
-        r2[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
-    }
+    for (int k = 0; k < V; ++k) r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
     const float inv_n = 1.0f / (float)(NS_T + 1);
     const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
     const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
@@ -231,8 +227,8 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     //  profiles/r01_run10_kernels.log vs r01_run7_kernels.log; the kernel waits on the re-gather, not on issue slots)
     // per view: homography rows applied to (x,y,1) once, cached base texel and its 2x2 block
     float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
-    int cx[NS_T], cy[NS_T], px[NS_T], py[NS_T];
-    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];   // physical [row][column] of the cached 2x2 block
+    int cx[NS_T], cy[NS_T];
+    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];   // t00, bx, by, bxy of the cached 2x2 block
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
         const float* R = rotb + s * 9;
@@ -240,7 +236,7 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
         ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
         rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
         tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
-        cx[s] = -0x40000000; cy[s] = -0x40000000; px[s] = 0; py[s] = 0;
+        cx[s] = -0x40000000; cy[s] = -0x40000000;
 #pragma unroll
         for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -249,7 +245,10 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
         const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
         float4 S[V], Q[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
+        for (int k = 0; k < V; ++k) {   // (the squares are recomputed per plane: 8 registers matter more than 4 packed multiplies)
+            Q[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
+            S[k] = a.ms_alias ? Q[k] : r[k];
+        }
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
             const float zz = fmaf(rz[s], dep, tz[s]);
@@ -259,77 +258,37 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
             const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
             const float fx = floorf(ix), fy = floorf(iy);
             const float wx = ix - fx, wy = iy - fy;
-            const float ex = 1.0f - wx, ey = 1.0f - wy;
             // v_cvt_i32_f32 saturates (huge -> INT_MAX/INT_MIN: every tap outside the image; NaN -> 0 with NaN
             // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
             const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
             if (x0 != cx[s] || y0 != cy[s]) {
-                // The sample point moves a fraction of a texel per plane, so nearly every cell change is a step of one
-                // texel along x or y: two of the four cached texels stay in the 2x2 block.  The registers hold the
-                // block in PHYSICAL columns / rows; the parity bits px / py say which physical column / row is the
-                // logical left / top one.  A one-texel step flips the parity and gathers only the two new texels into
-                // the column / row that left the block (no register copies; the weights are swapped instead).
-                const bool same_y = y0 == cy[s], same_x = x0 == cx[s];
-                const bool xp = same_y && (unsigned)x0 == (unsigned)cx[s] + 1u, xm = same_y && (unsigned)x0 + 1u == (unsigned)cx[s];
-                const bool yp = same_x && (unsigned)y0 == (unsigned)cy[s] + 1u, ym = same_x && (unsigned)y0 + 1u == (unsigned)cy[s];
                 cx[s] = x0; cy[s] = y0;
+                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float* __restrict__ fs = a.src[s] + fbase;
-                if (a.shift_cache && (xp || xm)) {
-                    px[s] ^= 1;
-                    const int c = xp ? (px[s] ^ 1) : px[s];           // physical column to refill
-                    const int xt = xp ? x0 + 1 : x0;                   // texel column it now holds
-                    const int ya = y0 + py[s], yb = y0 + (py[s] ^ 1);  // texel rows of physical rows 0 / 1
-                    const bool xin = xt >= 0 && xt < a.W, ina = xin && ya >= 0 && ya < a.H, inb = xin && yb >= 0 && yb < a.H;
-                    const float* __restrict__ fa = fs + ((long)ya * a.W + xt) * C;
-                    const float* __restrict__ fb = fs + ((long)yb * a.W + xt) * C;
-                    if (c == 0) {
 #pragma unroll
-                        for (int k = 0; k < V; ++k) { t00[s][k] = ina ? ld4(fa + ck * k) : z4; t10[s][k] = inb ? ld4(fb + ck * k) : z4; }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < V; ++k) { t01[s][k] = ina ? ld4(fa + ck * k) : z4; t11[s][k] = inb ? ld4(fb + ck * k) : z4; }
-                    }
-                } else if (a.shift_cache && (yp || ym)) {
-                    py[s] ^= 1;
-                    const int r = yp ? (py[s] ^ 1) : py[s];           // physical row to refill
-                    const int yt = yp ? y0 + 1 : y0;
-                    const int xa = x0 + px[s], xb = x0 + (px[s] ^ 1);  // texel columns of physical columns 0 / 1
-                    const bool yin = yt >= 0 && yt < a.H, ina = yin && xa >= 0 && xa < a.W, inb = yin && xb >= 0 && xb < a.W;
-                    const float* __restrict__ fa = fs + ((long)yt * a.W + xa) * C;
-                    const float* __restrict__ fb = fs + ((long)yt * a.W + xb) * C;
-                    if (r == 0) {
-#pragma unroll
-                        for (int k = 0; k < V; ++k) { t00[s][k] = ina ? ld4(fa + ck * k) : z4; t01[s][k] = inb ? ld4(fb + ck * k) : z4; }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < V; ++k) { t10[s][k] = ina ? ld4(fa + ck * k) : z4; t11[s][k] = inb ? ld4(fb + ck * k) : z4; }
-                    }
-                } else {
-                    px[s] = 0; py[s] = 0;
-                    const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
-                    const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
-                    const float* __restrict__ f = fs + ((long)y0 * a.W + x0) * C;
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
-                        t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
-                        t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
-                        t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
-                    }
+                for (int k = 0; k < V; ++k) {
+                    const float4 q00 = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                    const float4 q01 = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                    const float4 q10 = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                    const float4 q11 = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
+                    // the block is cached as the coefficients of  t00 + wx*bx + wy*(by + wx*bxy)  (3 FMAs per sample
+                    // instead of 4 weights x 4 texels; zero padding is already folded into the texels)
+                    t00[s][k] = q00;
+                    t01[s][k] = make_float4(q01.x - q00.x, q01.y - q00.y, q01.z - q00.z, q01.w - q00.w);
+                    t10[s][k] = make_float4(q10.x - q00.x, q10.y - q00.y, q10.z - q00.z, q10.w - q00.w);
+                    t11[s][k] = make_float4((q11.x - q10.x) - t01[s][k].x, (q11.y - q10.y) - t01[s][k].y,
+                                            (q11.z - q10.z) - t01[s][k].z, (q11.w - q10.w) - t01[s][k].w);
                 }
             }
-            // weights of the physical columns / rows
-            const float wc0 = px[s] ? wx : ex, wc1 = px[s] ? ex : wx;
-            const float wr0 = py[s] ? wy : ey, wr1 = py[s] ? ey : wy;
-            const float w00 = wr0 * wc0, w01 = wr0 * wc1, w10 = wr1 * wc0, w11 = wr1 * wc1;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 float4 v;
-                v.x = fmaf(t11[s][k].x, w11, fmaf(t10[s][k].x, w10, fmaf(t01[s][k].x, w01, t00[s][k].x * w00)));
-                v.y = fmaf(t11[s][k].y, w11, fmaf(t10[s][k].y, w10, fmaf(t01[s][k].y, w01, t00[s][k].y * w00)));
-                v.z = fmaf(t11[s][k].z, w11, fmaf(t10[s][k].z, w10, fmaf(t01[s][k].z, w01, t00[s][k].z * w00)));
-                v.w = fmaf(t11[s][k].w, w11, fmaf(t10[s][k].w, w10, fmaf(t01[s][k].w, w01, t00[s][k].w * w00)));
+                v.x = fmaf(wy, fmaf(wx, t11[s][k].x, t10[s][k].x), fmaf(wx, t01[s][k].x, t00[s][k].x));
+                v.y = fmaf(wy, fmaf(wx, t11[s][k].y, t10[s][k].y), fmaf(wx, t01[s][k].y, t00[s][k].y));
+                v.z = fmaf(wy, fmaf(wx, t11[s][k].z, t10[s][k].z), fmaf(wx, t01[s][k].z, t00[s][k].z));
+                v.w = fmaf(wy, fmaf(wx, t11[s][k].w, t10[s][k].w), fmaf(wx, t01[s][k].w, t00[s][k].w));
                 S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
                 Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
                 Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
@@ -772,21 +731,19 @@ static int sweep_fwd_variant() {
     return g_sweep_fwd_variant;
 }
 static int g_sweep_nt = 0;
-static int g_sweep_shift = 1;   // tuning knob "hshift": shift the cached 2x2 block on one-texel steps
 static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
 extern int g_conv_split;
 extern int g_conv_c8;
 extern int g_conv_xcd;
 extern "C" int mvs_set_tuning(const char* key, int value) {
-    if (key && key[0] == 'h') { g_sweep_shift = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
     if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value; return MVS_OK; }
     if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 5 ? 5 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
 }
@@ -798,7 +755,6 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
     a.nt_store = g_sweep_nt;
-    a.shift_cache = g_sweep_shift;
     if (g_sweep_dslab > 0) a.dslab = g_sweep_dslab;
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6) && !(variant == 4 && a.NS > 2)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
@@ -824,6 +780,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
+        else if (c8 && variant == 5) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, 3>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;

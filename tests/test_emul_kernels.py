@@ -220,11 +220,9 @@ def test_plane_sweep_bwd_segmented_windows(emul_lib):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 13])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
-    """All forward variants (taps through L1, LDS windows, register-cached 4/8/16 channels per thread; 13 = variant 3
-    re-gathering the whole 2x2 block on every cell change instead of shifting it)."""
-    shift, variant = (0, 3) if variant == 13 else (1, variant)
+    """All forward variants (taps through L1, LDS windows, register-cached 4/8/16 channels per thread)."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(17)
     b, c, d, h, w, ns = 1, 32, 20, 16, 24, 2
@@ -234,12 +232,10 @@ def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
     srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
     depth = (430 + 25.0 * torch.arange(d)).unsqueeze(0)
     emul_lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-    emul_lib.call("mvs_set_tuning", b"hshift", shift)
     try:
         var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
     finally:
         emul_lib.call("mvs_set_tuning", b"sweep_fwd", 3)
-        emul_lib.call("mvs_set_tuning", b"hshift", 1)
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((var - exp).abs().max()) < 2e-4
 

@@ -18,6 +18,8 @@ if [ "$what" = "kb" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
   timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json | cut -c1-300; grep "ms/step" gpurun_out/bench.err | head -14
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_clean.json 2> gpurun_out/bench_clean.err
+  echo "clean bench exit $?"; cut -c1-220 gpurun_out/bench_clean.json
 fi
 if [ "$what" = "pmc" ] || [ "$what" = "final" ]; then
   # HBM traffic of the roofline kernels: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
