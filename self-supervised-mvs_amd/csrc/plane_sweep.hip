@@ -197,9 +197,8 @@ template <int C, int CPT> struct TileC {
     static constexpr int LPP = C / CPT, PPB = 256 / LPP, TW = PPB >= 128 ? 16 : 8, TH = PPB / TW;
 };
 
-template <int C, int NS_T, int CPT, int OCC = (CPT <= 8 ? 4 : 2)>
-__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(OCC)
-void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
+template <int C, int NS_T, int CPT>
+__global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     constexpr int V = CPT / 4;                     // float4s per tap per thread
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
     const int TW = a.tile_w, TH = PPB / TW;
@@ -213,22 +212,27 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     const int d1 = min(a.D, d0 + a.dslab);
     const float xf = (float)x, yf = (float)y;
     // channel of float4 k of lane q: 4q + 4*LPP*k, so that ONE store instruction writes whole 64-byte segments
-    // (with CPT*q + 4k every store instruction wrote 16 of each 32 bytes: 5 % slower, profiles/r01_run20_kernels.log)
+    // (with CPT*q + 4k every store instruction wrote 16 of each 32 bytes: 5 % slower, profiles/r01_run19_kernels.log)
     const int cq = 4 * q;
     constexpr int ck = 4 * LPP;
     const size_t fbase = (size_t)b * HW * C + cq;
-    float4 r[V];
+    float4 r[V], r2[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
+    for (int k = 0; k < V; ++k) {
+        r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
+        r2[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
+    }
     const float inv_n = 1.0f / (float)(NS_T + 1);
     const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
     const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
-    // (a branch-free re-gather -- clamped addresses, zero padding folded into the weights -- measured 5 % slower:
-    //  profiles/r01_run10_kernels.log vs r01_run7_kernels.log; the kernel waits on the re-gather, not on issue slots)
+    // Measured and rejected (profiles/README.md): a branch-free re-gather (clamped addresses, padding folded into the
+    // weights) 5 % slower; keeping the two texels that stay in the block on a one-texel step (parity bits, half the
+    // gathers) no faster; caching the block as bilinear coefficients (3 FMAs per sample instead of 4) 10 % slower --
+    // hipcc then packs the arithmetic into v_pk_fma_f32, which issues at 4.6 cycles against 2 x 2.8.
     // per view: homography rows applied to (x,y,1) once, cached base texel and its 2x2 block
     float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
     int cx[NS_T], cy[NS_T];
-    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];   // t00, bx, by, bxy of the cached 2x2 block
+    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
         const float* R = rotb + s * 9;
@@ -245,10 +249,7 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
         const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
         float4 S[V], Q[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {   // (the squares are recomputed per plane: 8 registers matter more than 4 packed multiplies)
-            Q[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
-            S[k] = a.ms_alias ? Q[k] : r[k];
-        }
+        for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
             const float zz = fmaf(rz[s], dep, tz[s]);
@@ -258,6 +259,7 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
             const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
             const float fx = floorf(ix), fy = floorf(iy);
             const float wx = ix - fx, wy = iy - fy;
+            const float ex = 1.0f - wx, ey = 1.0f - wy;
             // v_cvt_i32_f32 saturates (huge -> INT_MAX/INT_MIN: every tap outside the image; NaN -> 0 with NaN
             // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
             const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
@@ -269,26 +271,20 @@ void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const float4 q00 = (xin0 && yin0) ? ld4(f + ck * k) : z4;
-                    const float4 q01 = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
-                    const float4 q10 = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
-                    const float4 q11 = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
-                    // the block is cached as the coefficients of  t00 + wx*bx + wy*(by + wx*bxy)  (3 FMAs per sample
-                    // instead of 4 weights x 4 texels; zero padding is already folded into the texels)
-                    t00[s][k] = q00;
-                    t01[s][k] = make_float4(q01.x - q00.x, q01.y - q00.y, q01.z - q00.z, q01.w - q00.w);
-                    t10[s][k] = make_float4(q10.x - q00.x, q10.y - q00.y, q10.z - q00.z, q10.w - q00.w);
-                    t11[s][k] = make_float4((q11.x - q10.x) - t01[s][k].x, (q11.y - q10.y) - t01[s][k].y,
-                                            (q11.z - q10.z) - t01[s][k].z, (q11.w - q10.w) - t01[s][k].w);
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
                 }
             }
+            const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 float4 v;
-                v.x = fmaf(wy, fmaf(wx, t11[s][k].x, t10[s][k].x), fmaf(wx, t01[s][k].x, t00[s][k].x));
-                v.y = fmaf(wy, fmaf(wx, t11[s][k].y, t10[s][k].y), fmaf(wx, t01[s][k].y, t00[s][k].y));
-                v.z = fmaf(wy, fmaf(wx, t11[s][k].z, t10[s][k].z), fmaf(wx, t01[s][k].z, t00[s][k].z));
-                v.w = fmaf(wy, fmaf(wx, t11[s][k].w, t10[s][k].w), fmaf(wx, t01[s][k].w, t00[s][k].w));
+                v.x = fmaf(t11[s][k].x, w11, fmaf(t10[s][k].x, w10, fmaf(t01[s][k].x, w01, t00[s][k].x * w00)));
+                v.y = fmaf(t11[s][k].y, w11, fmaf(t10[s][k].y, w10, fmaf(t01[s][k].y, w01, t00[s][k].y * w00)));
+                v.z = fmaf(t11[s][k].z, w11, fmaf(t10[s][k].z, w10, fmaf(t01[s][k].z, w01, t00[s][k].z * w00)));
+                v.w = fmaf(t11[s][k].w, w11, fmaf(t10[s][k].w, w10, fmaf(t01[s][k].w, w01, t00[s][k].w * w00)));
                 S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
                 Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
                 Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
@@ -743,7 +739,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value; return MVS_OK; }
     if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 5 ? 5 : value); return MVS_OK; }
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
 }
@@ -780,7 +776,6 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
-        else if (c8 && variant == 5) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, 3>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;
