@@ -106,7 +106,8 @@ def main():
     mdist.broadcast_parameters(net)
     # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
     bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
-    opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True)
+    # capturable: the step counter lives on the GPU, so a captured optimizer step stays correct when replayed
+    opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
 
     imgs, proj, dv = synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=1 + rank)
     imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)

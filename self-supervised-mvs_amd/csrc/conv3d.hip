@@ -679,6 +679,88 @@ __global__ __launch_bounds__(256) void conv_wgrad_cg1_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CG == 1, CX == 8 (the `prob` layer, mvsnet.py:63 / network.py:65) on the 16-block 4x4x1 MFMA:
+//   dW[tap][cx] = sum_q X[q][cx] * g[q - (tap - 1)]      (q over the X positions, g zero outside its volume)
+// is one MFMA per position q: block (tg, cg) accumulates the outer product of 4 taps (A: the Toeplitz gather
+// g[q - tap + 1] from a 6x6x18 g halo tile in LDS) and 4 channels (B: X[q][4cg + j]); 8 tap groups x 2 channel
+// groups = 16 blocks, 27 of 32 taps used.  X is read exactly once and needs no halo; the VALU form above did two
+// LDS reads per FMA and ran 6x over its HBM floor (profiles/r01_run17_bench_kernel_table.txt: 0.24 ms).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_wgrad_cg1_mfma_kernel(WgradArgs a) {
+    constexpr int TQD = 4, TQH = 4, TQW = 16, NPOS = TQD * TQH * TQW;
+    constexpr int GD = TQD + 2, GH = TQH + 2, GW = TQW + 2, NG = GD * GH * GW;   // 648
+    __shared__ __attribute__((aligned(16))) float xt[NPOS * 8];
+    __shared__ float gt[NG + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    // A-operand lane (block b = lane>>2, row i = lane&3): tap 4*(b>>1) + i; B-operand lane (b, j): channel 4*(b&1) + j
+    const int tapA = 4 * (lane >> 3) + (lane & 3);
+    const int tA = tapA < 27 ? tapA : 13;                  // rows 27..31 accumulate the centre tap again; never written
+    const int goffA = -((((tA / 9) - 1) * GH + ((tA / 3) % 3 - 1)) * GW + (tA % 3 - 1));
+    const int cxB = 4 * ((lane >> 2) & 1) + (lane & 3);
+
+    constexpr int GIT = (NG + 255) / 256;
+    float4 xv[2];
+    float gv[GIT];
+    auto load_tile = [&](int tile) {
+        int b, td, th, tw;
+        linear_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        const int qd0 = td * TQD, qh0 = th * TQH, qw0 = tw * TQW;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k, q = i >> 1, hq = i & 1;
+            const int qw = qw0 + q % TQW, qh = qh0 + (q / TQW) % TQH, qd = qd0 + q / (TQW * TQH);
+            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qd < a.Di && qh < a.Hi && qw < a.Wi)
+                xv[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + qd) * a.Hi + qh) * a.Wi + qw) * 8 + 4 * hq);
+        }
+#pragma unroll
+        for (int k = 0; k < GIT; ++k) {
+            const int i = tid + 256 * k;
+            const int rw = i % GW, rh = (i / GW) % GH, rd = i / (GW * GH);
+            const int gd = qd0 + rd - 1, gh = qh0 + rh - 1, gw = qw0 + rw - 1;
+            gv[k] = 0.f;
+            if (i < NG && gd >= 0 && gd < a.QD && gh >= 0 && gh < a.QH && gw >= 0 && gw < a.QW)
+                gv[k] = a.g[(((size_t)b * a.QD + gd) * a.QH + gh) * a.QW + gw];
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // previous tile's MFMAs have read the LDS images
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(&xt[(tid + 256 * k) * 4]) = xv[k];
+#pragma unroll
+        for (int k = 0; k < GIT; ++k)
+            if (tid + 256 * k < NG) gt[tid + 256 * k] = gv[k];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);   // in flight during this tile's MFMAs
+        // wave = plane of the tile; 4 rows x 16 positions
+#pragma unroll
+        for (int ph = 0; ph < TQH; ++ph) {
+            const int grow = ((wave + 1) * GH + ph + 1) * GW + 1 + goffA;
+            const int xrow = ((wave * TQH + ph) * TQW) * 8 + cxB;
+#pragma unroll
+            for (int pw = 0; pw < TQW; ++pw)
+                acc[pw & 3] = MVS_MFMA_4x4x1(gt[grow + pw], xt[xrow + pw * 8], acc[pw & 3]);
+        }
+    }
+    // D: lane (b, j) register r = dW[tap 4*(b>>1) + r][cx 4*(b&1) + j]; sum the 4 accumulators, then the 4 waves
+    __syncthreads();
+    float* red = xt;                                        // [wave][32 taps][8]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tap = 4 * (lane >> 3) + r;
+        red[(wave * 32 + tap) * 8 + cxB] = acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r];
+    }
+    __syncthreads();
+    if (tid < 27 * 8)
+        a.part[(size_t)blockIdx.x * (27 * 8) + tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Cout == 8 (conv0 32->8: 68 % of the regulariser's FLOPs; mvsnet.py:40): a 16-wide MFMA N tile is half
@@ -1392,7 +1474,8 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
         return wgrad_finish(ws, g8, CX, CG, gw, st);
     }
     if (geom == GEOM_S1 && CG == 1 && (CX == 8 || CX == 16)) {
-        if (CX == 8) MVS_LAUNCH((conv_wgrad_cg1_kernel<8>), dim3(groups), dim3(256), 0, st, a);
+        if (CX == 8 && g_conv_c8) MVS_LAUNCH(conv_wgrad_cg1_mfma_kernel, dim3(groups), dim3(256), 0, st, a);
+        else if (CX == 8) MVS_LAUNCH((conv_wgrad_cg1_kernel<8>), dim3(groups), dim3(256), 0, st, a);
         else MVS_LAUNCH((conv_wgrad_cg1_kernel<16>), dim3(groups), dim3(256), 0, st, a);
         int rc1 = mvs_check_launch("conv_wgrad_cg1");
         if (rc1) return rc1;

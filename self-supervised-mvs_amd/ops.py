@@ -60,9 +60,11 @@ def empty_cl3(b, c, d, h, w, like: torch.Tensor) -> torch.Tensor:
 # plane sweep (K1/K2)
 # ------------------------------------------------------------------------------------------------
 def relative_projection(src_proj: torch.Tensor, ref_proj: torch.Tensor):
-    """rot [B,3,3] / trans [B,3] of src_proj @ inverse(ref_proj) -- host torch code, exactly the
-    reference's lines (jdacs/models/module.py:116-118)."""
-    proj = torch.matmul(src_proj, torch.inverse(ref_proj))
+    """rot [B,3,3] / trans [B,3] of src_proj @ inverse(ref_proj) -- host torch code, the reference's lines
+    (jdacs/models/module.py:116-118).  ``linalg.inv_ex`` is the same LU inverse as ``torch.inverse`` without the
+    host-side singularity check, i.e. without a device synchronisation (and therefore capturable in a hipGraph);
+    a singular matrix yields inf/nan instead of an exception."""
+    proj = torch.matmul(src_proj, torch.linalg.inv_ex(ref_proj).inverse)
     return proj[:, :3, :3], proj[:, :3, 3]
 
 
