@@ -238,42 +238,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 tapbase = 0;
                 kk0 = chunk * KSF;
             }
-            // software pipeline: operands of k-step ks+1 are in flight while the MFMAs of k-step ks issue
-            float4 bf[NB], af[MB];
-            {
-                const int kflat = 4 * g;
-                const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
+            // software pipeline: the weight operands (global memory / L2, ~1 us away) run PD k-steps ahead of the MFMAs
+            // that consume them, the LDS operands one k-step.  A one-wave-per-SIMD launch (the deep U-Net levels: fewer
+            // workgroups than CUs) has nothing else to hide that latency: with PD = 1 those layers spent two thirds of
+            // their time waiting on the next 256-byte weight fragment (profiles/r01_run17_bench_kernel_stats.csv).
+            constexpr int PD = NB == 1 ? 4 : 2;
+            float4 bq[PD][NB], af[MB];
+            auto load_b = [&](int ks, float4 (&dst)[NB]) {
+                const int kc = ks < KS ? ks : KS - 1;   // past the end: re-read the last fragment (harmless)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)kk0 * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+                    dst[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + kc) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+            };
+            auto load_a = [&](int ks, float4 (&dst)[MB]) {
+                const int kc = ks < KS ? ks : KS - 1;
+                const int kflat = 16 * kc + 4 * g;
+                const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
-            }
-            for (int ks = 0; ks < KS; ++ks) {
-                float4 bn[NB], an[MB];
-                const int ksn = ks + 1 < KS ? ks + 1 : ks;   // last iteration re-reads its own operands (harmless)
-                {
-                    const int kflat = 16 * ksn + 4 * g;
-                    const int aoff = tapoff[tapbase + kflat / CC] + kflat % CC;
+                for (int mb = 0; mb < MB; ++mb) dst[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+            };
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        bn[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + ksn) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+            for (int u = 0; u < PD; ++u) load_b(u, bq[u]);
+            load_a(0, af);
+            for (int ks0 = 0; ks0 < KS; ks0 += PD) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) an[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
-                }
+                for (int u = 0; u < PD; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < KS) {
+                        float4 an[MB];
+                        load_a(ks + 1, an);
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+                        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bf[nb].x, acc[mb][nb]);
-                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bf[nb].y, acc[mb][nb]);
-                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bf[nb].z, acc[mb][nb]);
-                        acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bf[nb].w, acc[mb][nb]);
+                            for (int nb = 0; nb < NB; ++nb) {
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bq[u][nb].y, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bq[u][nb].z, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bq[u][nb].w, acc[mb][nb]);
+                            }
+                        load_b(ks + PD, bq[u]);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) af[mb] = an[mb];
                     }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bf[nb] = bn[nb];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) af[mb] = an[mb];
+                }
             }
         }
 
