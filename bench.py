@@ -43,6 +43,47 @@ def algorithmic_work():
     }
 
 
+HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
+    "sweep_fwd": "plane_sweep_variance_fwd_cached_kernel", "sweep_bwd": "plane_sweep_variance_bwd_kernel",
+    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2>",
+}
+
+
+def pmc_traffic():
+    """HBM traffic per launch of the roofline kernels: rocprofv3 PMC counters of tools/pmc_driver.py (the same kernels at
+    the same config-2 shapes), FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes.  On gfx950
+    FETCH_SIZE tallies every 128-byte line at 64 bytes (calibrated: tools/fetch_calib.hip, profiles/r01_run20_fetch_calib.log)
+    -> doubled; WRITE_SIZE matched known byte counts as reported.  Both are in KiB."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    root = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from pmc_summary import summarise
+    tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    dirs = []
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, counter)
+        r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                            sys.executable, os.path.join(root, "tools", "pmc_driver.py")],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+        dirs.append(d)
+    summ = summarise(dirs)
+    shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for tag, sub in HIP_KERNEL_OF.items():
+        for name, c in summ.items():
+            if sub in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out[tag] = {"fetch_bytes": 2.0 * 1024.0 * c["FETCH_SIZE"]["mean"], "write_bytes": 1024.0 * c["WRITE_SIZE"]["mean"]}
+    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py; FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)"
+
+
 def cpu_baseline(net_state, seed):
     """The oracle (a torch-ops port of the reference path) timed on this box's host cores on a bounded
     sample of the same workload: ONE config-2 training sample (forward + loss + backward)."""
@@ -80,6 +121,9 @@ def main():
                          "-1: try the graph, fall back to eager.  Default 0: the step is GPU-bound (profiles/), a replay buys nothing")
     ap.add_argument("--torch-profile", type=str, default="",
                     help="write a torch.profiler table (CPU + GPU, 5 steady-state steps) to this file (diagnostics)")
+    ap.add_argument("--pmc", type=int, default=1,
+                    help="1 (default, N=1 only): after the timed region run tools/pmc_driver.py under `rocprofv3 --pmc` (separate "
+                         "FETCH_SIZE and WRITE_SIZE passes) to fill roofline.traffic; 0 or no rocprofv3 on PATH: traffic = null")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="extra untimed pass bracketing EVERY C-ABI call with HIP events (diagnostics to stderr)")
     args = ap.parse_args()
@@ -230,12 +274,26 @@ def main():
                     ach, peak, unit = amount / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
                 kernels[key] = {"bound": bound, "ms": ms, "achieved": ach, "peak": peak, "unit": unit,
                                 "frac": ach / peak, "calls": calls}
-        dom = max((k for k in kernels if kernels[k]["bound"] == "mfma"), key=lambda k: kernels[k]["ms"], default=None)
+        traffic, traffic_note = None, "not collected"
+        if args.pmc and world == 1:
+            try:
+                traffic, traffic_note = pmc_traffic()
+            except Exception as e:  # the bench line must still come out
+                traffic, traffic_note = None, "PMC pass failed: %r" % (e,)
+        for k, t in (traffic or {}).items():
+            if k in kernels:
+                kernels[k]["traffic"] = t["fetch_bytes"] + t["write_bytes"]
+                hf, wf = IMG_H // 4, IMG_W // 4
+                # bytes each launch has to move at least once (conv0: the 32-channel volume + the 8-channel one)
+                kernels[k]["algorithmic_bytes"] = work[k][1] if work[k][0] == "hbm" else (FEAT_C + 8) * NDEPTH * hf * wf * 4
+        # the roofline object describes the dominant (longest-running) kernel of the step; the other tagged kernels are in "kernels"
+        dom = max(kernels, key=lambda k: kernels[k]["ms"], default=None)
         roof = None
         if dom is not None:
-            roof = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
+            roof = {"kernel": dom, "hip_kernel": HIP_KERNEL_OF[dom], "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                     "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
-                    "traffic": None, "ms": kernels[dom]["ms"]}
+                    "traffic": kernels[dom].get("traffic"), "traffic_unit": "bytes of HBM traffic per launch", "traffic_source": traffic_note,
+                    "ms": kernels[dom]["ms"]}
         res = {
             "metric": "depth-samples/sec (N=3, 640x512, D=192)", "value": world * args.steps / dt,
             "unit": "depth-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

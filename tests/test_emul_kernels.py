@@ -2,6 +2,8 @@
 (tests/cpu_emul) and driven through the product's Python wrappers, compared with the oracle.
 (The real parity tests are the -m gpu ones; these catch index-map / fragment-layout / reduction
 bugs in the build container.)"""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -315,6 +317,7 @@ def test_bn_relu_2d_grouped_equals_successive_calls(emul_lib):
     assert torch.allclose(bn.running_var, bn_r.running_var, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="4 minutes of emulation; set MVS_EMUL_FULL=1 (the same golden runs on the GPU in test_gpu_parity.py::test_golden_costregnet_cvp)")
 def test_costregnet_cvp_golden(emul_lib):
     """jdacs-ms regulariser (stride-1 transposed conv, 16->1 prob layer) vs the fixture from the imported reference."""
     from mvs_amd.jdacs_ms.models.network import CostRegNet
@@ -331,13 +334,13 @@ def test_costregnet_cvp_golden(emul_lib):
         assert rel_l1(p.grad, g["grad." + k]) < 5e-3, k
 
 
-@pytest.mark.parametrize("cin,dims,xcd", [(32, (5, 9, 18), 1), (16, (4, 22, 16), 1), (8, (3, 4, 33), 0), (32, (4, 4, 16), 0)])
+@pytest.mark.parametrize("cin,dims,xcd", [(32, (4, 4, 18), 1), (16, (5, 6, 16), 1), (8, (3, 4, 33), 0), (8, (2, 18, 16), 1)])
 def test_conv_c8_broadcast_operand_forward(emul_lib, cin, dims, xcd):
     """Cout == 8 stride-1 forward with the weights as the MFMA broadcast operand (tuning k8 = 7): conv, epilogue
     (scale/shift/relu/skip), BN stat partials and both tile orders vs F.conv3d (mvsnet.py:40 conv0, network.py:47)."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin + dims[1])
-    x = torch.randn(2, cin, *dims, generator=g)
+    x = torch.randn(2 if cin == 8 else 1, cin, *dims, generator=g)   # (the emulated MFMA is a 64-thread barrier: keep the tile count small)
     w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
     yr = F.conv3d(x, w, padding=1)
     emul_lib.call("mvs_set_tuning", b"k8", 7)

@@ -32,11 +32,16 @@ for _ in range(3):
     with torch.no_grad():
         v = var.detach()
         lib = ops._lib_for(v)
-        for k8, xcd in ((1, 0), (1, 1), (7, 0), (7, 1)):   # per-dispatch order in the summary
-            lib.call("mvs_set_tuning", b"k8", k8)
-            lib.call("mvs_set_tuning", b"xcd", xcd)
-            y0, _ = ops.conv3d_forward(v, w0, 1, False, want_stats=True)
-            ops.conv3d_wgrad(v, y0, tuple(w0.shape), 1, False)
+        if os.environ.get("MVS_PMC_VARIANTS"):   # A/B of the Cout==8 kernel forms / tile orders (per-dispatch order in the summary)
+            for k8, xcd in ((1, 0), (1, 1), (7, 0), (7, 1)):
+                lib.call("mvs_set_tuning", b"k8", k8)
+                lib.call("mvs_set_tuning", b"xcd", xcd)
+                y0, _ = ops.conv3d_forward(v, w0, 1, False, want_stats=True)
+                ops.conv3d_wgrad(v, y0, tuple(w0.shape), 1, False)
+            lib.call("mvs_set_tuning", b"k8", 7)
+            lib.call("mvs_set_tuning", b"xcd", 1)
+        y0, _ = ops.conv3d_forward(v, w0, 1, False, want_stats=True)
+        ops.conv3d_wgrad(v, y0, tuple(w0.shape), 1, False)
         ops.conv3d_dgrad(y0, w0, tuple(v.shape), 1, False)
 torch.cuda.synchronize()
 print("pmc driver done")
