@@ -21,7 +21,7 @@ if [ "$what" = "kb" ]; then
   timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_clean.json 2> gpurun_out/bench_clean.err
   echo "clean bench exit $?"; cut -c1-220 gpurun_out/bench_clean.json
 fi
-if [ "$what" = "pmc" ] || [ "$what" = "final" ]; then
+if [ "$what" = "pmc" ]; then
   # HBM traffic of the roofline kernels: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_$c
@@ -92,7 +92,7 @@ if [ "$what" = "final" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
-      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
   echo "prof exit $?"
   mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
   rm -rf gpurun_out/prof
