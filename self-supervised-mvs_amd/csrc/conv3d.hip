@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             // that consume them, the LDS operands one k-step.  A one-wave-per-SIMD launch (the deep U-Net levels: fewer
             // workgroups than CUs) has nothing else to hide that latency: with PD = 1 those layers spent two thirds of
             // their time waiting on the next 256-byte weight fragment (profiles/r01_run17_bench_kernel_stats.csv).
-            // (measured: 64>64 at 24x16x20 0.073 -> 0.061 ms; the transposed geometry got slower with PD > 1 and keeps 1)
-            constexpr int PD = (NB == 1 && GEOM != GEOM_TR2) ? 4 : 1;
+            // (measured: 64>64 at 24x16x20 0.073 -> 0.061 ms with PD = 4; conv0's dgrad, NB = 2: 0.556 ms with PD = 2 against 0.60
+            //  with 1; the transposed geometry got slower with PD > 1 and keeps 1)
+            constexpr int PD = GEOM == GEOM_TR2 ? 1 : (NB == 1 ? 4 : 2);
             float4 bq[PD][NB], af[MB];
             auto load_b = [&](int ks, float4 (&dst)[NB]) {
                 const int kc = ks < KS ? ks : KS - 1;   // past the end: re-read the last fragment (harmless)
