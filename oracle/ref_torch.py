@@ -511,3 +511,106 @@ def synthetic_mvsnet_inputs(batch, nviews, img_h, img_w, ndepth, seed=1, depth_m
     proj = proj.unsqueeze(0).repeat(batch, 1, 1, 1)
     depth_values = (depth_min + interval * torch.arange(ndepth, dtype=torch.float32)).unsqueeze(0).repeat(batch, 1)
     return imgs, proj, depth_values
+
+
+# =============================================================================================
+# SURVEY 8(f)-1: the self-supervised loss on the path's output (jdacs/losses/unsup_loss.py:19-83).
+# TEST INFRASTRUCTURE like everything in this file; pinned by tests/golden/g8_unsup_loss*.npz.
+# =============================================================================================
+def quarter_image(img):
+    """[B,3,H,W] -> [B,H/4,W/4,3]: F.interpolate(scale_factor=0.25, bilinear) + permute (unsup_loss.py:36-37,53-54)."""
+    return F.interpolate(img, scale_factor=0.25, mode="bilinear").permute(0, 2, 3, 1)
+
+
+def unsup_view_transform(ref_cam, view_cam):
+    """Per view: K_ref^-1 and the 3x4 matrix K_ref . [R_rel | t_rel] (homography.py:186-236).  The reference projects
+    with the REFERENCE intrinsics (`intrinsic_mat_hom` is built from K_left, homography.py:231), kept as is."""
+    R_l, t_l = ref_cam[:, 0, :3, :3], ref_cam[:, 0, :3, 3:4]
+    R_r, t_r = view_cam[:, 0, :3, :3], view_cam[:, 0, :3, 3:4]
+    K_l = ref_cam[:, 1, :3, :3]
+    R_rel = R_r @ R_l.transpose(1, 2)
+    t_rel = t_r - R_rel @ t_l
+    return torch.inverse(K_l), K_l @ torch.cat([R_rel, t_rel], 2)        # [B,3,3], [B,3,4]
+
+
+def unsup_inverse_warp(view_q, kinv, proj, depth):
+    """view_q [B,h,w,3], depth [B,h,w] -> warped [B,h,w,3], mask [B,h,w,1] (homography.py:186-351).
+    Quirks kept: z + 1e-10; the validity mask tests x0>=0, x1<=w-1, y0>=0, y0<=h-1 (not y1); the bilinear weights are
+    formed with the CLAMPED x1 / y1 (homography.py:294-334)."""
+    b, h, w, _ = view_q.shape
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=depth.device),
+                            torch.arange(w, dtype=torch.float32, device=depth.device), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, device=depth.device)], 0)      # [3,hw]
+    cam = (kinv @ pix.unsqueeze(0)) * depth.reshape(b, 1, h * w)                                         # [B,3,hw]
+    pc = proj[:, :, :3] @ cam + proj[:, :, 3:4]
+    x = pc[:, 0] / (pc[:, 2] + 1e-10)
+    y = pc[:, 1] / (pc[:, 2] + 1e-10)
+    # (the reference normalises to [-1,1] and back, homography.py:270-272,292-293: identity up to rounding)
+    x = ((x / (w - 1) * 2.0 - 1.0) + 1.0) * (w - 1.0) / 2.0
+    y = ((y / (h - 1) * 2.0 - 1.0) + 1.0) * (h - 1.0) / 2.0
+    x0 = torch.floor(x).int()
+    y0 = torch.floor(y).int()
+    x1, y1 = x0 + 1, y0 + 1
+    mask = ((x0 >= 0) & (x1 <= w - 1) & (y0 >= 0) & (y0 <= h - 1)).float()
+    x0c, x1c = x0.clamp(0, w - 1), x1.clamp(0, w - 1)
+    y0c, y1c = y0.clamp(0, h - 1), y1.clamp(0, h - 1)
+    flat = view_q.reshape(b, h * w, 3)
+
+    def take(yy, xx):
+        idx = (yy.long() * w + xx.long()).unsqueeze(-1).expand(-1, -1, 3)
+        return torch.gather(flat, 1, idx)
+    fx, fy = x1c.float() - x, y1c.float() - y
+    out = ((fx * fy).unsqueeze(-1) * take(y0c, x0c) + (fx * (1.0 - fy)).unsqueeze(-1) * take(y1c, x0c)
+           + ((1.0 - fx) * fy).unsqueeze(-1) * take(y0c, x1c) + ((1.0 - fx) * (1.0 - fy)).unsqueeze(-1) * take(y1c, x1c))
+    return out.reshape(b, h, w, 3), mask.reshape(b, h, w, 1)
+
+
+def unsup_reconstr_term(warped, ref, mask):
+    """0.5 smooth-L1 of the masked images + 0.5 smooth-L1 of their forward differences (modules.py:80-90)."""
+    wm, rm = warped * mask, ref * mask
+    photo = F.smooth_l1_loss(wm, rm)
+    gx = F.smooth_l1_loss(wm[:, :, 1:] - wm[:, :, :-1], rm[:, :, 1:] - rm[:, :, :-1])
+    gy = F.smooth_l1_loss(wm[:, 1:] - wm[:, :-1], rm[:, 1:] - rm[:, :-1])
+    return 0.5 * photo + 0.5 * (gx + gy)
+
+
+def unsup_ssim_map(x, y, mask):
+    """3x3 average-pool SSIM dissimilarity, mask pooled likewise (modules.py:17-52); NHWC in, NHWC out."""
+    x, y, mask = x.permute(0, 3, 1, 2), y.permute(0, 3, 1, 2), mask.permute(0, 3, 1, 2)
+    mu_x, mu_y = F.avg_pool2d(x, 3, 1), F.avg_pool2d(y, 3, 1)
+    sx = F.avg_pool2d(x * x, 3, 1) - mu_x ** 2
+    sy = F.avg_pool2d(y * y, 3, 1) - mu_y ** 2
+    sxy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + 0.01 ** 2) * (2 * sxy + 0.03 ** 2)
+    d = (mu_x ** 2 + mu_y ** 2 + 0.01 ** 2) * (sx + sy + 0.03 ** 2)
+    return (F.avg_pool2d(mask, 3, 1) * torch.clamp((1 - n / d) / 2, 0, 1)).permute(0, 2, 3, 1)
+
+
+def unsup_smoothness(depth, ref, lam):
+    """image-aware first-order smoothness (modules.py:55-77): |d(p)-d(p+1)| * exp(-lam * mean_c |I(p)-I(p+1)|)."""
+    d = depth.unsqueeze(-1)
+    wx = torch.exp(-lam * (ref[:, :, :-1] - ref[:, :, 1:]).abs().mean(3, keepdim=True))
+    wy = torch.exp(-lam * (ref[:, :-1] - ref[:, 1:]).abs().mean(3, keepdim=True))
+    return ((d[:, :, :-1] - d[:, :, 1:]) * wx).abs().mean() + ((d[:, :-1] - d[:, 1:]) * wy).abs().mean()
+
+
+def unsup_loss(imgs, cams, depth, smooth_lambda=1.0, return_terms=False):
+    """UnSupLoss.forward (unsup_loss.py:24-83): 12 * mean(sum of the 3 smallest valid per-view reconstruction terms)
+    + 6 * (SSIM of views 1, 2) + 0.18 * smoothness.  Note the per-view reconstruction term is a SCALAR broadcast
+    over the pixels (+1e4 where the view is invalid) before the top-3 selection (unsup_loss.py:61-63,74-81)."""
+    n = imgs.shape[1]
+    ref = quarter_image(imgs[:, 0])
+    vols, ssim = [], 0.0
+    for v in range(1, n):
+        kinv, proj = unsup_view_transform(cams[:, 0], cams[:, v])
+        warped, mask = unsup_inverse_warp(quarter_image(imgs[:, v]), kinv, proj, depth)
+        vols.append(unsup_reconstr_term(warped, ref, mask) + 1e4 * (1 - mask))
+        if v < 3:
+            ssim = ssim + unsup_ssim_map(ref, warped, mask).mean()
+    smooth = unsup_smoothness(depth, ref, smooth_lambda)
+    vol = torch.stack(vols).permute(1, 2, 3, 4, 0)
+    top = -torch.topk(-vol, k=3, sorted=False)[0]
+    top = top * (top < 1e4).float()
+    reconstr = top.sum(-1).mean()
+    total = 12 * reconstr + 6 * ssim + 0.18 * smooth
+    return (total, reconstr, ssim, smooth) if return_terms else total

@@ -1,4 +1,5 @@
 """Oracle (oracle/ref_torch.py) vs fixtures generated from the imported reference.  CPU only."""
+import pytest
 import torch
 
 from conftest import load_golden, rel_l1, state_dict_from
@@ -128,3 +129,23 @@ def test_g7_cvpmvsnet_end_to_end():
     assert rel_l1(out["depth_est_list"][1], g["depth1"]) < 1e-5
     assert rel_l1(out["depth_est_list"][0], g["depth0"]) < 1e-4
     close(out["prob_confidence"], g["conf"], atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["g8_unsup_loss", "g8_unsup_loss_n4"])
+def test_unsup_loss_oracle_vs_golden(name):
+    """the oracle's restatement of UnSupLoss against the fixture generated by the imported reference
+    (tests/golden/make_golden_unsup.py): loss, its three terms, d loss / d depth, and the first view's warp + mask."""
+    g = load_golden(name)
+    imgs, cams = g["imgs"].float(), g["cams"]
+    depth = g["depth"].clone().requires_grad_(True)
+    total, reconstr, ssim, smooth = R.unsup_loss(imgs, cams, depth, return_terms=True)
+    total.backward()
+    assert abs(float(total) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert abs(float(reconstr) - float(g["reconstr_loss"])) < 1e-5
+    assert abs(float(ssim) - float(g["ssim_loss"])) < 1e-5
+    assert abs(float(smooth) - float(g["smooth_loss"])) < 1e-4
+    assert float((depth.grad - g["grad_depth"]).abs().max()) < 2e-6 + 1e-4 * float(g["grad_depth"].abs().max())
+    kinv, proj = R.unsup_view_transform(cams[:, 0], cams[:, 1])
+    warped, mask = R.unsup_inverse_warp(R.quarter_image(imgs[:, 1]), kinv, proj, g["depth"])
+    assert torch.equal(mask, g["mask1"])
+    assert float((warped - g["warped1"]).abs().max()) < 2e-4
