@@ -142,6 +142,24 @@ int mvs_softargmin_conf_bwd(const float* grad_depth, const float* logits, const 
                             const float* out_depth, const float* save_max, const float* save_sum, int B, int D, int H,
                             int W, float* grad_logits, hipStream_t stream);
 
+/* ---- the self-supervised loss on the path's output ------------------------------------------------
+ * Replaces UnSupLoss.forward and its autograd graph (jdacs/losses/unsup_loss.py:24-83; inverse_warping
+ * jdacs/losses/homography.py:186-351; compute_reconstr_loss / SSIM / depth_smoothness jdacs/losses/modules.py:17-90).
+ * ref, views[v]: quarter-resolution NHWC images [B,H,W,3] (the caller does F.interpolate(0.25, bilinear) + permute,
+ * unsup_loss.py:36-37,53-54); kinv [B,9] = K_ref^-1; proj [B,V,12] = K_ref.[R_rel | t_rel] row major
+ * (homography.py:200-236: R_rel = R_v R_ref^T, t_rel = t_v - R_rel t_ref; the REFERENCE intrinsics project, as there);
+ * depth [B,H,W]; V = number of source views, 3 <= V <= 10 (the top-3 selection needs three).
+ * out[4] (device): total = 12 reconstr + 6 ssim + 0.18 smooth, then the three terms.  ws: caller-owned scratch of
+ * mvs_unsup_loss_workspace_floats() floats; the backward reads what the forward left there.  grad_out: device scalar.
+ * Only the depth map receives a gradient. */
+long long mvs_unsup_loss_workspace_floats(int B, int V, int H, int W);
+int mvs_unsup_loss_fwd(const float* ref, const float* const* views, const float* kinv, const float* proj,
+                       const float* depth, int B, int V, int H, int W, float smooth_lambda, float* ws, float* out,
+                       hipStream_t stream);
+int mvs_unsup_loss_bwd(const float* ref, const float* const* views, const float* kinv, const float* proj,
+                       const float* depth, int B, int V, int H, int W, float smooth_lambda, float* ws,
+                       const float* grad_out, float* grad_depth, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

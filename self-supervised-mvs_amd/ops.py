@@ -395,3 +395,67 @@ class SoftArgminConf(torch.autograd.Function):
 
 def softargmin_conf(logits, depth_values):
     return SoftArgminConf.apply(logits, depth_values)
+
+
+# ------------------------------------------------------------------------------------------------
+# self-supervised loss on the path's output
+# ------------------------------------------------------------------------------------------------
+def unsup_view_transforms(cams: torch.Tensor):
+    """cams [B,N,2,4,4] (extrinsic in [:, :, 0], K in [:, :, 1, :3, :3]) -> kinv [B,9], proj [B,N-1,12]: host torch code
+    for the few 3x3 products of jdacs/losses/homography.py:188-236 (K_ref^-1; K_ref.[R_v R_ref^T | t_v - R_rel t_ref])."""
+    R_ref, t_ref = cams[:, 0, 0, :3, :3], cams[:, 0, 0, :3, 3:4]
+    K_ref = cams[:, 0, 1, :3, :3]
+    R_v, t_v = cams[:, 1:, 0, :3, :3], cams[:, 1:, 0, :3, 3:4]
+    R_rel = torch.matmul(R_v, R_ref.transpose(1, 2).unsqueeze(1))
+    t_rel = t_v - torch.matmul(R_rel, t_ref.unsqueeze(1))
+    proj = torch.matmul(K_ref.unsqueeze(1), torch.cat([R_rel, t_rel], 3))
+    kinv = torch.linalg.inv_ex(K_ref).inverse
+    b = cams.shape[0]
+    return kinv.reshape(b, 9).contiguous(), proj.reshape(b, -1, 12).contiguous()
+
+
+class UnsupLossFn(torch.autograd.Function):
+    """depth [B,h,w] -> (total, reconstr, ssim, smooth) scalars; differentiable w.r.t. the depth map only (the images and
+    cameras are inputs of the training step, jdacs/train.py:199-210)."""
+
+    @staticmethod
+    def forward(ctx, depth, ref_q, views_q, kinv, proj, smooth_lambda):
+        lib = _lib_for(depth)
+        depth = depth.contiguous()
+        b, h, w = depth.shape
+        nv = len(views_q)
+        ref_q = ref_q.contiguous()
+        views_q = [v.contiguous() for v in views_q]
+        for t in [ref_q] + views_q:
+            if tuple(t.shape) != (b, h, w, 3):
+                raise ValueError("quarter-resolution images must be [B,h,w,3] = %s, got %s" % ((b, h, w, 3), tuple(t.shape)))
+        if tuple(kinv.shape) != (b, 9) or tuple(proj.shape) != (b, nv, 12):
+            raise ValueError("kinv must be [B,9] and proj [B,V,12], got %s / %s" % (tuple(kinv.shape), tuple(proj.shape)))
+        nws = lib.raw("mvs_unsup_loss_workspace_floats", b, nv, h, w)
+        if nws < 0:
+            raise ValueError("unsup_loss: bad shape B=%d V=%d h=%d w=%d" % (b, nv, h, w))
+        ws = torch.empty(nws, dtype=torch.float32, device=depth.device)
+        out = torch.empty(4, dtype=torch.float32, device=depth.device)
+        lib.call("mvs_unsup_loss_fwd", _p(ref_q), _ptr_array(views_q), _p(kinv), _p(proj), _p(depth), b, nv, h, w,
+                 float(smooth_lambda), _p(ws), _p(out), _stream(depth))
+        ctx.save_for_backward(depth, ref_q, kinv, proj, ws, *views_q)
+        ctx.lam = float(smooth_lambda)
+        total, reconstr, ssim, smooth = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(reconstr, ssim, smooth)   # reported for logging, like the reference's attributes
+        return total, reconstr, ssim, smooth
+
+    @staticmethod
+    def backward(ctx, g_total, g_reconstr, g_ssim, g_smooth):
+        depth, ref_q, kinv, proj, ws, *views_q = ctx.saved_tensors
+        lib = _lib_for(depth)
+        b, h, w = depth.shape
+        # only the total is differentiable here (its three terms are reported for logging, like the reference's attributes)
+        g = g_total.contiguous().reshape(1).to(torch.float32)
+        gd = torch.empty_like(depth)
+        lib.call("mvs_unsup_loss_bwd", _p(ref_q), _ptr_array(views_q), _p(kinv), _p(proj), _p(depth), b, len(views_q), h, w,
+                 ctx.lam, _p(ws), _p(g), _p(gd), _stream(depth))
+        return gd, None, None, None, None, None
+
+
+def unsup_loss(depth, ref_q, views_q, kinv, proj, smooth_lambda=1.0):
+    return UnsupLossFn.apply(depth, ref_q, list(views_q), kinv, proj, smooth_lambda)

@@ -371,3 +371,48 @@ def test_conv_c8_broadcast_operand_forward(emul_lib, cin, dims, xcd):
     finally:
         emul_lib.call("mvs_set_tuning", b"k8", 1)
         emul_lib.call("mvs_set_tuning", b"xcd", 1)
+
+
+@pytest.mark.parametrize("name", ["g8_unsup_loss", "g8_unsup_loss_n4"])
+def test_unsup_loss_golden(emul_lib, name):
+    """UnSupLoss through the kernels (csrc/unsup_loss.hip) vs the fixture from the imported reference:
+    total, the three terms and d total / d depth."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    g = load_golden(name)
+    depth = g["depth"].clone().requires_grad_(True)
+    crit = UnSupLoss()
+    total = crit(g["imgs"].float(), g["cams"], depth)
+    (2.0 * total).backward()
+    assert abs(float(total) - float(g["loss"])) < 3e-5 * abs(float(g["loss"]))
+    assert abs(float(crit.reconstr_loss) - float(g["reconstr_loss"])) < 2e-5
+    assert abs(float(crit.ssim_loss) - float(g["ssim_loss"])) < 2e-5
+    assert abs(float(crit.smooth_loss) - float(g["smooth_loss"])) < 2e-4
+    gd = g["grad_depth"] * 2.0
+    assert float((depth.grad - gd).abs().max()) < 4e-6 + 2e-4 * float(gd.abs().max())
+
+
+def test_unsup_loss_vs_oracle_ragged_and_errors(emul_lib):
+    """odd image sizes, batch 3, N = 7, a different smoothness weight; argument checks."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    gen = torch.Generator().manual_seed(3)
+    b, n, h, w = 3, 7, 52, 76          # quarter resolution 13 x 19
+    imgs = F.avg_pool2d(torch.randn(b * n, 3, h, w, generator=gen), 5, 1, 2).view(b, n, 3, h, w) * 3
+    K, E = R.synthetic_cameras(n, h // 4, w // 4, w)
+    cams = torch.zeros(b, n, 2, 4, 4)
+    cams[:, :, 0] = E
+    cams[:, :, 1, :3, :3] = K
+    depth = (600.0 + 40.0 * torch.rand(b, h // 4, w // 4, generator=gen))
+    da, db = depth.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    crit = UnSupLoss(smooth_lambda=0.5)
+    la = crit(imgs, cams, da)
+    lb = R.unsup_loss(imgs, cams, db, smooth_lambda=0.5)
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 3e-5 * abs(float(lb))
+    assert float((da.grad - db.grad).abs().max()) < 4e-6 + 2e-4 * float(db.grad.abs().max())
+    with pytest.raises(ValueError):
+        crit(imgs[:, :3], cams[:, :3], depth)          # two source views: no top-3
+    with pytest.raises(ValueError):
+        crit(imgs, cams[:, :5], depth)
+    with pytest.raises(ValueError):
+        crit(imgs, cams, depth[:, :-1])

@@ -478,3 +478,43 @@ def test_config5_shape_seven_views_eval(dev):
     assert o["depth"].shape == (1, 152, 200)
     assert rel_l1(o["depth"], r["depth"]) < 1e-3
     assert float((o["photometric_confidence"] - r["photometric_confidence"]).abs().mean()) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["g8_unsup_loss", "g8_unsup_loss_n4"])
+def test_golden_unsup_loss(dev, name):
+    """UnSupLoss through the HIP kernels vs the fixture generated by the imported reference."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    g = load_golden(name)
+    depth = g["depth"].to(dev).requires_grad_(True)
+    crit = UnSupLoss()
+    total = crit(g["imgs"].float().to(dev), g["cams"].to(dev), depth)
+    total.backward()
+    assert abs(float(total) - float(g["loss"])) < 3e-5 * abs(float(g["loss"]))
+    assert abs(float(crit.reconstr_loss) - float(g["reconstr_loss"])) < 2e-5
+    assert abs(float(crit.ssim_loss) - float(g["ssim_loss"])) < 2e-5
+    assert abs(float(crit.smooth_loss) - float(g["smooth_loss"])) < 2e-4
+    gd = g["grad_depth"]
+    assert float((depth.grad.cpu() - gd).abs().max()) < 4e-6 + 2e-4 * float(gd.abs().max())
+
+
+def test_unsup_loss_config3_shape_vs_gpu_oracle(dev):
+    """BASELINE config 3 per-GPU shape (N = 5, 640x512 images -> 160x128 loss resolution), batch 2, vs the oracle's
+    torch ops on the same GPU; also as the loss of an MVSNet training step (gradient reaches the network)."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    gen = torch.Generator().manual_seed(8)
+    b, n, h, w = 2, 5, 512, 640
+    imgs = F.avg_pool2d(torch.randn(b * n, 3, h, w, generator=gen), 9, 1, 4).view(b, n, 3, h, w) * 4
+    K, E = R.synthetic_cameras(n, h // 4, w // 4, w)
+    cams = torch.zeros(b, n, 2, 4, 4)
+    cams[:, :, 0] = E
+    cams[:, :, 1, :3, :3] = K
+    depth = 600.0 + 60.0 * torch.rand(b, h // 4, w // 4, generator=gen)
+    imgs, cams = imgs.to(dev), cams.to(dev)
+    da, db = depth.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True)
+    la = UnSupLoss()(imgs, cams, da)
+    lb = R.unsup_loss(imgs, cams, db)
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 3e-5 * abs(float(lb))
+    assert float((da.grad - db.grad).abs().max()) < 4e-6 + 3e-4 * float(db.grad.abs().max())
+    assert float(da.grad.abs().max()) > 0
