@@ -480,40 +480,29 @@ __device__ __forceinline__ void scatter_tap(float* __restrict__ win, const Win& 
 
 
 // Register-resident 2x2 source texel block of one (pixel, channel quad, view): tap values + grad accumulators.
-// The registers hold the block in PHYSICAL rows / columns; the parity bits px / py say which physical column / row is
-// the logical left / top one.  The sample point moves a fraction of a texel per plane, so nearly every block change is
-// a one-texel step along x or y: only the column / row that LEAVES the block is flushed (2 of the 4 texels: half the
-// LDS atomics, the kernel's busiest unit) and re-gathered for the texels that enter; the parity flips and the
-// weights are swapped instead of copying registers.
+// (Measured and rejected, run 27: flushing only the texel pair that leaves the block on a one-texel step -- half the LDS
+//  atomics and gathers -- 0.63 -> 0.66 ms: 241 instead of 207 VGPRs and more VALU outweigh it.)
 struct ViewCache {
-    int cx, cy, px, py;
-    float4 t00, t01, t10, t11;   // tap values, physical [row][column] (zero where the tap is outside the image)
-    float4 g00, g01, g10, g11;   // gradient accumulated since the texel entered the block
+    int cx, cy;
+    float4 t00, t01, t10, t11;   // tap values (zero where the tap is outside the image)
+    float4 g00, g01, g10, g11;   // gradient accumulated since the block was entered
     __device__ __forceinline__ void reset() {
         cx = cy = -0x40000000;
-        px = py = 0;
         t00 = t01 = t10 = t11 = g00 = g01 = g10 = g11 = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    template <int C>
-    __device__ __forceinline__ void flush_one(int xi, int yi, int H, int W, float* __restrict__ win, const Win& w, bool use_win,
-                                              float* __restrict__ gp, int q, float4& g) {
-        if (xi >= 0 && xi < W && yi >= 0 && yi < H) scatter_tap<C>(win, w, use_win, gp, xi, yi, W, q, g, 1.0f);
-        g = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     template <int C>
     __device__ __forceinline__ void flush(int H, int W, float* __restrict__ win, const Win& w, bool use_win,
                                           float* __restrict__ gp, int q) {
         if (cx == -0x40000000) return;
-        // physical (r, c) holds the texel (cx + (c ^ px), cy + (r ^ py))
-        flush_one<C>(cx + px, cy + py, H, W, win, w, use_win, gp, q, g00);
-        flush_one<C>(cx + (px ^ 1), cy + py, H, W, win, w, use_win, gp, q, g01);
-        flush_one<C>(cx + px, cy + (py ^ 1), H, W, win, w, use_win, gp, q, g10);
-        flush_one<C>(cx + (px ^ 1), cy + (py ^ 1), H, W, win, w, use_win, gp, q, g11);
+        const bool xin0 = cx >= 0 && cx < W, xin1 = cx + 1 >= 0 && cx + 1 < W;
+        const bool yin0 = cy >= 0 && cy < H, yin1 = cy + 1 >= 0 && cy + 1 < H;
+        if (xin0 && yin0) scatter_tap<C>(win, w, use_win, gp, cx, cy, W, q, g00, 1.0f);
+        if (xin1 && yin0) scatter_tap<C>(win, w, use_win, gp, cx + 1, cy, W, q, g01, 1.0f);
+        if (xin0 && yin1) scatter_tap<C>(win, w, use_win, gp, cx, cy + 1, W, q, g10, 1.0f);
+        if (xin1 && yin1) scatter_tap<C>(win, w, use_win, gp, cx + 1, cy + 1, W, q, g11, 1.0f);
+        g00 = g01 = g10 = g11 = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    static __device__ __forceinline__ float4 tap(const float* __restrict__ f, int xi, int yi, int H, int W, int C) {
-        return (xi >= 0 && xi < W && yi >= 0 && yi < H) ? ld4(f + ((long)yi * W + xi) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // move to the texel block of (ix, iy); returns the bilinear sample, wt[4] = weights of the physical t00,t01,t10,t11
+    // move to the texel block of (ix, iy) (flush + re-gather if it changed); returns the bilinear sample, wt[4] = weights
     template <int C>
     __device__ __forceinline__ float4 advance(float ix, float iy, const float* __restrict__ f, int H, int W,
                                               float* __restrict__ win, const Win& w, bool use_win,
@@ -524,43 +513,18 @@ struct ViewCache {
         const float fxc = fminf(fmaxf(fx, -2.0f), (float)W), fyc = fminf(fmaxf(fy, -2.0f), (float)H);
         const int x0 = (fxc == fxc) ? (int)fxc : -2, y0 = (fyc == fyc) ? (int)fyc : -2;
         if (x0 != cx || y0 != cy) {
-            const bool live = cx != -0x40000000;
-            const bool xp = live && y0 == cy && x0 == cx + 1, xm = live && y0 == cy && x0 == cx - 1;
-            const bool yp = live && x0 == cx && y0 == cy + 1, ym = live && x0 == cx && y0 == cy - 1;
-            if (xp || xm || yp || ym) {
-                // kind of the physical pair that leaves (and then holds the entering texels): 0/1 = column 0/1, 2/3 = row 0/1.
-                // One code path for all four (selects instead of four copies of the scatter: the copies cost 50 VGPRs + spills).
-                const bool xs = xp || xm;
-                const int kind = xs ? (xp ? px : (px ^ 1)) : 2 + (yp ? py : (py ^ 1));
-                // texel coordinates of the two leaving (o) and the two entering (i) taps; A = first, B = second of the pair
-                const int ya = cy + py, yb = cy + (py ^ 1), xa = cx + px, xb = cx + (px ^ 1);
-                const int xoA = xs ? (xp ? cx : cx + 1) : xa, xoB = xs ? xoA : xb;
-                const int yoA = xs ? ya : (yp ? cy : cy + 1), yoB = xs ? yb : yoA;
-                const int xiA = xs ? (xp ? x0 + 1 : x0) : xa, xiB = xs ? xiA : xb;
-                const int yiA = xs ? ya : (yp ? y0 + 1 : y0), yiB = xs ? yb : yiA;
-                float4 gA = kind == 1 ? g01 : (kind == 3 ? g10 : g00);
-                float4 gB = kind == 0 ? g10 : (kind == 2 ? g01 : g11);
-                flush_one<C>(xoA, yoA, H, W, win, w, use_win, gp, q, gA);
-                flush_one<C>(xoB, yoB, H, W, win, w, use_win, gp, q, gB);
-                const float4 tA = tap(f, xiA, yiA, H, W, C), tB = tap(f, xiB, yiB, H, W, C);
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kind == 0 || kind == 2) { g00 = z4; t00 = tA; }
-                if (kind == 1) { g01 = z4; t01 = tA; } else if (kind == 2) { g01 = z4; t01 = tB; }
-                if (kind == 0) { g10 = z4; t10 = tB; } else if (kind == 3) { g10 = z4; t10 = tA; }
-                if (kind == 1 || kind == 3) { g11 = z4; t11 = tB; }
-                if (xs) { px ^= 1; cx = x0; } else { py ^= 1; cy = y0; }
-            } else {
-                flush<C>(H, W, win, w, use_win, gp, q);
-                cx = x0; cy = y0; px = 0; py = 0;
-                t00 = tap(f, x0, y0, H, W, C);
-                t01 = tap(f, x0 + 1, y0, H, W, C);
-                t10 = tap(f, x0, y0 + 1, H, W, C);
-                t11 = tap(f, x0 + 1, y0 + 1, H, W, C);
-            }
+            flush<C>(H, W, win, w, use_win, gp, q);
+            cx = x0; cy = y0;
+            const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+            const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const float* __restrict__ p = f + ((long)y0 * W + x0) * C;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            t00 = (xin0 && yin0) ? ld4(p) : z4;
+            t01 = (xin1 && yin0) ? ld4(p + C) : z4;
+            t10 = (xin0 && yin1) ? ld4(p + W * C) : z4;
+            t11 = (xin1 && yin1) ? ld4(p + W * C + C) : z4;
         }
-        const float wc0 = px ? wx : ex, wc1 = px ? ex : wx;
-        const float wr0 = py ? wy : ey, wr1 = py ? ey : wy;
-        wt[0] = wr0 * wc0; wt[1] = wr0 * wc1; wt[2] = wr1 * wc0; wt[3] = wr1 * wc1;
+        wt[0] = ey * ex; wt[1] = ey * wx; wt[2] = wy * ex; wt[3] = wy * wx;
         float4 v;
         v.x = fmaf(t11.x, wt[3], fmaf(t10.x, wt[2], fmaf(t01.x, wt[1], t00.x * wt[0])));
         v.y = fmaf(t11.y, wt[3], fmaf(t10.y, wt[2], fmaf(t01.y, wt[1], t00.y * wt[0])));
