@@ -160,6 +160,15 @@ int mvs_unsup_loss_bwd(const float* ref, const float* const* views, const float*
                        const float* depth, int B, int V, int H, int W, float smooth_lambda, float* ws,
                        const float* grad_out, float* grad_depth, hipStream_t stream);
 
+/* ---- stage glue of CVP-MVSNet --------------------------------------------------------------------
+ * Replaces calDepthHypo (jdacs-ms/models/modules.py:107-206): hypos[b,k] = ref_depths[b] + (k - 4) * interval_b, k = 0..7,
+ * interval_b = mean over the pixels of |depth change that moves the projection into source view 0 by one pixel along the
+ * epipolar line| (fp64 inside, like the reference).  mats [B,30] fp64: K_ref^-1 (9), K_src (E_src E_ref^-1)[:3,:] (12),
+ * (K_ref R_ref)(K_src R_src)^-1 (9), prepared by the caller from the camera matrices.  ws: fp64 scratch. */
+long long mvs_depth_hypo_workspace_doubles(int B, int H, int W);
+int mvs_depth_hypo(const float* ref_depths, const double* mats, int B, int H, int W, double* ws, float* hypos,
+                   hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

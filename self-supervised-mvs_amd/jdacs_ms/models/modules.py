@@ -67,45 +67,17 @@ def calDepthHypo(netArgs, ref_depths, ref_intrinsics, src_intrinsics, ref_extrin
     """modules.py:107-206: per-level depth hypotheses [B,8,H,W] = upsampled depth + k * interval,
     k=-4..3, where interval is the MEAN over pixels of the depth change that moves the projection
     into source view 0 by one pixel along the epipolar line (fp64 inside, fp32 out; App. A Q4).
-    The reference's H*W batched 2x2 torch.inverse is replaced by its closed form."""
-    d, pixel_interval = 4, 1.0
-    nb, h, w = ref_depths.shape
-    dev = ref_depths.device
+    One fused kernel pair (csrc/depth_hypo.hip) instead of the reference's ~40 fp64 elementwise ops and
+    H*W batched 2x2 torch.inverse per batch item; only the few 3x3 / 4x4 camera products stay host torch code."""
     with torch.no_grad():
-        ki = ref_intrinsics.double()
-        ks = src_intrinsics[:, 0].double()
-        ei = ref_extrinsics.double()
-        es = src_extrinsics[:, 0].double()
-        ys = torch.arange(h, device=dev, dtype=torch.float64).view(h, 1).expand(h, w).reshape(-1)
-        xs = torch.arange(w, device=dev, dtype=torch.float64).view(1, w).expand(h, w).reshape(-1)
-        X = torch.stack([xs, ys, torch.ones_like(xs)], 0)  # [3,HW]
-        one = torch.ones(1, h * w, dtype=torch.float64, device=dev)
-        hypos = ref_depths.unsqueeze(1).repeat(1, 2 * d, 1, 1).double()
-        for b in range(nb):
-            D1 = ref_depths[b].reshape(-1).double()
-            ki_inv, ei_inv = torch.inverse(ki[b]), torch.inverse(ei[b])
-
-            def to_src(Dz):
-                wpt = ei_inv @ torch.cat([ki_inv @ (X * Dz), one], 0)
-                pix = ks[b] @ (es[b] @ wpt)[:3]
-                z = pix[2].clone()
-                return pix / z, z
-
-            X1, X1_d = to_src(D1)
-            X2, _ = to_src(D1 + 1)
-            theta = torch.atan((X2[1] - X1[1]) / (X2[0] - X1[0]))
-            X3 = X1 + torch.stack([torch.cos(theta) * pixel_interval, torch.sin(theta) * pixel_interval,
-                                   torch.zeros_like(theta)], 0)
-            A = (ki[b] @ ei[b][:3, :3]) @ torch.inverse(ks[b] @ es[b][:3, :3])
-            t1 = X1_d * (A @ X1)
-            t2 = A @ X3
-            # solve [[y, t2.y], [1, t2.z]] @ (delta_d, .) = (t1.y, t1.z) for delta_d
-            det = ys * t2[2] - t2[1]
-            delta_d = (t2[2] * t1[1] - t2[1] * t1[2]) / det
-            interval = delta_d.abs().mean()
-            for lv in range(-d, d):
-                hypos[b, lv + d] += lv * interval
-        return hypos.float()
+        ki, ks = ref_intrinsics.double(), src_intrinsics[:, 0].double()
+        ei, es = ref_extrinsics.double(), src_extrinsics[:, 0].double()
+        inv = lambda m: torch.linalg.inv_ex(m).inverse            # same LU as torch.inverse, no device sync
+        T = ks @ (es @ inv(ei))[:, :3, :]                          # src pixel (homogeneous) of a ref camera-frame point
+        A = (ki @ ei[:, :3, :3]) @ inv(ks @ es[:, :3, :3])
+        nb = ref_depths.shape[0]
+        mats = torch.cat([inv(ki).reshape(nb, 9), T.reshape(nb, 12), A.reshape(nb, 9)], 1)
+        return ops.depth_hypotheses(ref_depths.float(), mats)
 
 
 def proj_cost(settings, ref_feature, src_feature, level, ref_in, src_in, ref_ex, src_ex, depth_hypos,

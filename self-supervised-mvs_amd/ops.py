@@ -459,3 +459,21 @@ class UnsupLossFn(torch.autograd.Function):
 
 def unsup_loss(depth, ref_q, views_q, kinv, proj, smooth_lambda=1.0):
     return UnsupLossFn.apply(depth, ref_q, list(views_q), kinv, proj, smooth_lambda)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-level depth hypotheses of CVP-MVSNet
+# ------------------------------------------------------------------------------------------------
+def depth_hypotheses(ref_depths: torch.Tensor, mats: torch.Tensor) -> torch.Tensor:
+    """ref_depths [B,H,W] fp32, mats [B,30] fp64 (K_ref^-1 | K_src (E_src E_ref^-1)[:3,:] | (K_ref R_ref)(K_src R_src)^-1)
+    -> hypotheses [B,8,H,W] fp32 (jdacs-ms/models/modules.py:107-206).  No gradient, like the reference (no_grad)."""
+    lib = _lib_for(ref_depths)
+    ref_depths = ref_depths.detach().contiguous()
+    b, h, w = ref_depths.shape
+    if mats.dtype != torch.float64 or tuple(mats.shape) != (b, 30):
+        raise ValueError("mats must be float64 [B,30], got %s %s" % (mats.dtype, tuple(mats.shape)))
+    mats = mats.contiguous()
+    ws = torch.empty(lib.raw("mvs_depth_hypo_workspace_doubles", b, h, w), dtype=torch.float64, device=ref_depths.device)
+    hypos = torch.empty((b, 8, h, w), dtype=torch.float32, device=ref_depths.device)
+    lib.call("mvs_depth_hypo", _p(ref_depths), _p(mats), b, h, w, _p(ws), _p(hypos), _stream(ref_depths))
+    return hypos

@@ -416,3 +416,23 @@ def test_unsup_loss_vs_oracle_ragged_and_errors(emul_lib):
         crit(imgs, cams[:, :5], depth)
     with pytest.raises(ValueError):
         crit(imgs, cams, depth[:, :-1])
+
+
+def test_cal_depth_hypo_golden_and_oracle(emul_lib):
+    """calDepthHypo through the fused kernel pair vs the fixture from the imported reference and vs the
+    oracle on a ragged batch-2 case."""
+    from mvs_amd.jdacs_ms.models import modules as M
+    g = load_golden("g7_cvpmvsnet_e2e")
+    hyp = M.calDepthHypo(None, g["depth_up"], g["ref_in"], g["src_in"], g["ref_ex"], g["src_ex"], None, None, 0)
+    assert hyp.shape == g["hypos0"].shape and hyp.dtype == torch.float32
+    assert float((hyp - g["hypos0"]).abs().max()) < 1e-3
+    gen = torch.Generator().manual_seed(4)
+    b, h, w = 2, 37, 53
+    K, E = R.synthetic_cameras(3, h, w, 4 * w)
+    ref_in, src_in = K.unsqueeze(0).repeat(b, 1, 1), K.view(1, 1, 3, 3).repeat(b, 2, 1, 1)
+    ref_ex, src_ex = E[0].unsqueeze(0).repeat(b, 1, 1), E[1:].unsqueeze(0).repeat(b, 1, 1, 1).clone()
+    src_ex[1, :, :3, 3] *= 1.4
+    depth = 600.0 + 80.0 * torch.rand(b, h, w, generator=gen)
+    a = M.calDepthHypo(None, depth, ref_in, src_in, ref_ex, src_ex, None, None, 1)
+    e = R.cal_depth_hypo(depth, ref_in, src_in, ref_ex, src_ex)
+    assert float((a - e).abs().max()) < 1e-3
