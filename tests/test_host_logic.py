@@ -1,5 +1,7 @@
 """CPU: host-side logic of the drop-in modules that needs no kernel (loss form, state_dict layout,
 depth-hypothesis helpers, argument validation)."""
+import os
+
 import pytest
 import torch
 
@@ -69,3 +71,51 @@ def test_shape_validation_raises_early():
         CostRegNet()(torch.zeros(1, 32, 12, 16, 16))
     with pytest.raises(ValueError):
         ConvBnReLU3D(8, 8, kernel_size=5)
+
+
+def test_pfm_bytes_match_the_reference_and_round_trip(tmp_path):
+    """the on-disk format of the path's outputs.  The fixture holds the bytes the reference's save_pfm wrote."""
+    import numpy as np
+    from mvs_amd.jdacs.datasets.data_io import read_pfm, save_pfm
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_pfm.npz"))
+    for key, scale in (("depth", 1), ("color", 2.5)):
+        p = str(tmp_path / (key + ".pfm"))
+        save_pfm(p, g[key], scale)
+        assert open(p, "rb").read() == g[key + "_bytes"].tobytes()
+        back, sc = read_pfm(p)
+        assert np.array_equal(back, g[key]) and sc == scale
+    save_pfm(str(tmp_path / "one.pfm"), g["depth"][:, :, None])
+    assert read_pfm(str(tmp_path / "one.pfm"))[0].shape == (32, 40)
+    with pytest.raises(Exception, match="float32"):
+        save_pfm(str(tmp_path / "x.pfm"), g["depth"].astype(np.float64))
+    with pytest.raises(Exception, match="dimensions"):
+        save_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 3, 4), np.float32))
+    (tmp_path / "bad.pfm").write_bytes(b"P6\n1 1\n255\n")
+    with pytest.raises(Exception, match="Not a PFM"):
+        read_pfm(str(tmp_path / "bad.pfm"))
+
+
+def test_eval_plumbing_helpers(tmp_path):
+    """checkpoint with DataParallel's `module.` prefix -> model; outputs dict -> PFM files named like jdacs/eval.py:155-164."""
+    import numpy as np
+    from mvs_amd.jdacs.datasets.data_io import read_pfm
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    from mvs_amd.jdacs.utils import load_checkpoint, save_depth_outputs, tensor2float, tensor2numpy
+    torch.manual_seed(1)
+    src = MVSNet(refine=False)
+    ckpt = {"epoch": 3, "model": {"module." + k: v for k, v in src.state_dict().items()}}
+    torch.save(ckpt, str(tmp_path / "model_000003.ckpt"))
+    dst = MVSNet(refine=False)
+    res = load_checkpoint(dst, str(tmp_path / "model_000003.ckpt"))
+    assert not res.missing_keys and not res.unexpected_keys
+    assert all(torch.equal(v, dst.state_dict()[k]) for k, v in src.state_dict().items())
+    outputs = {"depth": torch.rand(2, 8, 10) + 500, "photometric_confidence": torch.rand(2, 8, 10)}
+    names = ["scan1/{}/00000000{}", "scan1/{}/00000001{}"]
+    paths = save_depth_outputs(outputs, names, str(tmp_path / "out"))
+    assert len(paths) == 4 and paths[0].endswith("scan1/depth_est/00000000.pfm") and paths[3].endswith("scan1/confidence/00000001.pfm")
+    assert np.array_equal(read_pfm(paths[2])[0], outputs["depth"][1].numpy())
+    nested = tensor2numpy({"a": [torch.ones(2), (torch.zeros(1),)], "b": np.ones(3)})
+    assert isinstance(nested["a"][1][0], np.ndarray) and nested["a"][0].sum() == 2
+    assert tensor2float({"loss": torch.tensor(1.5), "lr": 0.1}) == {"loss": 1.5, "lr": 0.1}
+    with pytest.raises(NotImplementedError):
+        tensor2numpy("x")
