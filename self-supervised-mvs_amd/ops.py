@@ -8,6 +8,7 @@ which is the layout the kernels index.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -232,6 +233,63 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
     return gw
 
 
+# ---- weight gradients on a side stream -------------------------------------------------------------------------
+# In the backward pass a layer's weight gradient is a leaf of the dependency graph: nothing needs it before the optimiser
+# step, while the input gradient feeds the next layer's backward.  The deep U-Net levels launch fewer workgroups than
+# the chip has CUs and every weight gradient ends in two tiny reduction kernels, so running them on a second HIP stream
+# lets them fill the gaps of the main chain.  The side stream forks from the main stream when the output gradient is
+# ready and is joined by ONE end-of-backward callback (autograd engine), so every consumer after backward() sees
+# finished gradients.  Safe only if nothing consumes the gradient DURING the backward pass: a weight whose .grad already
+# exists (accumulation kernel on the main stream) or that was used by several forward calls (the engine sums the
+# contributions) takes the synchronous path.  MVS_ASYNC_WGRAD=0 switches it off.
+_ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
+_SIDE_STREAMS = {}      # device index -> side stream
+_WEIGHT_USES = {}       # weight data_ptr -> forward uses since the last completed backward pass
+_JOIN_PENDING = {}      # device index -> main stream that has to wait for the side stream
+
+
+def set_async_wgrad(flag: bool) -> None:
+    global _ASYNC_WGRAD
+    _ASYNC_WGRAD = bool(flag)
+
+
+def _note_weight_use(weight: torch.Tensor) -> None:
+    if _ASYNC_WGRAD and weight.is_cuda:
+        _WEIGHT_USES[weight.data_ptr()] = _WEIGHT_USES.get(weight.data_ptr(), 0) + 1
+
+
+def _join_side_streams() -> None:
+    for idx, main in list(_JOIN_PENDING.items()):
+        main.wait_stream(_SIDE_STREAMS[idx])
+    _JOIN_PENDING.clear()
+    _WEIGHT_USES.clear()
+
+
+def _wgrad_maybe_async(x, gy, weight, stride, transposed):
+    lib = _lib_for(x)
+    ok = (_ASYNC_WGRAD and x.is_cuda and lib.profiler is None and weight.grad is None
+          and _WEIGHT_USES.get(weight.data_ptr(), 0) <= 1)
+    if not ok:
+        return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
+    idx = x.device.index
+    main = torch.cuda.current_stream(x.device)
+    side = _SIDE_STREAMS.get(idx)
+    if side is None:
+        side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=x.device)
+    x, gy = as_cl3(x), as_cl3(gy)
+    side.wait_stream(main)                       # gy was produced on the main stream
+    with torch.cuda.stream(side):
+        gw = conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
+    for t in (x, gy):
+        t.record_stream(side)                    # the caching allocator must not recycle them under the side kernels
+    gw.record_stream(main)
+    if idx not in _JOIN_PENDING:
+        _JOIN_PENDING[idx] = main
+        if len(_JOIN_PENDING) == 1:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+    return gw
+
+
 class ConvBnReLU3dFn(torch.autograd.Function):
     """conv3d | conv_transpose3d (bias-free, k3 p1) -> BatchNorm3d -> ReLU (-> + skip, after the ReLU).
 
@@ -255,6 +313,7 @@ class ConvBnReLU3dFn(torch.autograd.Function):
             y, _ = conv3d_forward(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
             ctx.eval_mode = True
             return y
+        _note_weight_use(weight)
         raw, parts = conv3d_forward(x, weight, stride, transposed, want_stats=True)
         b, _, od, oh, ow = raw.shape
         count = b * od * oh * ow
@@ -286,7 +345,7 @@ class ConvBnReLU3dFn(torch.autograd.Function):
         lib.call("mvs_bn_relu_bwd", _p(gy), _p(raw), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, count,
                  cout, _p(ws), _p(draw), _p(dgb[0]), _p(dgb[1]), st)
         gx = conv3d_dgrad(draw, weight, tuple(x.shape), stride, transposed) if ctx.needs_input_grad[0] else None
-        gw = conv3d_wgrad(x, draw, tuple(weight.shape), stride, transposed) if ctx.needs_input_grad[1] else None
+        gw = _wgrad_maybe_async(x, draw, weight, stride, transposed) if ctx.needs_input_grad[1] else None
         gskip = gy if has_skip else None
         return gx, gw, dgb[0], dgb[1], None, None, gskip, None, None, None, None, None
 
@@ -344,6 +403,7 @@ class ConvBias3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = as_cl3(x)
+        _note_weight_use(weight)
         y, _ = conv3d_forward(x, weight, 1, False, shift=bias.contiguous())
         ctx.save_for_backward(x, weight)
         return y
@@ -353,7 +413,7 @@ class ConvBias3dFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = as_cl3(gy)
         gx = conv3d_dgrad(gy, weight, tuple(x.shape), 1, False) if ctx.needs_input_grad[0] else None
-        gw = conv3d_wgrad(x, gy, tuple(weight.shape), 1, False) if ctx.needs_input_grad[1] else None
+        gw = _wgrad_maybe_async(x, gy, weight, 1, False) if ctx.needs_input_grad[1] else None
         gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
