@@ -267,8 +267,8 @@ def _join_side_streams() -> None:
 
 def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     lib = _lib_for(x)
-    ok = (_ASYNC_WGRAD and x.is_cuda and lib.profiler is None and weight.grad is None
-          and _WEIGHT_USES.get(weight.data_ptr(), 0) <= 1)
+    # (a KernelTimer keeps working: its events are recorded on the current stream, which is the side stream below)
+    ok = _ASYNC_WGRAD and x.is_cuda and weight.grad is None and _WEIGHT_USES.get(weight.data_ptr(), 0) <= 1
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
     idx = x.device.index
