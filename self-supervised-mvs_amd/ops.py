@@ -267,8 +267,14 @@ def _join_side_streams() -> None:
 
 def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     lib = _lib_for(x)
-    # (a KernelTimer keeps working: its events are recorded on the current stream, which is the side stream below)
     ok = _ASYNC_WGRAD and x.is_cuda and weight.grad is None and _WEIGHT_USES.get(weight.data_ptr(), 0) <= 1
+    if ok and lib.profiler is not None:
+        # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
+        # not the kernel's plus whatever shares the chip with it on the other stream
+        b, cin, d, h, w = x.shape
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        ok = not lib.profiler.wants("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad",
+                                    _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
     idx = x.device.index
