@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -243,9 +244,10 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
 # exists (accumulation kernel on the main stream) or that was used by several forward calls (the engine sums the
 # contributions) takes the synchronous path.  MVS_ASYNC_WGRAD=0 switches it off.
 _ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
-_SIDE_STREAMS = {}      # device index -> side stream
-_WEIGHT_USES = {}       # weight data_ptr -> forward uses since the last completed backward pass
-_JOIN_PENDING = {}      # device index -> main stream that has to wait for the side stream
+_SIDE_STREAMS = {}                 # device index -> side stream (created once)
+_TLS = threading.local()           # per Python thread (nn.DataParallel-style callers run one thread per GPU):
+#   .uses    weight data_ptr -> forward uses since the last completed backward pass
+#   .pending device index -> main stream that has to wait for the side stream at the end of the backward pass
 
 
 def set_async_wgrad(flag: bool) -> None:
@@ -253,21 +255,30 @@ def set_async_wgrad(flag: bool) -> None:
     _ASYNC_WGRAD = bool(flag)
 
 
+def _tls():
+    if not hasattr(_TLS, "uses"):
+        _TLS.uses, _TLS.pending = {}, {}
+    return _TLS
+
+
 def _note_weight_use(weight: torch.Tensor) -> None:
     if _ASYNC_WGRAD and weight.is_cuda:
-        _WEIGHT_USES[weight.data_ptr()] = _WEIGHT_USES.get(weight.data_ptr(), 0) + 1
+        t = _tls()
+        t.uses[weight.data_ptr()] = t.uses.get(weight.data_ptr(), 0) + 1
 
 
 def _join_side_streams() -> None:
-    for idx, main in list(_JOIN_PENDING.items()):
+    t = _tls()
+    for idx, main in list(t.pending.items()):
         main.wait_stream(_SIDE_STREAMS[idx])
-    _JOIN_PENDING.clear()
-    _WEIGHT_USES.clear()
+    t.pending.clear()
+    t.uses.clear()
 
 
 def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     lib = _lib_for(x)
-    ok = _ASYNC_WGRAD and x.is_cuda and weight.grad is None and _WEIGHT_USES.get(weight.data_ptr(), 0) <= 1
+    t = _tls()
+    ok = _ASYNC_WGRAD and x.is_cuda and weight.grad is None and t.uses.get(weight.data_ptr(), 0) <= 1
     if ok and lib.profiler is not None:
         # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
         # not the kernel's plus whatever shares the chip with it on the other stream
@@ -281,17 +292,17 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     main = torch.cuda.current_stream(x.device)
     side = _SIDE_STREAMS.get(idx)
     if side is None:
-        side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=x.device)
+        side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=x.device))
     x, gy = as_cl3(x), as_cl3(gy)
     side.wait_stream(main)                       # gy was produced on the main stream
     with torch.cuda.stream(side):
         gw = conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
-    for t in (x, gy):
-        t.record_stream(side)                    # the caching allocator must not recycle them under the side kernels
+    for ten in (x, gy):
+        ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
     gw.record_stream(main)
-    if idx not in _JOIN_PENDING:
-        _JOIN_PENDING[idx] = main
-        if len(_JOIN_PENDING) == 1:
+    if idx not in t.pending:
+        t.pending[idx] = main
+        if len(t.pending) == 1:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
     return gw
 
