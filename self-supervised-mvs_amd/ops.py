@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -244,10 +243,12 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
 # exists (accumulation kernel on the main stream) or that was used by several forward calls (the engine sums the
 # contributions) takes the synchronous path.  MVS_ASYNC_WGRAD=0 switches it off.
 _ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
-_SIDE_STREAMS = {}                 # device index -> side stream (created once)
-_TLS = threading.local()           # per Python thread (nn.DataParallel-style callers run one thread per GPU):
-#   .uses    weight data_ptr -> forward uses since the last completed backward pass
-#   .pending device index -> main stream that has to wait for the side stream at the end of the backward pass
+# Bookkeeping is per DEVICE, not per thread: the autograd engine runs backward nodes on its own worker threads and the
+# final callback on the thread that called backward(), so thread-local state would not connect them; one-thread-per-GPU
+# callers (nn.DataParallel style) touch disjoint entries.
+_SIDE_STREAMS = {}      # device index -> side stream (created once)
+_WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses since the last completed backward pass}
+_JOIN_PENDING = {}      # device index -> main stream that has to wait for the side stream at the end of the backward pass
 
 
 def set_async_wgrad(flag: bool) -> None:
@@ -255,30 +256,24 @@ def set_async_wgrad(flag: bool) -> None:
     _ASYNC_WGRAD = bool(flag)
 
 
-def _tls():
-    if not hasattr(_TLS, "uses"):
-        _TLS.uses, _TLS.pending = {}, {}
-    return _TLS
-
-
 def _note_weight_use(weight: torch.Tensor) -> None:
     if _ASYNC_WGRAD and weight.is_cuda:
-        t = _tls()
-        t.uses[weight.data_ptr()] = t.uses.get(weight.data_ptr(), 0) + 1
+        uses = _WEIGHT_USES.setdefault(weight.device.index, {})
+        uses[weight.data_ptr()] = uses.get(weight.data_ptr(), 0) + 1
 
 
-def _join_side_streams() -> None:
-    t = _tls()
-    for idx, main in list(t.pending.items()):
+def _join_side_stream(idx: int) -> None:
+    main = _JOIN_PENDING.pop(idx, None)
+    if main is not None:
         main.wait_stream(_SIDE_STREAMS[idx])
-    t.pending.clear()
-    t.uses.clear()
+    _WEIGHT_USES.pop(idx, None)
 
 
 def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     lib = _lib_for(x)
-    t = _tls()
-    ok = _ASYNC_WGRAD and x.is_cuda and weight.grad is None and t.uses.get(weight.data_ptr(), 0) <= 1
+    idx = x.device.index
+    ok = (_ASYNC_WGRAD and x.is_cuda and weight.grad is None
+          and _WEIGHT_USES.get(idx, {}).get(weight.data_ptr(), 0) <= 1)
     if ok and lib.profiler is not None:
         # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
         # not the kernel's plus whatever shares the chip with it on the other stream
@@ -288,7 +283,6 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
                                     _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
-    idx = x.device.index
     main = torch.cuda.current_stream(x.device)
     side = _SIDE_STREAMS.get(idx)
     if side is None:
@@ -300,10 +294,9 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     for ten in (x, gy):
         ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
     gw.record_stream(main)
-    if idx not in t.pending:
-        t.pending[idx] = main
-        if len(t.pending) == 1:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+    if idx not in _JOIN_PENDING:
+        _JOIN_PENDING[idx] = main
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side_stream(idx))
     return gw
 
 
