@@ -56,3 +56,38 @@ def test_error_convention():
     with pytest.raises(ValueError, match="null pointer"):
         lib.call("mvs_softargmin_conf_fwd", None, None, 0, 1, 4, 2, 2, None, None, None, None, None)
     assert lib.raw("mvs_conv3d_workspace_bytes", 99, 1, 8, 8, 8, 8, 8, 1) == -1
+
+
+def test_error_convention_of_every_entry_point():
+    """Each compute entry point validates its arguments on the host BEFORE launching anything: null pointers and shapes
+    the kernels do not support come back as a negative code with a message (ValueError in the wrapper), never as a crash.
+    Runs against the product library on the CPU (validation happens before any device call)."""
+    from mvs_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = _lib.MvsLib()
+    null_calls = [
+        ("mvs_plane_sweep_variance_fwd", (None, None, None, None, None, 0, 1, 3, 32, 8, 8, 8, 0, 0, None, None)),
+        ("mvs_homo_warp_fwd", (None, None, None, None, 0, 1, 8, 4, 8, 8, 0, None, None)),
+        ("mvs_conv3d_fwd", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None, None, None, 0, None, None)),
+        ("mvs_conv3d_dgrad", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None)),
+        ("mvs_conv3d_wgrad", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None)),
+        ("mvs_convT3d_fwd", (None, None, None, None, 1, 4, 4, 8, 16, 8, 2, None, None, None, 0, None, None)),
+        ("mvs_bn_relu_fwd", (None, None, None, None, 1, 64, 8, None, None)),
+        ("mvs_softargmin_conf_bwd", (None, None, None, 0, None, None, None, 1, 4, 2, 2, None, None)),
+        ("mvs_unsup_loss_fwd", (None, None, None, None, None, 1, 4, 8, 8, 1.0, None, None, None)),
+        ("mvs_unsup_loss_bwd", (None, None, None, None, None, 1, 4, 8, 8, 1.0, None, None, None, None)),
+        ("mvs_depth_hypo", (None, None, 1, 8, 8, None, None, None)),
+    ]
+    for name, args in null_calls:
+        with pytest.raises(ValueError):
+            lib.call(name, *args)
+        assert lib.raw("mvs_last_error"), name
+    # shape / size queries answer -1 for impossible shapes instead of a size
+    assert lib.raw("mvs_unsup_loss_workspace_floats", 1, 4, 2, 8) == -1
+    assert lib.raw("mvs_depth_hypo_workspace_doubles", 0, 8, 8) == -1
+    assert lib.raw("mvs_unsup_loss_workspace_floats", 2, 4, 16, 20) == 4 * 2 * 320 * 4 + (4 * 4 + 2) * 3 + 64 + 2 * 2 * 14 * 18 * 9
+    assert lib.raw("mvs_conv3d_stat_rows", 0, 1, 192, 128, 160, 32, 8, 1) == 15360
+    # unknown tuning key
+    with pytest.raises(ValueError, match="unknown key"):
+        lib.call("mvs_set_tuning", b"zz_no_such_knob", 1)
