@@ -436,3 +436,39 @@ def test_cal_depth_hypo_golden_and_oracle(emul_lib):
     a = M.calDepthHypo(None, depth, ref_in, src_in, ref_ex, src_ex, None, None, 1)
     e = R.cal_depth_hypo(depth, ref_in, src_in, ref_ex, src_ex)
     assert float((a - e).abs().max()) < 1e-3
+
+
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="2.5 minutes of emulation; set MVS_EMUL_FULL=1 (the GPU version is test_gpu_parity.py::test_config3_self_supervised_step_vs_gpu_oracle)")
+def test_jdacs_self_supervised_step_end_to_end(emul_lib):
+    """BASELINE config 3 in miniature (N = 4 views, 32x64 images, D = 8): MVSNet forward -> UnSupLoss on its depth map ->
+    backward into the network, every kernel of the path in one graph, vs the oracle's MVSNet + UnSupLoss."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(5)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(30.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    net.train()
+    oracle.train()
+    b, n, h, w, d = 1, 4, 32, 64, 8
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(b, n, h, w, d, seed=2, depth_min=600.0, interval=8.0)
+    imgs = F.avg_pool2d(imgs.view(b * n, 3, h, w), 5, 1, 2).view(b, n, 3, h, w) * 3
+    K, E = R.synthetic_cameras(n, h // 4, w // 4, w)
+    cams = torch.zeros(b, n, 2, 4, 4)
+    cams[:, :, 0] = E
+    cams[:, :, 1, :3, :3] = K
+    la = UnSupLoss()(imgs, cams, net(imgs, proj, dv)["depth"])
+    lb = R.unsup_loss(imgs, cams, oracle(imgs, proj, dv)["depth"])
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 1e-4 * abs(float(lb))
+    pa, pb = dict(net.named_parameters()), dict(oracle.named_parameters())
+    checked = 0
+    for k in ("cost_regularization.prob.weight", "cost_regularization.conv0.conv.weight", "feature.conv0.conv.weight",
+              "cost_regularization.conv7.0.weight"):
+        if pb[k].grad is not None and float(pb[k].grad.abs().max()) > 0:
+            assert rel_l1(pa[k].grad, pb[k].grad) < 2e-2, k
+            checked += 1
+    assert checked >= 3

@@ -518,3 +518,42 @@ def test_unsup_loss_config3_shape_vs_gpu_oracle(dev):
     assert abs(float(la) - float(lb)) < 3e-5 * abs(float(lb))
     assert float((da.grad - db.grad).abs().max()) < 4e-6 + 3e-4 * float(db.grad.abs().max())
     assert float(da.grad.abs().max()) > 0
+
+
+def test_config3_self_supervised_step_vs_gpu_oracle(dev):
+    """BASELINE config 3 per GPU (N = 5, 640x512, D = 192, one sample): MVSNet forward -> UnSupLoss on its depth map ->
+    backward into the network, vs the oracle's MVSNet + UnSupLoss (stock torch ops) on the same GPU.  The loss has
+    branch points (floor, validity masks, the smooth-L1 knee, top-3 selection), so the gradients are compared by
+    direction and magnitude rather than element by element."""
+    from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(5)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    oracle = R.OracleMVSNet(refine=False)
+    oracle.load_state_dict(net.state_dict())
+    net, oracle = net.to(dev).train(), oracle.to(dev).train()
+    b, n, h, w, d = 1, 5, 512, 640, 192
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(b, n, h, w, d, seed=2)
+    imgs = F.avg_pool2d(imgs.view(b * n, 3, h, w), 9, 1, 4).view(b, n, 3, h, w) * 4
+    K, E = R.synthetic_cameras(n, h // 4, w // 4, w)
+    cams = torch.zeros(b, n, 2, 4, 4)
+    cams[:, :, 0] = E
+    cams[:, :, 1, :3, :3] = K
+    imgs, proj, dv, cams = imgs.to(dev), proj.to(dev), dv.to(dev), cams.to(dev)
+    da = net(imgs, proj, dv)["depth"]
+    db = oracle(imgs, proj, dv)["depth"]
+    assert rel_l1(da, db) < 1e-3
+    la = UnSupLoss()(imgs, cams, da)
+    lb = R.unsup_loss(imgs, cams, db)
+    assert abs(float(la) - float(lb)) < 1e-3 * abs(float(lb))
+    la.backward()
+    lb.backward()
+    pa, pb = dict(net.named_parameters()), dict(oracle.named_parameters())
+    for k in ("cost_regularization.conv0.conv.weight", "cost_regularization.prob.weight", "feature.feature.weight"):
+        ga, gb = pa[k].grad.flatten(), pb[k].grad.flatten()
+        assert torch.isfinite(ga).all()
+        cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30))
+        assert cos > 0.98, (k, cos)
+        assert 0.8 < float(ga.norm() / (gb.norm() + 1e-30)) < 1.25, k
