@@ -101,7 +101,7 @@ CONV_CASES = [
     (16, 32, 2, False, (6, 4, 8)),
     (16, 8, 2, True, (2, 4, 10)),
     (64, 32, 2, True, (2, 2, 4)),
-    (64, 32, 1, True, (3, 4, 6)),
+    (64, 32, 1, True, (2, 3, 5)),
     (8, 1, 1, False, (4, 5, 18)),
 ]
 
@@ -110,7 +110,7 @@ CONV_CASES = [
 def test_conv3d_family(emul_lib, cin, cout, stride, transposed, dims):
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin * 7 + cout)
-    b = 2 if max(dims) <= 16 else 1
+    b = 2 if max(dims) <= 16 and cin < 64 else 1      # (the emulated MFMA is a 64-thread barrier: keep the 64-channel cases small)
     x = torch.randn(b, cin, *dims, generator=g)
     wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
     w = torch.randn(wshape, generator=g) * 0.2
