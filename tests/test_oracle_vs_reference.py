@@ -96,3 +96,36 @@ for (k, p), (_, q) in zip(ref.named_parameters(), ora.named_parameters()):
     if p.grad is None or k.endswith("prob0.bias"): continue
     assert float((p.grad - q.grad).abs().mean()) <= 3e-2 * float(p.grad.abs().mean()) + 1e-9, k  # roundoff grows 4e-7 -> 9e-3 from last to first layer (3 levels of batch-stat BN)
 """)
+
+
+def test_unsup_loss_seven_views_other_lambda_and_pfm():
+    """SURVEY 8(f)-1 / A12 beyond the committed fixtures: N = 7, odd quarter-resolution size, batch 3; the reference's
+    save_pfm / read_pfm against the drop-in's on a random map."""
+    _run(PRE + """
+sys.argv = ["x", "--smooth_lambda", "0.5"]
+sys.path.insert(0, "/root/reference/jdacs")
+from losses.unsup_loss import UnSupLoss
+g = torch.Generator().manual_seed(4)
+b, n, h, w = 3, 7, 52, 76
+imgs = F.avg_pool2d(torch.randn(b * n, 3, h, w, generator=g), 5, 1, 2).view(b, n, 3, h, w) * 3
+K, E = R.synthetic_cameras(n, h // 4, w // 4, w)
+cams = torch.zeros(b, n, 2, 4, 4); cams[:, :, 0] = E; cams[:, :, 1, :3, :3] = K
+depth = 600.0 + 40.0 * torch.rand(b, h // 4, w // 4, generator=g)
+da, db = depth.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+la = UnSupLoss()(imgs, cams, da)
+lb = R.unsup_loss(imgs, cams, db, smooth_lambda=0.5)
+la.backward(); lb.backward()
+assert abs(float(la) - float(lb)) < 2e-5 * abs(float(la)), (float(la), float(lb))
+assert float((da.grad - db.grad).abs().max()) < 2e-6 + 1e-4 * float(da.grad.abs().max())
+import numpy as np, tempfile, os
+import mvs_amd
+from mvs_amd.jdacs.datasets import data_io as mine
+import importlib.util
+spec = importlib.util.spec_from_file_location("ref_data_io", "/root/reference/jdacs/datasets/data_io.py")
+ref_io = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_io)
+arr = np.random.RandomState(1).rand(17, 23).astype(np.float32) * 900
+with tempfile.TemporaryDirectory() as d:
+    ref_io.save_pfm(os.path.join(d, "a.pfm"), arr); mine.save_pfm(os.path.join(d, "b.pfm"), arr)
+    assert open(os.path.join(d, "a.pfm"), "rb").read() == open(os.path.join(d, "b.pfm"), "rb").read()
+    assert np.array_equal(mine.read_pfm(os.path.join(d, "a.pfm"))[0], ref_io.read_pfm(os.path.join(d, "b.pfm"))[0])
+""")
