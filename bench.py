@@ -131,7 +131,7 @@ def main():
     import mvs_amd  # noqa: F401
     from mvs_amd import _lib, dist as mdist
     from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
-    from oracle.ref_torch import synthetic_mvsnet_inputs  # input generator only (shared synthetic cameras)
+    from mvs_amd.synthetic import synthetic_mvsnet_inputs
 
     rank, world, local = mdist.init_from_env("nccl")
     if world != args.gpus and rank == 0:

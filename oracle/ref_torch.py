@@ -474,43 +474,14 @@ def cvp_args(nsrc=2, nscale=2, mode="test"):
 # --------------------------------------------------------------------------------------------
 # synthetic DTU-shaped inputs; used by tests, smoke and bench (CPU leg)
 # --------------------------------------------------------------------------------------------
-def _rot_xy(ax_deg, ay_deg):
-    ax, ay = math.radians(ax_deg), math.radians(ay_deg)
-    rx = torch.tensor([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
-    ry = torch.tensor([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
-    return (ry @ rx).float()
+# The generators themselves live in the package (mvs_amd.synthetic) so that bench.py and the measurement tools need not
+# import this test-only module for their inputs; re-exported here for the tests.
+import os as _os
+import sys as _sys
 
-
-def synthetic_cameras(nviews, feat_h, feat_w, img_w):
-    """Feature-resolution K, and extrinsics: reference = small rotation + small translation; sources
-    rotate +-(2..6) deg about x and y and translate +-(30..100) mm in x, 1/3 in y, 1/10 in z."""
-    f = 0.565 * img_w * (feat_w / img_w)
-    K = torch.tensor([[f, 0, feat_w / 2.0], [0, f, feat_h / 2.0], [0, 0, 1]], dtype=torch.float32)
-    exts = []
-    for v in range(nviews):
-        E = torch.eye(4)
-        if v == 0:
-            E[:3, :3] = _rot_xy(1.0, -0.7)
-            E[:3, 3] = torch.tensor([5.0, 2.0, 0.5])
-        else:
-            sgn = 1.0 if v % 2 else -1.0
-            mag = 30.0 + 70.0 * ((v * 37) % 100) / 100.0
-            E[:3, :3] = _rot_xy(sgn * (2.0 + (v * 1.3) % 4.0), -sgn * (2.0 + (v * 2.1) % 4.0))
-            E[:3, 3] = torch.tensor([sgn * mag, -sgn * mag / 3.0, sgn * mag / 10.0])
-        exts.append(E)
-    return K, torch.stack(exts)
-
-
-def synthetic_mvsnet_inputs(batch, nviews, img_h, img_w, ndepth, seed=1, depth_min=425.0, interval=2.65):
-    g = torch.Generator().manual_seed(seed)
-    imgs = torch.randn(batch, nviews, 3, img_h, img_w, generator=g)
-    fh, fw = img_h // 4, img_w // 4
-    K, E = synthetic_cameras(nviews, fh, fw, img_w)
-    proj = E.clone()
-    proj[:, :3, :4] = torch.matmul(K, E[:, :3, :4])
-    proj = proj.unsqueeze(0).repeat(batch, 1, 1, 1)
-    depth_values = (depth_min + interval * torch.arange(ndepth, dtype=torch.float32)).unsqueeze(0).repeat(batch, 1)
-    return imgs, proj, depth_values
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import mvs_amd  # noqa: E402,F401  (repo-root alias of self-supervised-mvs_amd/)
+from mvs_amd.synthetic import _rot_xy, synthetic_cameras, synthetic_mvsnet_inputs  # noqa: E402,F401
 
 
 # =============================================================================================

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 import mvs_amd  # noqa: F401
 from mvs_amd import _lib, ops
-from oracle import ref_torch as R  # synthetic cameras only
+from mvs_amd import synthetic as R
 
 
 def timeit(fn, reps, warm=3):
@@ -43,7 +43,7 @@ def main():
     K, E = R.synthetic_cameras(NS + 1, H, W, 4 * W)
     P = E.clone()
     P[:, :3, :4] = K @ E[:, :3, :4]
-    rt = [R.relative_projection(P[s:s + 1], P[0:1]) for s in range(1, NS + 1)]
+    rt = [ops.relative_projection(P[s:s + 1], P[0:1]) for s in range(1, NS + 1)]
     rot = torch.stack([r for r, _ in rt], 1).to(dev)
     trans = torch.stack([t for _, t in rt], 1).to(dev)
     feats = [F.avg_pool2d(torch.randn(B, C, H, W, generator=g), 3, 1, 1).to(dev).contiguous(memory_format=torch.channels_last)
