@@ -169,6 +169,18 @@ long long mvs_depth_hypo_workspace_doubles(int B, int H, int W);
 int mvs_depth_hypo(const float* ref_depths, const double* mats, int B, int H, int W, double* ws, float* hypos,
                    hipStream_t stream);
 
+/* ---- SURVEY.md 8(f)-3, first cut (not used by default): the feature extractors' 2-D convolutions ---------------------
+ * nn.Conv2d of jdacs/models/module.py:15-22 as used by FeatureNet (jdacs/models/mvsnet.py:17-34): 3x3 stride 1 pad 1 and
+ * 5x5 stride 2 pad 2, 1..32 channels, channels-last images x [N,H,W,Cin], w [Cout][Cin][ks][ks], y [N,Ho,Wo,Cout].
+ * op for the workspace query: 0 forward, 1 input gradient, 2 weight gradient. */
+long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, int Cin, int Cout, int ks, int stride);
+int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
+                   int Cout, int ks, int stride, hipStream_t stream);
+int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                     int stride, hipStream_t stream);
+int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                     int stride, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ SIGNATURES = {
     "mvs_bn_group_relu_bwd": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
+    "mvs_conv2d_workspace_floats": (_ll, [_i] * 8),
+    "mvs_conv2d_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),
     "mvs_depth_hypo": (_i, [_f, _f, _i, _i, _i, _f, _f, _s]),
     "mvs_unsup_loss_workspace_floats": (_ll, [_i, _i, _i, _i]),

@@ -1,0 +1,367 @@
+// SURVEY.md 8(f)-3 (first cut, OFF by default -- see jdacs/models/module.py::ConvBnReLU.hip_conv): the 2-D convolutions
+// of the feature extractors (jdacs/models/mvsnet.py:17-34: 3x3 stride 1 pad 1 and 5x5 stride 2 pad 2, 3/8/16/32
+// channels; jdacs-ms/models/network.py:16-41 uses the same 3x3 shapes) on channels-last images, as fp32 MFMA implicit
+// GEMMs in the style of conv3d.hip.  Not yet measured on the GPU: kernel logic is covered by the CPU emulation tests,
+// tile shapes and staging are the untuned first version.
+//
+//   forward      y[n,oy,ox,co] = sum_{ty,tx,ci} x[n, oy*S + ty - P, ox*S + tx - P, ci] * w[co][ci][ty][tx]   (+ bias)
+//   input grad   stride 1: the same kernel on gy with the weights transposed and flipped;
+//                stride 2: direct form (each input pixel gathers the <= 3x3 taps of its parity class)
+//   weight grad  dW[(ty,tx,ci)][co] = sum_positions x[...] * gy[...]: rows = (tap, ci), columns = co, K = positions;
+//                persistent workgroups, one partial image each, deterministic finish
+#include "mvs_rt.h"
+#include "conv_map.h"   // MVS_HD
+
+struct Conv2dArgs {
+    const float* x;      // [N,Hi,Wi,Cin]
+    const float* wp;     // packed weights [kstep][nb][64][4]
+    const float* bias;   // [Cout] or null
+    float* y;            // [N,Ho,Wo,Cout]
+    int N, Hi, Wi, Ho, Wo, Cin, Cout;
+    int nth, ntw, nb_total;
+};
+
+template <int KS, int S>
+struct Geo2 {
+    static constexpr int TH = 8, TW = 32, P = KS / 2;
+    static constexpr int RH = (TH - 1) * S + KS, RW = (TW - 1) * S + KS, NT = KS * KS;
+};
+
+MVS_HD inline int c2_ksteps(int ntaps, int cc) { return (ntaps * cc + 15) / 16; }
+
+// packed image: lane l, element j of k-step ks, column tile nb holds W[flattened k = 16 ks + 4 (l>>4) + j][co = 16 nb + (l&15)],
+// flattened k -> (tap = k / CC, ci = chunk * CC + k % CC); zero beyond the taps / channels.
+// layout 0: w[co][ci][tap]; layout 1 (input gradient of a stride-1 layer): w[ci'][co'][tap] read as co = ci', ci = co', tap flipped
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
+                                                          int Cin, int Cout, int NB, int transposed, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
+    const int KS = c2_ksteps(NT, CC), chunk = kk / KS, ks = kk % KS;
+    const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = nb * 16 + (lane & 15);
+    float v = 0.f;
+    if (tap < NT && ci < Cin && co < Cout)
+        v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)] : w[((size_t)co * Cin + ci) * NT + tap];
+    wp[idx] = v;
+}
+
+template <int KS, int S, int CC, int NB>
+__global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
+    using G = Geo2<KS, S>;
+    constexpr int CCP = CC + 4, CQ = CC / 4, NR = G::RH * G::RW, KSTEPS = (G::NT * CC + 15) / 16;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ int tapoff[(G::NT + 4 + 3) & ~3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int n = t;
+    const int oy0 = th * G::TH, ox0 = tw * G::TW;
+    const int nb0 = blockIdx.y * NB;
+    for (int i = tid; i < (int)(sizeof(tapoff) / sizeof(int)); i += 256)
+        tapoff[i] = i < G::NT ? ((i / KS) * G::RW + i % KS) * CCP : 0;   // padded k-steps read a valid location (zero weights)
+    // wave -> output rows 2w, 2w+1; m-block mb: row 2w + (mb >> 1), columns 16 (mb & 1) + l15
+    int baseA[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) baseA[mb] = (((2 * wave + (mb >> 1)) * S) * G::RW + (16 * (mb & 1) + l15) * S) * CCP;
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (a.Cin + CC - 1) / CC;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        // halo tile of channels [chunk*CC, +CC): zero outside the image and beyond Cin
+        for (int i = tid; i < NR * CQ; i += 256) {
+            const int px = i / CQ, cq = i % CQ;
+            const int rx = px % G::RW, ry = px / G::RW;
+            const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P, c0 = chunk * CC + 4 * cq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.Cin + c0;
+                if ((a.Cin & 3) == 0 && c0 + 3 < a.Cin) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (c0 < a.Cin) v.x = src[0];
+                    if (c0 + 1 < a.Cin) v.y = src[1];
+                    if (c0 + 2 < a.Cin) v.z = src[2];
+                    if (c0 + 3 < a.Cin) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(&tile[px * CCP + 4 * cq]) = v;
+        }
+        __syncthreads();
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int kflat = 16 * ks + 4 * g;
+            const int aoff = tapoff[kflat / CC] + kflat % CC;
+            float4 bf[NB], af[4];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(chunk * KSTEPS + ks) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bf[nb].x, acc[mb][nb]);
+                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bf[nb].y, acc[mb][nb]);
+                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bf[nb].z, acc[mb][nb]);
+                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bf[nb].w, acc[mb][nb]);
+                }
+        }
+    }
+    // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int oy = oy0 + 2 * wave + (mb >> 1);
+        if (oy >= a.Ho) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ox = ox0 + 16 * (mb & 1) + 4 * g + r;
+            if (ox >= a.Wo) continue;
+            float* __restrict__ o = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = (nb0 + nb) * 16 + l15;
+                if (co < a.Cout) o[co] = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
+            }
+        }
+    }
+}
+
+// input gradient of a stride-2 layer, direct form: gx[n,iy,ix,ci] = sum over the taps (ty,tx) with iy + P - ty and ix + P - tx
+// even and the output position inside the map, and over co, of gy[n,(iy+P-ty)/2,(ix+P-tx)/2,co] * w[co][ci][ty][tx]
+template <int KS>
+__global__ __launch_bounds__(256) void conv2d_dgrad_s2_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                              float* __restrict__ gx, int N, int Hi, int Wi, int Ho, int Wo,
+                                                              int Cin, int Cout) {
+    constexpr int P = KS / 2;
+    const size_t total = (size_t)N * Hi * Wi * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        size_t p = i / Cin;
+        const int ix = (int)(p % Wi); p /= Wi;
+        const int iy = (int)(p % Hi);
+        const int n = (int)(p / Hi);
+        float s = 0.f;
+        for (int ty = (iy + P) & 1; ty < KS; ty += 2) {
+            const int oy = (iy + P - ty) / 2;
+            if (iy + P - ty < 0 || oy >= Ho) continue;
+            for (int tx = (ix + P) & 1; tx < KS; tx += 2) {
+                const int ox = (ix + P - tx) / 2;
+                if (ix + P - tx < 0 || ox >= Wo) continue;
+                const float* __restrict__ g = gy + (((size_t)n * Ho + oy) * Wo + ox) * Cout;
+                const float* __restrict__ wt = w + (size_t)ci * KS * KS + ty * KS + tx;
+                for (int co = 0; co < Cout; ++co) s = fmaf(g[co], wt[(size_t)co * Cin * KS * KS], s);
+            }
+        }
+        gx[i] = s;
+    }
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------------------------------
+struct Wgrad2dArgs {
+    const float* x;     // [N,Hi,Wi,CX]
+    const float* g;     // [N,Ho,Wo,CG]
+    float* part;        // [groups][rows = NT*CXP][CGP]
+    int N, Hi, Wi, Ho, Wo, CX, CG, nth, ntw;
+};
+
+// CXP: CX rounded up to a multiple of 4 (LDS image), MT: m-tiles (16 rows of (tap, cx)) per wave, NB: 16-wide CG tiles
+template <int KS, int S, int CXP, int MT, int NB>
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
+    using G = Geo2<KS, S>;
+    constexpr int NR = G::RH * G::RW, NPOS = G::TH * G::TW, ROWS = G::NT * CXP, CGP = NB * 16;
+    constexpr int XP = CXP + 1;                       // odd pixel stride: the A gather walks (tap, cx) rows
+    __shared__ float xt[NR * XP];
+    __shared__ float gt[NPOS * CGP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l15 = lane & 15;
+    // m-tile m of this wave covers rows 16 (wave + 4 m) .. +15; row -> (tap = row / CXP, cx = row % CXP)
+    int rowoff[MT];
+    bool rowok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = 16 * (wave + 4 * m) + l15;
+        rowok[m] = row < ROWS;
+        const int tap = rowok[m] ? row / CXP : 0, cx = row % CXP;
+        rowoff[m] = ((tap / KS) * G::RW + tap % KS) * XP + cx;
+    }
+    f32x4 acc[MT][NB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ntiles = a.N * a.nth * a.ntw;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw = t % a.ntw; t /= a.ntw;
+        const int th = t % a.nth; t /= a.nth;
+        const int n = t, oy0 = th * G::TH, ox0 = tw * G::TW;
+        __syncthreads();
+        for (int i = tid; i < NR * CXP; i += 256) {
+            const int px = i / CXP, cx = i % CXP, rx = px % G::RW, ry = px / G::RW;
+            const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P;
+            float v = 0.f;
+            if (cx < a.CX && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = a.x[(((size_t)n * a.Hi + iy) * a.Wi + ix) * a.CX + cx];
+            xt[px * XP + cx] = v;
+        }
+        for (int i = tid; i < NPOS * CGP; i += 256) {
+            const int p = i / CGP, co = i % CGP, oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
+            gt[i] = (co < a.CG && oy < a.Ho && ox < a.Wo) ? a.g[(((size_t)n * a.Ho + oy) * a.Wo + ox) * a.CG + co] : 0.f;
+        }
+        __syncthreads();
+        for (int ks = 0; ks < NPOS / 4; ++ks) {
+            const int p = 4 * ks + kq;                                    // this lane's position of the k-step
+            const int posoff = ((p / G::TW) * S * G::RW + (p % G::TW) * S) * XP;
+            float bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = gt[p * CGP + nb * 16 + l15];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float av = rowok[m] ? xt[posoff + rowoff[m]] : 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[m][nb] = MVS_MFMA_16x16x4(av, bv[nb], acc[m][nb]);
+            }
+        }
+    }
+    // D: column = lane & 15 (co), row = 4 (lane >> 4) + r of the m-tile
+    float* __restrict__ out = a.part + (size_t)blockIdx.x * ROWS * CGP;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * (wave + 4 * m) + 4 * kq + r;
+            if (row >= ROWS) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) out[(size_t)row * CGP + nb * 16 + l15] = acc[m][nb][r];
+        }
+}
+
+// gw[co][ci][tap] = sum over the partial images part[p][(tap*CXP + ci)][co]  (fixed order)
+__global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int NT, int CX, int CXP,
+                                                                  int CG, int CGP, float* __restrict__ gw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= CG * CX * NT) return;
+    const int tap = e % NT, ci = (e / NT) % CX, co = e / (NT * CX);
+    const size_t stride = (size_t)NT * CXP * CGP, off = (size_t)(tap * CXP + ci) * CGP + co;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < nparts; p += 4) {
+        s0 += part[(size_t)p * stride + off]; s1 += part[(size_t)(p + 1) * stride + off];
+        s2 += part[(size_t)(p + 2) * stride + off]; s3 += part[(size_t)(p + 3) * stride + off];
+    }
+    for (; p < nparts; ++p) s0 += part[(size_t)p * stride + off];
+    gw[e] = (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static const int C2_WGRAD_GROUPS = 256;
+
+static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
+static int c2_cc(int ks, int cin) { return ks == 5 ? 8 : (cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32))); }
+
+extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, int Cin, int Cout, int ks, int stride) {
+    if (!c2_shape_ok(ks, stride) || Cin < 1 || Cin > 32 || Cout < 1 || Cout > 32) return -1;
+    const int nt = ks * ks;
+    if (op == 2) return (long long)C2_WGRAD_GROUPS * nt * ((Cin + 3) / 4 * 4) * ((Cout + 15) / 16 * 16);
+    const int ci = op == 1 ? Cout : Cin, co = op == 1 ? Cin : Cout;   // the stride-1 input gradient is a forward pass on gy
+    const int cc = c2_cc(ks, ci), nch = (ci + cc - 1) / cc;
+    return (long long)nch * c2_ksteps(nt, cc) * ((co + 15) / 16) * 256;
+}
+
+template <int KS, int S, int CC>
+static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
+    if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1>), grid, dim3(256), 0, st, a);
+    else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2>), grid, dim3(256), 0, st, a);
+}
+
+static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
+                        int Cout, int ks, int stride, int transposed, hipStream_t st) {
+    Conv2dArgs a = {};
+    a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
+    a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
+    a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
+    const int cc = c2_cc(ks, Cin), nt = ks * ks, nch = mvs_cdiv(Cin, cc);
+    a.nb_total = mvs_cdiv(Cout, 16);
+    const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
+    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total);
+    a.wp = ws;
+    const int nb = a.nb_total;   // <= 2 (Cout <= 32)
+    dim3 grid(N * a.nth * a.ntw, 1);
+    if (ks == 5) c2_launch<5, 2, 8>(a, nb, grid, st);
+    else if (cc == 4) c2_launch<3, 1, 4>(a, nb, grid, st);
+    else if (cc == 8) c2_launch<3, 1, 8>(a, nb, grid, st);
+    else if (cc == 16) c2_launch<3, 1, 16>(a, nb, grid, st);
+    else c2_launch<3, 1, 32>(a, nb, grid, st);
+    return mvs_check_launch("conv2d_igemm");
+}
+
+static int c2_check(const char* what, int N, int H, int W, int Cin, int Cout, int ks, int stride) {
+    MVS_REQUIRE(c2_shape_ok(ks, stride), MVS_ERR_UNSUPPORTED, "%s: supports 3x3 stride 1 and 5x5 stride 2, got %dx%d stride %d", what, ks, ks, stride);
+    MVS_REQUIRE(N > 0 && H > 0 && W > 0, MVS_ERR_SHAPE, "%s: bad shape N=%d H=%d W=%d", what, N, H, W);
+    MVS_REQUIRE(Cin >= 1 && Cin <= 32 && Cout >= 1 && Cout <= 32, MVS_ERR_UNSUPPORTED, "%s: channels must be 1..32, got %d -> %d", what, Cin, Cout);
+    return MVS_OK;
+}
+
+// x [N,H,W,Cin] channels-last, w [Cout][Cin][ks][ks], y [N,Ho,Wo,Cout]; pad = ks/2
+extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W,
+                              int Cin, int Cout, int ks, int stride, hipStream_t stream) {
+    int rc = c2_check("conv2d_fwd", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_fwd: null pointer argument");
+    return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
+}
+
+// gx [N,H,W,Cin] from gy [N,Ho,Wo,Cout]
+extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout,
+                                int ks, int stride, hipStream_t stream) {
+    int rc = c2_check("conv2d_dgrad", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv2d_dgrad: null pointer argument");
+    if (stride == 1) return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream);
+    const size_t total = (size_t)N * H * W * Cin;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    MVS_LAUNCH((conv2d_dgrad_s2_kernel<5>), dim3(blocks), dim3(256), 0, stream, gy, w, gx, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cin, Cout);
+    return mvs_check_launch("conv2d_dgrad_s2");
+}
+
+template <int KS, int S, int CXP, int NB>
+static void c2_wgrad_launch(const Wgrad2dArgs& a, int groups, hipStream_t st) {
+    constexpr int MT = (KS * KS * CXP + 63) / 64;
+    MVS_LAUNCH((conv2d_wgrad_kernel<KS, S, CXP, MT, NB>), dim3(groups), dim3(256), 0, st, a);
+}
+
+// gw [Cout][Cin][ks][ks]
+extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout,
+                                int ks, int stride, hipStream_t stream) {
+    int rc = c2_check("conv2d_wgrad", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && gy && gw && ws, MVS_ERR_NULL, "conv2d_wgrad: null pointer argument");
+    Wgrad2dArgs a = {};
+    a.x = x; a.g = gy; a.part = ws; a.N = N; a.Hi = H; a.Wi = W; a.CX = Cin; a.CG = Cout;
+    a.Ho = stride == 1 ? H : (H - 1) / 2 + 1; a.Wo = stride == 1 ? W : (W - 1) / 2 + 1;
+    a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
+    const int ntiles = N * a.nth * a.ntw, groups = ntiles < C2_WGRAD_GROUPS ? ntiles : C2_WGRAD_GROUPS;
+    const int cxp = (Cin + 3) / 4 * 4, nb = mvs_cdiv(Cout, 16);
+    bool ok = true;
+    if (ks == 3) {
+        if (cxp == 4) { if (nb == 1) c2_wgrad_launch<3, 1, 4, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 4, 2>(a, groups, stream); }
+        else if (cxp == 8) { if (nb == 1) c2_wgrad_launch<3, 1, 8, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 8, 2>(a, groups, stream); }
+        else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<3, 1, 16, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 16, 2>(a, groups, stream); }
+        else if (cxp == 32) { if (nb == 1) c2_wgrad_launch<3, 1, 32, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 32, 2>(a, groups, stream); }
+        else ok = false;
+    } else {
+        if (cxp == 8) { if (nb == 1) c2_wgrad_launch<5, 2, 8, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 8, 2>(a, groups, stream); }
+        else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<5, 2, 16, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 16, 2>(a, groups, stream); }
+        else ok = false;
+    }
+    MVS_REQUIRE(ok, MVS_ERR_UNSUPPORTED, "conv2d_wgrad: input channels %d not supported for the %dx%d layer", Cin, ks, ks);
+    rc = mvs_check_launch("conv2d_wgrad");
+    if (rc) return rc;
+    const int nt = ks * ks, n = Cout * Cin * nt;
+    MVS_LAUNCH(conv2d_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, groups, nt, Cin, cxp, Cout, nb * 16, gw);
+    return mvs_check_launch("conv2d_wgrad_reduce");
+}

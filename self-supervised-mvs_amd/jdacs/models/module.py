@@ -5,6 +5,8 @@
   ConvBnReLU3D                                                             (module.py:35-42)
   ConvBnReLU (2-D, FeatureNet/RefineNet: stock PyTorch, not on the hot path; module.py:15-22)
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -15,11 +17,24 @@ from ...nn3d import ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, count_batch  # noq
 ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >= 1.3
 
 
+def conv2d_maybe_hip(conv: nn.Conv2d, x):
+    """nn.Conv2d through csrc/conv2d.hip when it is one of the feature extractors' shapes (3x3 s1 p1 or 5x5 s2 p2, <= 32
+    channels, fp32 on the GPU); the stock module otherwise."""
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    ok = (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and conv.dilation == (1, 1)
+          and conv.in_channels <= 32 and conv.out_channels <= 32
+          and ((k, s, p) == ((3, 3), (1, 1), (1, 1)) or (k, s, p) == ((5, 5), (2, 2), (2, 2))))
+    return ops.Conv2dFn.apply(x, conv.weight, conv.bias, s[0]) if ok else conv(x)
+
+
 class ConvBnReLU(nn.Module):
     """module.py:15-22.  The 2-D convolution stays MIOpen (stock PyTorch); BatchNorm2d + ReLU run through the
     library's BatchNorm kernels when the activation is channels-last on the GPU with C % 4 == 0 (``hip_bn``);
     otherwise (e.g. RefineNet's 1-channel output layer) the stock modules are used."""
     hip_bn = True
+    # SURVEY 8(f)-3, first cut: the convolution itself through csrc/conv2d.hip instead of MIOpen.  Parity-tested (CPU
+    # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
+    hip_conv = os.environ.get("MVS_HIP_FEATURE", "0") == "1"
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -29,7 +44,7 @@ class ConvBnReLU(nn.Module):
     def forward(self, x, groups=1):
         """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one
         after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
-        y = self.conv(x)
+        y = conv2d_maybe_hip(self.conv, x) if self.hip_conv else self.conv(x)
         bn = self.bn
         if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 64
                 and y.is_contiguous(memory_format=torch.channels_last)):

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...nn3d import batched_bn_counters
-from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d
+from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, conv2d_maybe_hip
 
 
 # (name, Cin, Cout, kernel, stride, pad) in registration order == the reference's (same seed => same init)
@@ -36,7 +36,7 @@ class FeatureNet(nn.Module):
         """groups: number of views stacked along the batch dim (per-view BatchNorm statistics are kept)."""
         for name, *_ in _FEATURE_LAYERS:
             x = getattr(self, name)(x, groups)
-        return self.feature(x)
+        return conv2d_maybe_hip(self.feature, x) if ConvBnReLU.hip_conv else self.feature(x)
 
 
 class CostRegNet(nn.Module):

@@ -547,3 +547,76 @@ def depth_hypotheses(ref_depths: torch.Tensor, mats: torch.Tensor) -> torch.Tens
     hypos = torch.empty((b, 8, h, w), dtype=torch.float32, device=ref_depths.device)
     lib.call("mvs_depth_hypo", _p(ref_depths), _p(mats), b, h, w, _p(ws), _p(hypos), _stream(ref_depths))
     return hypos
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8(f)-3, first cut (not used by default): the feature extractors' 2-D convolutions
+# ------------------------------------------------------------------------------------------------
+def _c2_ws(lib, op, n, h, w, cin, cout, ks, stride, like):
+    nfl = lib.raw("mvs_conv2d_workspace_floats", op, n, h, w, cin, cout, ks, stride)
+    if nfl < 0:
+        raise ValueError("conv2d: unsupported shape (3x3 stride 1 or 5x5 stride 2, 1..32 channels): Cin=%d Cout=%d k=%d s=%d"
+                         % (cin, cout, ks, stride))
+    return torch.empty(nfl, dtype=torch.float32, device=like.device)
+
+
+def conv2d_forward(x, weight, bias=None, stride=1):
+    """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last)."""
+    lib = _lib_for(x)
+    x = as_cl2(x)
+    n, cin, h, w = x.shape
+    cout, cin_w, ks, ks2 = weight.shape
+    if cin_w != cin or ks != ks2:
+        raise ValueError("weight shape %s does not match %d input channels" % (tuple(weight.shape), cin))
+    ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x)
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=CL2)
+    lib.call("mvs_conv2d_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
+             n, h, w, cin, cout, ks, stride, _stream(x), tag="fwd2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+    return y
+
+
+def conv2d_dgrad(gy, weight, in_shape, stride=1):
+    lib = _lib_for(gy)
+    gy = as_cl2(gy)
+    n, cin, h, w = in_shape
+    cout, _, ks, _ = weight.shape
+    ws = _c2_ws(lib, 1, n, h, w, cin, cout, ks, stride, gy)
+    gx = torch.empty((n, cin, h, w), dtype=torch.float32, device=gy.device, memory_format=CL2)
+    lib.call("mvs_conv2d_dgrad", _p(gy), _p(weight.contiguous()), _p(gx), _p(ws), n, h, w, cin, cout, ks, stride, _stream(gy),
+             tag="dgrad2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+    return gx
+
+
+def conv2d_wgrad(x, gy, weight_shape, stride=1):
+    lib = _lib_for(x)
+    x, gy = as_cl2(x), as_cl2(gy)
+    n, cin, h, w = x.shape
+    cout, _, ks, _ = weight_shape
+    ws = _c2_ws(lib, 2, n, h, w, cin, cout, ks, stride, x)
+    gw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
+    lib.call("mvs_conv2d_wgrad", _p(x), _p(gy), _p(gw), _p(ws), n, h, w, cin, cout, ks, stride, _stream(x),
+             tag="wgrad2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+    return gw
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (k3 s1 p1 | k5 s2 p2, optional bias) on channels-last activations through csrc/conv2d.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        x = as_cl2(x)
+        y = conv2d_forward(x, weight, bias, stride)
+        ctx.save_for_backward(x, weight)
+        ctx.stride = stride
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = as_cl2(gy)
+        gx = conv2d_dgrad(gy, weight, tuple(x.shape), ctx.stride) if ctx.needs_input_grad[0] else None
+        gw = conv2d_wgrad(x, gy, tuple(weight.shape), ctx.stride) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None

@@ -472,3 +472,54 @@ def test_jdacs_self_supervised_step_end_to_end(emul_lib):
             assert rel_l1(pa[k].grad, pb[k].grad) < 2e-2, k
             checked += 1
     assert checked >= 3
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (11, 37)), (8, 8, 3, 1, (8, 32)), (8, 16, 5, 2, (18, 70)),
+                                                    (16, 16, 3, 1, (9, 33)), (16, 32, 5, 2, (17, 41)), (32, 32, 3, 1, (10, 20))])
+def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
+    """SURVEY 8(f)-3 first cut: every 2-D convolution shape of FeatureNet (mvsnet.py:17-34) -- forward (+ bias), input and
+    weight gradient -- vs ATen, on ragged image sizes."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 3 + cout + ks)
+    x = torch.randn(2, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.Conv2dFn.apply(xa, wa, ba, stride)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y - yr).abs().max()) < 2e-4
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    y.backward(gy)
+    assert float((xa.grad - xr.grad).abs().max()) < 3e-4
+    assert float((wa.grad - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+    assert float((ba.grad - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
+    y2 = ops.conv2d_forward(x, w, None, stride)
+    assert float((y2 - F.conv2d(x, w, None, stride=stride, padding=ks // 2)).abs().max()) < 2e-4
+
+
+def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
+    """FeatureNet (mvsnet.py:17-34) with its convolutions through csrc/conv2d.hip (ConvBnReLU.hip_conv) vs the stock path:
+    three views batched with per-view BatchNorm statistics, forward + parameter gradients."""
+    import copy
+    from mvs_amd.jdacs.models import module as MM
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(2)
+    a = FeatureNet().train()
+    b = copy.deepcopy(a).train()
+    x = torch.randn(3, 3, 24, 40)
+    monkeypatch.setattr(MM.ConvBnReLU, "hip_conv", False)
+    yb = b(x, 3)
+    yb.square().mean().backward()
+    monkeypatch.setattr(MM.ConvBnReLU, "hip_conv", True)
+    monkeypatch.setattr(MM, "conv2d_maybe_hip", lambda conv, t: __import__("mvs_amd").ops.Conv2dFn.apply(t, conv.weight, conv.bias, conv.stride[0]))
+    import mvs_amd.jdacs.models.mvsnet as MV
+    monkeypatch.setattr(MV, "conv2d_maybe_hip", MM.conv2d_maybe_hip)
+    ya = a(x, 3)
+    ya.square().mean().backward()
+    assert ya.shape == (3, 32, 6, 10)
+    assert float((ya - yb).abs().max()) < 1e-3
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_l1(p.grad, q.grad) < 2e-2, k

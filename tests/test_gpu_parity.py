@@ -557,3 +557,50 @@ def test_config3_self_supervised_step_vs_gpu_oracle(dev):
         cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30))
         assert cos > 0.98, (k, cos)
         assert 0.8 < float(ga.norm() / (gb.norm() + 1e-30)) < 1.25, k
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (75, 101)), (8, 8, 3, 1, (64, 96)), (8, 16, 5, 2, (66, 130)),
+                                                    (16, 16, 3, 1, (33, 65)), (16, 32, 5, 2, (41, 77)), (32, 32, 3, 1, (32, 40))])
+def test_conv2d_family_vs_torch(dev, cin, cout, ks, stride, hw):
+    """SURVEY 8(f)-3 first cut (off by default): the feature extractors' 2-D convolution shapes through csrc/conv2d.hip vs
+    ATen on the CPU: forward (+ bias), input gradient, weight gradient, ragged sizes, batch 3."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 3 + cout + ks)
+    x = torch.randn(3, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xa, wa, ba = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.Conv2dFn.apply(xa, wa, ba, stride)
+    y.backward(gy.to(dev))
+    assert float((y.cpu() - yr).abs().max()) < 3e-4
+    assert float((xa.grad.cpu() - xr.grad).abs().max()) < 5e-4
+    assert float((wa.grad.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+    assert float((ba.grad.cpu() - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
+
+
+def test_featurenet_hip_convs_vs_stock(dev):
+    """FeatureNet with ConvBnReLU.hip_conv (csrc/conv2d.hip) vs the stock MIOpen convolutions: 3 views, 128x160."""
+    import copy
+    from mvs_amd.jdacs.models import module as MM
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(2)
+    a = FeatureNet().to(dev).train()
+    b = copy.deepcopy(a).train()
+    x = torch.randn(3, 3, 128, 160, device=dev)
+    old = MM.ConvBnReLU.hip_conv
+    try:
+        MM.ConvBnReLU.hip_conv = False
+        yb = b(x, 3)
+        yb.square().mean().backward()
+        MM.ConvBnReLU.hip_conv = True
+        ya = a(x, 3)
+        ya.square().mean().backward()
+    finally:
+        MM.ConvBnReLU.hip_conv = old
+    assert float((ya - yb).abs().max()) < 2e-3
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_l1(p.grad, q.grad) < 3e-2, k
