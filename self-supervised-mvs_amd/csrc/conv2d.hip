@@ -72,43 +72,71 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     const int nchunks = (a.Cin + CC - 1) / CC;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();
-        // halo tile of channels [chunk*CC, +CC): zero outside the image and beyond Cin
-        for (int i = tid; i < NR * CQ; i += 256) {
-            const int px = i / CQ, cq = i % CQ;
-            const int rx = px % G::RW, ry = px / G::RW;
-            const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P, c0 = chunk * CC + 4 * cq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.Cin + c0;
-                if ((a.Cin & 3) == 0 && c0 + 3 < a.Cin) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    if (c0 < a.Cin) v.x = src[0];
-                    if (c0 + 1 < a.Cin) v.y = src[1];
-                    if (c0 + 2 < a.Cin) v.z = src[2];
-                    if (c0 + 3 < a.Cin) v.w = src[3];
+        // halo tile of channels [chunk*CC, +CC): zero outside the image and beyond Cin.  All loads of a batch are issued
+        // before the first LDS write (a load -> store loop serialises one memory round trip per iteration).
+        constexpr int NIT = (NR * CQ + 255) / 256, BATCH = NIT < 12 ? NIT : 12;
+#pragma unroll
+        for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+            float4 v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int i = tid + 256 * (k0 + k);
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < NIT && i < NR * CQ) {
+                    const int px = i / CQ, cq = i % CQ;
+                    const int rx = px % G::RW, ry = px / G::RW;
+                    const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P, c0 = chunk * CC + 4 * cq;
+                    if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                        const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.Cin + c0;
+                        if ((a.Cin & 3) == 0 && c0 + 3 < a.Cin) v[k] = *reinterpret_cast<const float4*>(src);
+                        else {
+                            if (c0 < a.Cin) v[k].x = src[0];
+                            if (c0 + 1 < a.Cin) v[k].y = src[1];
+                            if (c0 + 2 < a.Cin) v[k].z = src[2];
+                            if (c0 + 3 < a.Cin) v[k].w = src[3];
+                        }
+                    }
                 }
             }
-            *reinterpret_cast<float4*>(&tile[px * CCP + 4 * cq]) = v;
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int i = tid + 256 * (k0 + k);
+                if (k0 + k < NIT && i < NR * CQ) *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = v[k];
+            }
         }
         __syncthreads();
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int kflat = 16 * ks + 4 * g;
-            const int aoff = tapoff[kflat / CC] + kflat % CC;
-            float4 bf[NB], af[4];
+        // weight fragments (global / L2) run two k-steps ahead of the MFMAs that consume them
+        float4 bq[2][NB];
+        auto load_b = [&](int ks, float4 (&dst)[NB]) {
+            const int kc = ks < KSTEPS ? ks : KSTEPS - 1;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                bf[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(chunk * KSTEPS + ks) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+                dst[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(chunk * KSTEPS + kc) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+        };
+        load_b(0, bq[0]);
+        load_b(1, bq[1]);
+        for (int ks0 = 0; ks0 < KSTEPS; ks0 += 2) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+            for (int u = 0; u < 2; ++u) {
+                const int ks = ks0 + u;
+                if (ks < KSTEPS) {
+                    const int kflat = 16 * ks + 4 * g;
+                    const int aoff = tapoff[kflat / CC] + kflat % CC;
+                    float4 af[4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+                    for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bf[nb].x, acc[mb][nb]);
-                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bf[nb].y, acc[mb][nb]);
-                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bf[nb].z, acc[mb][nb]);
-                    acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bf[nb].w, acc[mb][nb]);
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bq[u][nb].y, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bq[u][nb].z, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bq[u][nb].w, acc[mb][nb]);
+                        }
+                    load_b(ks + 2, bq[u]);
                 }
+            }
         }
     }
     // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
@@ -199,12 +227,40 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
         const int th = t % a.nth; t /= a.nth;
         const int n = t, oy0 = th * G::TH, ox0 = tw * G::TW;
         __syncthreads();
-        for (int i = tid; i < NR * CXP; i += 256) {
-            const int px = i / CXP, cx = i % CXP, rx = px % G::RW, ry = px / G::RW;
-            const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P;
-            float v = 0.f;
-            if (cx < a.CX && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) v = a.x[(((size_t)n * a.Hi + iy) * a.Wi + ix) * a.CX + cx];
-            xt[px * XP + cx] = v;
+        {   // X halo tile: float4 loads (CX % 4 == 0) issued in batches before the LDS writes; odd pixel stride -> scalar writes
+            constexpr int XQ = CXP / 4, NIT = (NR * XQ + 255) / 256, BATCH = NIT < 10 ? NIT : 10;
+            const bool vec = (a.CX & 3) == 0;
+#pragma unroll 1
+            for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+                float4 v[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int i = tid + 256 * (k0 + k);
+                    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + k < NIT && i < NR * XQ) {
+                        const int px = i / XQ, c0 = 4 * (i % XQ), rx = px % G::RW, ry = px / G::RW;
+                        const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P;
+                        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                            const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.CX + c0;
+                            if (vec) v[k] = *reinterpret_cast<const float4*>(src);
+                            else {
+                                if (c0 < a.CX) v[k].x = src[0];
+                                if (c0 + 1 < a.CX) v[k].y = src[1];
+                                if (c0 + 2 < a.CX) v[k].z = src[2];
+                                if (c0 + 3 < a.CX) v[k].w = src[3];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int i = tid + 256 * (k0 + k);
+                    if (k0 + k < NIT && i < NR * XQ) {
+                        float* __restrict__ d = &xt[(i / XQ) * XP + 4 * (i % XQ)];
+                        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+                    }
+                }
+            }
         }
         for (int i = tid; i < NPOS * CGP; i += 256) {
             const int p = i / CGP, co = i % CGP, oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
