@@ -481,7 +481,7 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
     weight gradient -- vs ATen, on ragged image sizes."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin * 3 + cout + ks)
-    x = torch.randn(2, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(1 if ks == 5 else 2, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
     b = torch.randn(cout, generator=g)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
@@ -509,7 +509,7 @@ def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
     torch.manual_seed(2)
     a = FeatureNet().train()
     b = copy.deepcopy(a).train()
-    x = torch.randn(3, 3, 24, 40)
+    x = torch.randn(3, 3, 16, 24)
     monkeypatch.setattr(MM.ConvBnReLU, "hip_conv", False)
     yb = b(x, 3)
     yb.square().mean().backward()
@@ -519,7 +519,7 @@ def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
     monkeypatch.setattr(MV, "conv2d_maybe_hip", MM.conv2d_maybe_hip)
     ya = a(x, 3)
     ya.square().mean().backward()
-    assert ya.shape == (3, 32, 6, 10)
+    assert ya.shape == (3, 32, 4, 6)
     assert float((ya - yb).abs().max()) < 1e-3
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert rel_l1(p.grad, q.grad) < 2e-2, k
