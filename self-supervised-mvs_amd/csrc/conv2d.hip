@@ -17,8 +17,9 @@ struct Conv2dArgs {
     const float* wp;     // packed weights [kstep][nb][64][4]
     const float* bias;   // [Cout] or null
     float* y;            // [N,Ho,Wo,Cout]
-    int N, Hi, Wi, Ho, Wo, Cin, Cout;
+    int N, Hi, Wi, Ho, Wo, Cin, Cout;   // Ho x Wo: the grid the tiles walk (== the output map for a forward pass)
     int nth, ntw, nb_total;
+    int os, py, px, YH, YW;             // output pixel of grid point (oy,ox) is (oy*os + py, ox*os + px) of a YH x YW map
 };
 
 template <int KS, int S>
@@ -32,16 +33,29 @@ MVS_HD inline int c2_ksteps(int ntaps, int cc) { return (ntaps * cc + 15) / 16; 
 // packed image: lane l, element j of k-step ks, column tile nb holds W[flattened k = 16 ks + 4 (l>>4) + j][co = 16 nb + (l&15)],
 // flattened k -> (tap = k / CC, ci = chunk * CC + k % CC); zero beyond the taps / channels.
 // layout 0: w[co][ci][tap]; layout 1 (input gradient of a stride-1 layer): w[ci'][co'][tap] read as co = ci', ci = co', tap flipped
+// cls >= 0 (input gradient of the 5x5 stride-2 layer, parity class cls = 2 py + px): a 3x3 stride-1 kernel over gy whose tap
+// (ty', tx') is the original tap (ty, tx) with ty = 2 (2 - ty') + py - ... see c2_s2_tap; w is [co'][ci'][5][5] read transposed.
+MVS_HD inline int c2_s2_tap(int tp, int par) {   // tp in 0..2 = offset -1, 0, +1 on the coarse grid; -> original tap or -1
+    // iy = 2 q + par, oy = (iy + 2 - t) / 2 = q + off  =>  t = par + 2 - 2 off, off = tp - 1
+    const int t = par + 2 - 2 * (tp - 1);
+    return (t >= 0 && t < 5) ? t : -1;
+}
 __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
-                                                          int Cin, int Cout, int NB, int transposed, int total) {
+                                                          int Cin, int Cout, int NB, int transposed, int total, int cls) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
     const int KS = c2_ksteps(NT, CC), chunk = kk / KS, ks = kk % KS;
     const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = nb * 16 + (lane & 15);
     float v = 0.f;
-    if (tap < NT && ci < Cin && co < Cout)
-        v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)] : w[((size_t)co * Cin + ci) * NT + tap];
+    if (tap < NT && ci < Cin && co < Cout) {
+        if (cls >= 0) {
+            const int ty = c2_s2_tap(tap / 3, cls >> 1), tx = c2_s2_tap(tap % 3, cls & 1);
+            if (ty >= 0 && tx >= 0) v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
+        } else {
+            v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)] : w[((size_t)co * Cin + ci) * NT + tap];
+        }
+    }
     wp[idx] = v;
 }
 
@@ -142,13 +156,13 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        const int oy = oy0 + 2 * wave + (mb >> 1);
-        if (oy >= a.Ho) continue;
+        const int oy = (oy0 + 2 * wave + (mb >> 1)) * a.os + a.py;
+        if (oy >= a.YH) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ox = ox0 + 16 * (mb & 1) + 4 * g + r;
-            if (ox >= a.Wo) continue;
-            float* __restrict__ o = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+            const int ox = (ox0 + 16 * (mb & 1) + 4 * g + r) * a.os + a.px;
+            if (ox >= a.YW) continue;
+            float* __restrict__ o = a.y + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = (nb0 + nb) * 16 + l15;
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 // host side
 // ------------------------------------------------------------------------------------------------
 static const int C2_WGRAD_GROUPS = 256;
+int g_conv2d_s2_mfma = 1;   // tuning knob "2": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
 static int c2_cc(int ks, int cin) { return ks == 5 ? 8 : (cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32))); }
@@ -323,7 +338,11 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
     if (!c2_shape_ok(ks, stride) || Cin < 1 || Cin > 32 || Cout < 1 || Cout > 32) return -1;
     const int nt = ks * ks;
     if (op == 2) return (long long)C2_WGRAD_GROUPS * nt * ((Cin + 3) / 4 * 4) * ((Cout + 15) / 16 * 16);
-    const int ci = op == 1 ? Cout : Cin, co = op == 1 ? Cin : Cout;   // the stride-1 input gradient is a forward pass on gy
+    const int ci = op == 1 ? Cout : Cin, co = op == 1 ? Cin : Cout;   // an input gradient is a forward-style pass on gy
+    if (op == 1 && stride == 2) {                                      // four parity-class 3x3 weight images
+        const int cc3 = c2_cc(3, ci);
+        return 4LL * ((ci + cc3 - 1) / cc3) * c2_ksteps(9, cc3) * ((co + 15) / 16) * 256;
+    }
     const int cc = c2_cc(ks, ci), nch = (ci + cc - 1) / cc;
     return (long long)nch * c2_ksteps(nt, cc) * ((co + 15) / 16) * 256;
 }
@@ -339,11 +358,12 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
     Conv2dArgs a = {};
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
+    a.os = 1; a.py = 0; a.px = 0; a.YH = a.Ho; a.YW = a.Wo;
     a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
     const int cc = c2_cc(ks, Cin), nt = ks * ks, nch = mvs_cdiv(Cin, cc);
     a.nb_total = mvs_cdiv(Cout, 16);
     const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
-    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total);
+    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1);
     a.wp = ws;
     const int nb = a.nb_total;   // <= 2 (Cout <= 32)
     dim3 grid(N * a.nth * a.ntw, 1);
@@ -378,6 +398,29 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
     if (rc) return rc;
     MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv2d_dgrad: null pointer argument");
     if (stride == 1) return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream);
+    if (g_conv2d_s2_mfma) {
+        // four parity classes, each a 3x3 stride-1 pass over gy on the coarse grid with its own (partly empty) weight image
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        const int cc = c2_cc(3, Cout), nch = mvs_cdiv(Cout, cc), nbt = mvs_cdiv(Cin, 16);
+        const int total_w = nch * c2_ksteps(9, cc) * nbt * 256;
+        for (int cls = 0; cls < 4; ++cls) {
+            Conv2dArgs a = {};
+            a.x = gy; a.bias = nullptr; a.y = gx; a.N = N; a.Hi = Ho; a.Wi = Wo; a.Cin = Cout; a.Cout = Cin;
+            a.os = 2; a.py = cls >> 1; a.px = cls & 1; a.YH = H; a.YW = W;
+            a.Ho = mvs_cdiv(H - a.py, 2); a.Wo = mvs_cdiv(W - a.px, 2);          // grid points of this class
+            if (a.Ho <= 0 || a.Wo <= 0) continue;
+            a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32); a.nb_total = nbt;
+            float* wpc = ws + (size_t)cls * total_w;
+            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls);
+            a.wp = wpc;
+            dim3 grid(N * a.nth * a.ntw, 1);
+            if (cc == 8) c2_launch<3, 1, 8>(a, nbt, grid, stream);
+            else if (cc == 16) c2_launch<3, 1, 16>(a, nbt, grid, stream);
+            else if (cc == 32) c2_launch<3, 1, 32>(a, nbt, grid, stream);
+            else c2_launch<3, 1, 4>(a, nbt, grid, stream);
+        }
+        return mvs_check_launch("conv2d_dgrad_s2_classes");
+    }
     const size_t total = (size_t)N * H * W * Cin;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     MVS_LAUNCH((conv2d_dgrad_s2_kernel<5>), dim3(blocks), dim3(256), 0, stream, gy, w, gx, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cin, Cout);

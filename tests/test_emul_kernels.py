@@ -498,6 +498,13 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
     assert float((ba.grad - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
     y2 = ops.conv2d_forward(x, w, None, stride)
     assert float((y2 - F.conv2d(x, w, None, stride=stride, padding=ks // 2)).abs().max()) < 2e-4
+    if stride == 2:   # the direct form of the stride-2 input gradient (tuning knob "2" = 0) agrees with the parity-class MFMA passes
+        emul_lib.call("mvs_set_tuning", b"2", 0)
+        try:
+            gx = ops.conv2d_dgrad(gy, w, tuple(x.shape), 2)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"2", 1)
+        assert float((gx - xr.grad).abs().max()) < 3e-4
 
 
 def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
