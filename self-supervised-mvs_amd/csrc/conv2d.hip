@@ -6,7 +6,8 @@
 //
 //   forward      y[n,oy,ox,co] = sum_{ty,tx,ci} x[n, oy*S + ty - P, ox*S + tx - P, ci] * w[co][ci][ty][tx]   (+ bias)
 //   input grad   stride 1: the same kernel on gy with the weights transposed and flipped;
-//                stride 2: direct form (each input pixel gathers the <= 3x3 taps of its parity class)
+//                stride 2: four output-parity classes, each a 3x3 stride-1 pass over gy on the coarse grid with its
+//                own (partly empty) weight image; a direct VALU form is kept behind mvs_set_tuning("2", 0)
 //   weight grad  dW[(ty,tx,ci)][co] = sum_positions x[...] * gy[...]: rows = (tap, ci), columns = co, K = positions;
 //                persistent workgroups, one partial image each, deterministic finish
 #include "mvs_rt.h"
