@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static const int C2_WGRAD_GROUPS = 256;
+static const int C2_WGRAD_GROUPS = 256;   // partial images the workspace holds
+int g_conv2d_wgrad_groups = 256;          // tuning knob "g" (<= 256): persistent workgroups of the weight gradient
 int g_conv2d_s2_mfma = 1;   // tuning knob "2": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
@@ -444,7 +445,8 @@ extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, floa
     a.x = x; a.g = gy; a.part = ws; a.N = N; a.Hi = H; a.Wi = W; a.CX = Cin; a.CG = Cout;
     a.Ho = stride == 1 ? H : (H - 1) / 2 + 1; a.Wo = stride == 1 ? W : (W - 1) / 2 + 1;
     a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
-    const int ntiles = N * a.nth * a.ntw, groups = ntiles < C2_WGRAD_GROUPS ? ntiles : C2_WGRAD_GROUPS;
+    const int gmax = g_conv2d_wgrad_groups < 1 ? 1 : (g_conv2d_wgrad_groups > C2_WGRAD_GROUPS ? C2_WGRAD_GROUPS : g_conv2d_wgrad_groups);
+    const int ntiles = N * a.nth * a.ntw, groups = ntiles < gmax ? ntiles : gmax;
     const int cxp = (Cin + 3) / 4 * 4, nb = mvs_cdiv(Cout, 16);
     bool ok = true;
     if (ks == 3) {

@@ -735,12 +735,14 @@ extern int g_conv_split;
 extern int g_conv_c8;
 extern int g_conv_xcd;
 extern int g_conv2d_s2_mfma;
+extern int g_conv2d_wgrad_groups;
 extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
     if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value; return MVS_OK; }
+    if (key && key[0] == 'g') { g_conv2d_wgrad_groups = value; return MVS_OK; }
     if (key && key[0] == '2') { g_conv2d_s2_mfma = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }

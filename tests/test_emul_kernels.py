@@ -530,3 +530,20 @@ def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
     assert float((ya - yb).abs().max()) < 1e-3
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert rel_l1(p.grad, q.grad) < 2e-2, k
+
+
+def test_conv2d_wgrad_persistent_workgroups_walk_several_tiles(emul_lib):
+    """The weight gradient's persistent workgroups accumulate over several tiles (forced here with 3 workgroups for 12 tiles;
+    at FeatureNet sizes there are thousands of tiles for 256 workgroups)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 8, 20, 70, generator=g).contiguous(memory_format=torch.channels_last)   # 3 x 3 tiles per image
+    gy = torch.randn(2, 16, 20, 70, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(16, 8, 3, 3, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(gy)
+    emul_lib.call("mvs_set_tuning", b"g", 3)
+    try:
+        gw = ops.conv2d_wgrad(x, gy, (16, 8, 3, 3), 1)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"g", 256)
+    assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
