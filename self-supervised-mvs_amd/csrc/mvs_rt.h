@@ -17,6 +17,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #define MVS_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define MVS_RCP(x) __builtin_amdgcn_rcpf(x)
+// value of quad lane s (0..3) broadcast to the 4 lanes of its quad: one DPP move (quad_perm [s,s,s,s]); the control word is
+// an immediate, so s must be known after unrolling (the switch folds)
+static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
+    switch (s) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false);
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);
+    }
+}
+#define MVS_QUAD_BCAST_I(v, s) mvs_quad_bcast_i((v), (s))
+#define MVS_QUAD_BCAST_F(v, s) __int_as_float(mvs_quad_bcast_i(__float_as_int(v), (s)))
 #define MVS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget 512 / n per wave
 #define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating

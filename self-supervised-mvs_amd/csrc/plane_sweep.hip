@@ -197,16 +197,27 @@ template <int C, int CPT> struct TileC {
     static constexpr int LPP = C / CPT, PPB = 256 / LPP, TW = PPB >= 128 ? 16 : 8, TH = PPB / TW;
 };
 
-template <int C, int NS_T, int CPT>
+// QS (quad-shared coordinates; C == 32, CPT == 8 -> the 4 lanes of a quad are the 4 channel groups of ONE pixel, NS_T in
+// {2, 4}): the per-plane projection of source view s (homography, reciprocal, floor, fractions) is the same for the four
+// lanes, so lane q computes only view q % NS_T and the others fetch (wx, wy, x0, y0) with quad-broadcast DPP moves
+// instead of recomputing them: ~20 (NS_T = 2) / ~70 (NS_T = 4) fewer VALU instructions per plane in a kernel whose VALU
+// is busy 73 % of the time.  Bit-identical results.  Variant 6 of the "sweep_fwd" knob; not yet measured on the GPU.
+template <int C, int NS_T, int CPT, bool QS = false>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     constexpr int V = CPT / 4;                     // float4s per tap per thread
+    static_assert(!QS || (C == 32 && CPT == 8 && (NS_T == 2 || NS_T == 4)), "quad sharing needs 4 lanes per pixel");
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
     const int TW = a.tile_w, TH = PPB / TW;
     const int tid = threadIdx.x;
     const int q = tid % LPP, pl = tid / LPP;
-    const int x = (blockIdx.x % a.tiles_x) * TW + pl % TW, y = (blockIdx.x / a.tiles_x) * TH + pl / TW;
+    const int xr = (blockIdx.x % a.tiles_x) * TW + pl % TW, yr = (blockIdx.x / a.tiles_x) * TH + pl / TW;
     const int b = blockIdx.z;
-    if (x >= a.W || y >= a.H) return;  // no barriers / cross-lane ops below
+    if (!QS) {
+        if (xr >= a.W || yr >= a.H) return;  // no barriers / cross-lane ops below
+    }
+    // QS: quad exchanges below -> out-of-image lanes follow along on pixel 0 and store nothing
+    const bool live = !QS || (xr < a.W && yr < a.H);
+    const int x = live ? xr : 0, y = live ? yr : 0;
     const int HW = a.H * a.W, pix = y * a.W + x;
     const int d0 = blockIdx.y * a.dslab;
     const int d1 = min(a.D, d0 + a.dslab);
@@ -235,11 +246,12 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
-        const float* R = rotb + s * 9;
+        const int sv = QS ? (s == 0 ? q % NS_T : 0) : s;   // QS: slot 0 holds the lane's own view, the other slots are unused
+        const float* R = rotb + sv * 9;
         rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
         ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
         rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
-        tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
+        tx[s] = trb[sv * 3]; ty[s] = trb[sv * 3 + 1]; tz[s] = trb[sv * 3 + 2];
         cx[s] = -0x40000000; cy[s] = -0x40000000;
 #pragma unroll
         for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -250,19 +262,40 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         float4 S[V], Q[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
+        // QS: this lane's own view (index 0 of the per-lane arrays), computed once per plane
+        float own_wx = 0.f, own_wy = 0.f;
+        int own_x0 = 0, own_y0 = 0;
+        if (QS) {
+            const float zz = fmaf(rz[0], dep, tz[0]);
+            float iz = MVS_RCP(zz);
+            iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
+            const float ix = fmaf(fmaf(rx[0], dep, tx[0]) * iz, a.sx, a.ox);
+            const float iy = fmaf(fmaf(ry[0], dep, ty[0]) * iz, a.sy, a.oy);
+            const float fx = floorf(ix), fy = floorf(iy);
+            own_wx = ix - fx; own_wy = iy - fy;
+            own_x0 = MVS_F2I(fx); own_y0 = MVS_F2I(fy);
+        }
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
-            const float zz = fmaf(rz[s], dep, tz[s]);
-            float iz = MVS_RCP(zz);                 // v_rcp_f32 (1 ulp) + one Newton step: < 1 ulp, 3 instructions
-            iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz); // instead of the ~10 of an IEEE division
-            const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
-            const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
-            const float fx = floorf(ix), fy = floorf(iy);
-            const float wx = ix - fx, wy = iy - fy;
+            float wx, wy;
+            int x0, y0;
+            if (QS) {
+                // view s was computed by quad lane s (NS_T == 2: lanes 0/1; lanes 2/3 computed the same pair again)
+                wx = MVS_QUAD_BCAST_F(own_wx, s); wy = MVS_QUAD_BCAST_F(own_wy, s);
+                x0 = MVS_QUAD_BCAST_I(own_x0, s); y0 = MVS_QUAD_BCAST_I(own_y0, s);
+            } else {
+                const float zz = fmaf(rz[s], dep, tz[s]);
+                float iz = MVS_RCP(zz);                 // v_rcp_f32 (1 ulp) + one Newton step: < 1 ulp, 3 instructions
+                iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz); // instead of the ~10 of an IEEE division
+                const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
+                const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
+                const float fx = floorf(ix), fy = floorf(iy);
+                wx = ix - fx; wy = iy - fy;
+                // v_cvt_i32_f32 saturates (huge -> INT_MAX/INT_MIN: every tap outside the image; NaN -> 0 with NaN
+                // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
+                x0 = MVS_F2I(fx); y0 = MVS_F2I(fy);
+            }
             const float ex = 1.0f - wx, ey = 1.0f - wy;
-            // v_cvt_i32_f32 saturates (huge -> INT_MAX/INT_MIN: every tap outside the image; NaN -> 0 with NaN
-            // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
-            const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
             if (x0 != cx[s] || y0 != cy[s]) {
                 cx[s] = x0; cy[s] = y0;
                 const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
@@ -299,6 +332,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
             m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
             m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
+            if (QS && !live) continue;
             if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
             else *reinterpret_cast<float4*>(outp + ck * k) = o;
         }
@@ -745,7 +779,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'g') { g_conv2d_wgrad_groups = value; return MVS_OK; }
     if (key && key[0] == '2') { g_conv2d_s2_mfma = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return MVS_OK; }
+    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 6 ? 6 : value); return MVS_OK; }
     mvs_set_error("mvs_set_tuning: unknown key");
     return MVS_ERR_UNSUPPORTED;
 }
@@ -782,6 +816,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
+        else if (c8 && variant == 6 && C == 32 && (N == 2 || N == 4))                                            \
+            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, (N == 2 || N == 4) ? N : 2, CPT8, (C == 32 && (N == 2 || N == 4))>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;

@@ -118,6 +118,15 @@ static inline f32x4 emul_mfma_4x4x1_bc(float a, float b, f32x4 c, int abid) {
     for (int r = 0; r < 4; ++r) c[r] = fmaf(w->fa[s][abid * 4 + r], w->fb[s][l], c[r]);
     return c;
 }
+static inline int __shfl(int v, int src, int width = 64) {
+    float f;
+    memcpy(&f, &v, 4);
+    f = __shfl(f, src, width);
+    memcpy(&v, &f, 4);
+    return v;
+}
+#define MVS_QUAD_BCAST_I(v, s) __shfl((int)(v), (emul::lane & ~3) | (s))
+#define MVS_QUAD_BCAST_F(v, s) __shfl((float)(v), (emul::lane & ~3) | (s))
 #define MVS_SCHED_FENCE() ((void)0)
 #define MVS_WAVES_PER_SIMD(n)
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) emul_mfma_4x4x1_bc((a), (b), (c), (abid))

@@ -222,9 +222,10 @@ def test_plane_sweep_bwd_segmented_windows(emul_lib):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):
-    """All forward variants (taps through L1, LDS windows, register-cached 4/8/16 channels per thread)."""
+    """All forward variants (taps through L1, LDS windows, register-cached 4/8/16 channels per thread, 6 = cached8 with the
+    per-view projection shared across the 4 lanes of a pixel through quad broadcasts)."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(17)
     b, c, d, h, w, ns = 1, 32, 20, 16, 24, 2
@@ -547,3 +548,28 @@ def test_conv2d_wgrad_persistent_workgroups_walk_several_tiles(emul_lib):
     finally:
         emul_lib.call("mvs_set_tuning", b"g", 256)
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("ns,hw", [(2, (13, 21)), (4, (10, 19))])
+def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw):
+    """Forward variant 6 (the per-view projection computed once per pixel quad and broadcast) on ragged image sizes -- tiles
+    overhang the image, so some quads follow along on a dummy pixel -- for N = 3 and N = 5 views: bit-identical to variant 3."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(31 + ns)
+    b, c, d = 2, 32, 9
+    h, w = hw
+    rot, trans = _cams(b, ns, h, w, g)
+    trans = trans * torch.tensor([3.0, -2.0, 1.0])
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 21.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    outs = {}
+    for variant in (3, 6):
+        emul_lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+        try:
+            outs[variant] = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"sweep_fwd", 3)
+    assert torch.equal(outs[3], outs[6])
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    assert float((outs[6] - exp).abs().max()) < 2e-4

@@ -604,3 +604,26 @@ def test_featurenet_hip_convs_vs_stock(dev):
     assert float((ya - yb).abs().max()) < 2e-3
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert rel_l1(p.grad, q.grad) < 3e-2, k
+
+
+@pytest.mark.parametrize("ns,hw", [(2, (61, 83)), (4, (32, 40))])
+def test_plane_sweep_fwd_quad_shared_projection(dev, ns, hw):
+    """Forward variant 6 (per-view projection computed once per pixel quad, quad-broadcast DPP moves; not the default) must be
+    bit-identical to the default variant 3: N = 3 and N = 5 views, ragged image size."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(31 + ns)
+    b, c, d = 2, 32, 24
+    h, w = hw
+    rot, trans = _cams(b, ns, h, w)
+    ref = torch.randn(b, c, h, w, generator=g).to(dev)
+    srcs = [torch.randn(b, c, h, w, generator=g).to(dev) for _ in range(ns)]
+    depth = (430 + 11.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1).to(dev)
+    outs = {}
+    for variant in (3, 6):
+        lib.call("mvs_set_tuning", b"sweep_fwd", variant)
+        try:
+            outs[variant] = ops.plane_sweep_variance(ref, srcs, rot.to(dev), trans.to(dev), depth)
+        finally:
+            lib.call("mvs_set_tuning", b"sweep_fwd", 3)
+    assert torch.equal(outs[3], outs[6])

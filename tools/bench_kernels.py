@@ -65,7 +65,8 @@ def main():
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     with torch.no_grad():
-        for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (3, "cached8"), (4, "cached16")):
+        for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (6, "cached8, quad-shared projection"), (3, "cached8"),
+                               (6, "cached8, quad-shared projection"), (4, "cached16")):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
         lib.call("mvs_set_tuning", b"dslab", 0)
