@@ -768,6 +768,7 @@ static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the fo
 extern int g_conv_split;
 extern int g_conv_c8;
 extern int g_conv_xcd;
+extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 extern "C" int mvs_set_tuning(const char* key, int value) {
@@ -776,6 +777,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
     if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'k') { g_conv_c8 = value; return MVS_OK; }
+    if (key && key[0] == 'f') { g_conv_fs = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'g') { g_conv2d_wgrad_groups = value; return MVS_OK; }
     if (key && key[0] == '2') { g_conv2d_s2_mfma = value ? 1 : 0; return MVS_OK; }
     if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }

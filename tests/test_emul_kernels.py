@@ -573,3 +573,28 @@ def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw):
     assert torch.equal(outs[3], outs[6])
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((outs[6] - exp).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 16, 1, False, (9, 9, 33)), (8, 16, 2, False, (10, 16, 40)),
+                                                             (16, 8, 2, True, (5, 5, 20))])
+def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, dims):
+    """Generic implicit-GEMM kernels with the fast halo staging of interior tiles (tuning knob "fs", not the default): volumes
+    large enough to have interior tiles next to boundary ones; forward + input gradient, bit-identical to the default."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + stride)
+    x = torch.randn(1, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    y0, _ = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
+    gy = torch.randn(y0.shape, generator=g)
+    can_dgrad = not (stride == 2 and not transposed and any(s % 2 for s in dims))
+    gx0 = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed) if can_dgrad else None
+    emul_lib.call("mvs_set_tuning", b"fs", 1)
+    try:
+        y1, _ = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
+        gx1 = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed) if can_dgrad else None
+    finally:
+        emul_lib.call("mvs_set_tuning", b"fs", 0)
+    assert torch.equal(y0, y1)
+    if can_dgrad:
+        assert torch.equal(gx0, gx1)
