@@ -575,6 +575,7 @@ def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw):
     assert float((outs[6] - exp).abs().max()) < 2e-4
 
 
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="1.5 minutes of emulation for a non-default variant; set MVS_EMUL_FULL=1")
 @pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 16, 1, False, (9, 9, 33)), (8, 16, 2, False, (10, 16, 40)),
                                                              (16, 8, 2, True, (5, 5, 20))])
 def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, dims):
