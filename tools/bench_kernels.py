@@ -102,6 +102,9 @@ def main():
         lib.call("mvs_set_tuning", b"k8", _lib.DEFAULT_TUNING["k8"])
         lib.call("mvs_set_tuning", b"xcd", _lib.DEFAULT_TUNING["xcd"])
         add("conv0 dgrad", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
+        lib.call("mvs_set_tuning", b"fs", 1)     # fast halo staging of interior tiles in the generic kernels (not the default)
+        add("conv0 dgrad [fast staging]", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
+        lib.call("mvs_set_tuning", b"fs", 0)
         # L0 8-channel layers
         w1 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
         add("conv1 fwd 8>16 s2", lambda: ops.conv3d_forward(y0, w1, 2, False, want_stats=True), "mfma", 2 * 27 * 8 * 16 * vox / 8)
@@ -120,6 +123,9 @@ def main():
         w2 = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
         fl2 = 2 * 27 * 16 * 16 * vox / 8
         add("conv2 fwd 16>16 @L1", lambda: ops.conv3d_forward(x2, w2, 1, False, want_stats=True), "mfma", fl2)
+        lib.call("mvs_set_tuning", b"fs", 1)
+        add("conv2 fwd 16>16 @L1 [fast staging]", lambda: ops.conv3d_forward(x2, w2, 1, False, want_stats=True), "mfma", fl2)
+        lib.call("mvs_set_tuning", b"fs", 0)
         add("conv2 wgrad", lambda: ops.conv3d_wgrad(x2, x2, tuple(w2.shape), 1, False), "mfma", fl2)
         # BN passes on the L0 activation
         sc = torch.ones(8, device=dev)
