@@ -52,6 +52,18 @@ for k,v in d.items(): print(k, {c:x['per_dispatch'] for c,x in v.items()})"
     echo "bench $t exit $?"; cut -c1-200 gpurun_out/bench_$t.json
   done
 fi
+if [ "$what" = "r2" ]; then
+  # first GPU session of round 2: the variants written but not measured in round 1
+  timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED" gpurun_out/pytest_gpu.log | tail -8
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -E "sweep_fwd|fast staging|conv0 dgrad|conv2 fwd" gpurun_out/kernels.log
+  for t in "" "sweep_fwd=6" "fs=1" "sweep_fwd=6,fs=1"; do
+    MVS_TUNING=$t timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; cut -c1-200 "gpurun_out/bench_[$t].json"
+  done
+  MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
+  echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
+fi
 if [ "$what" = "sq" ]; then
   # where the cycles of the big kernels go: SQ busy / wait / MFMA-busy / LDS counters + effective clock (GRBM_GUI_ACTIVE)
   (cd /tmp && timeout 120 rocprofv3 -L > "$OLDPWD/gpurun_out/rocprof_counters.txt" 2>&1); grep -c . gpurun_out/rocprof_counters.txt
