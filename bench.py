@@ -124,19 +124,51 @@ def main():
     ap.add_argument("--pmc", type=int, default=1,
                     help="1 (default, N=1 only): after the timed region run tools/pmc_driver.py under `rocprofv3 --pmc` (separate "
                          "FETCH_SIZE and WRITE_SIZE passes) to fill roofline.traffic; 0 or no rocprofv3 on PATH: traffic = null")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check (tests, no GPU needed): start the ranks, all-reduce one number over gloo, print it, exit")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="extra untimed pass bracketing EVERY C-ABI call with HIP events (diagnostics to stderr)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, the reference starts all its
+        # GPUs from one command too, jdacs/train.py:65) by re-executing under torch.distributed.run on the loopback address
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import mvs_amd  # noqa: F401
     from mvs_amd import _lib, dist as mdist
     from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
     from mvs_amd.synthetic import synthetic_mvsnet_inputs
 
+    if args.dry_launch:
+        rank, world, local = mdist.init_from_env("gloo")
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": float(t)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rank, world, local = mdist.init_from_env("nccl")
-    if world != args.gpus and rank == 0:
-        sys.stderr.write("warning: --gpus %d but WORLD_SIZE %d\n" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d but only %d GPUs are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = True  # as the reference does (jdacs/train.py:35); FeatureNet uses MIOpen
@@ -178,6 +210,10 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.get()
+    # weight gradients on a side HIP stream: safe here -- gradients are read (bucket.gather) only after backward() has
+    # returned, no DDP / DataParallel hooks; the library default is off (ops.py)
+    from mvs_amd import ops as _ops
+    _ops.set_async_wgrad(os.environ.get("MVS_ASYNC_WGRAD", "1") != "0")
     eager_step = step
     graph_mode = False
     if args.graph != 0:
@@ -303,6 +339,8 @@ def main():
                                    "1 sample/GPU/step (BASELINE configs[1])",
                        "views": NVIEWS, "image": [IMG_H, IMG_W], "depth_planes": NDEPTH,
                        "global_batch": world, "parallelism": "dp%d" % world},
+            "ranks": (dist.get_world_size() if world > 1 else 1),
+            "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if world > 1 else "none (1 rank)",
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "grad_bucket_bytes": bucket.nbytes,

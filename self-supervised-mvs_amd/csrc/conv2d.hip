@@ -7,7 +7,7 @@
 //   forward      y[n,oy,ox,co] = sum_{ty,tx,ci} x[n, oy*S + ty - P, ox*S + tx - P, ci] * w[co][ci][ty][tx]   (+ bias)
 //   input grad   stride 1: the same kernel on gy with the weights transposed and flipped;
 //                stride 2: four output-parity classes, each a 3x3 stride-1 pass over gy on the coarse grid with its
-//                own (partly empty) weight image; a direct VALU form is kept behind mvs_set_tuning("2", 0)
+//                own (partly empty) weight image; a direct VALU form is kept behind mvs_set_tuning("conv2d_s2_mfma", 0)
 //   weight grad  dW[(ty,tx,ci)][co] = sum_positions x[...] * gy[...]: rows = (tap, ci), columns = co, K = positions;
 //                persistent workgroups, one partial image each, deterministic finish
 #include "mvs_rt.h"
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 // host side
 // ------------------------------------------------------------------------------------------------
 static const int C2_WGRAD_GROUPS = 256;   // partial images the workspace holds
-int g_conv2d_wgrad_groups = 256;          // tuning knob "g" (<= 256): persistent workgroups of the weight gradient
-int g_conv2d_s2_mfma = 1;   // tuning knob "2": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
+int g_conv2d_wgrad_groups = 256;          // tuning knob "wgrad2d_groups" (<= 256): persistent workgroups of the weight gradient
+int g_conv2d_s2_mfma = 1;   // tuning knob "conv2d_s2_mfma": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
 static int c2_cc(int ks, int cin) { return ks == 5 ? 8 : (cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32))); }

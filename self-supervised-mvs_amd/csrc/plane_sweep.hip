@@ -18,6 +18,7 @@
 // The reference reaches the same index through  g = p/((W-1)/2) - 1 ; ix = ((g+1)*W - 1)/2  -- the same
 // value up to fp32 rounding of the chain (tests bound both against an fp64 evaluation).
 #include <stdlib.h>
+#include <string.h>
 #include "mvs_rt.h"
 
 struct SweepArgs {
@@ -771,18 +772,24 @@ extern int g_conv_xcd;
 extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
+static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = default backward kernel
+// Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
+// is an error, never a silent hit on another knob.  Process-wide; not part of the data path's contract.
 extern "C" int mvs_set_tuning(const char* key, int value) {
-    if (key && key[0] == 'n') { g_sweep_nt = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 't') { g_sweep_tile_w = value; return MVS_OK; }
-    if (key && key[0] == 'd') { g_sweep_dslab = value; return MVS_OK; }
-    if (key && key[0] == 'c') { g_conv_split = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 'k') { g_conv_c8 = value; return MVS_OK; }
-    if (key && key[0] == 'f') { g_conv_fs = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 'g') { g_conv2d_wgrad_groups = value; return MVS_OK; }
-    if (key && key[0] == '2') { g_conv2d_s2_mfma = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 'x') { g_conv_xcd = value ? 1 : 0; return MVS_OK; }
-    if (key && key[0] == 's') { g_sweep_fwd_variant = value < 0 ? 0 : (value > 6 ? 6 : value); return MVS_OK; }
-    mvs_set_error("mvs_set_tuning: unknown key");
+    MVS_REQUIRE(key, MVS_ERR_NULL, "mvs_set_tuning: null key");
+    struct Knob { const char* name; int* var; int lo, hi; };
+    const Knob knobs[] = {
+        {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
+        {"conv_split", &g_conv_split, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
+        {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
+        {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 3},
+    };
+    for (const Knob& k : knobs)
+        if (strcmp(key, k.name) == 0) {
+            *k.var = value < k.lo ? k.lo : (value > k.hi ? k.hi : value);
+            return MVS_OK;
+        }
+    mvs_set_error("mvs_set_tuning: unknown key '%s'", key);
     return MVS_ERR_UNSUPPORTED;
 }
 

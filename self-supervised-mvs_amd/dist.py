@@ -53,14 +53,48 @@ class FlatGradBucket:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_param = None
         if flatten_params:
-            store = torch.cat([p.detach().reshape(-1) for p in self.params])
+            # every parameter keeps its PHYSICAL layout (a channels-last conv weight stays channels-last): the chunk of the
+            # store holds the parameter's elements in storage order and the view re-applies its strides
+            for p in self.params:
+                if not self._is_dense(p):
+                    raise ValueError("FlatGradBucket(flatten_params=True) needs dense parameters, got strides %s for shape %s"
+                                     % (p.stride(), tuple(p.shape)))
+            store = torch.cat([self._storage_order(p.detach()) for p in self.params])
             off = 0
             for p in self.params:
                 n = p.numel()
-                p.data = store[off:off + n].view_as(p)
+                p.data = store[off:off + n].as_strided(p.shape, p.stride())
                 off += n
             self.flat_param = torch.nn.Parameter(store)
             self.flat_param.grad = self.flat
+
+    @staticmethod
+    def _is_dense(t: torch.Tensor) -> bool:
+        """True if the strides are a permutation layout without gaps or overlaps (contiguous, channels-last, ...)."""
+        expect = 1
+        for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz > 1), key=lambda x: x[1]):
+            if stride != expect:
+                return False
+            expect *= size
+        return True
+
+    @staticmethod
+    def _storage_order(t: torch.Tensor) -> torch.Tensor:
+        """The elements of a dense tensor in the order they lie in memory, as a 1-D tensor (a view)."""
+        return t.as_strided((t.numel(),), (1,))
+
+    def check_aliasing(self) -> None:
+        """flatten_params: every parameter must still be a view of the flat store (something that re-allocates parameter
+        storage after the bucket was built -- module.to(memory_format=...), .double(), ... -- would detach it from the
+        optimiser silently)."""
+        if self.flat_param is None:
+            return
+        lo = self.flat_param.data_ptr()
+        hi = lo + self.flat_param.numel() * 4
+        for p in self.params:
+            if not (lo <= p.data_ptr() < hi):
+                raise RuntimeError("FlatGradBucket: a parameter of shape %s no longer aliases the flat store; build the "
+                                   "bucket after every layout / dtype conversion of the model" % (tuple(p.shape),))
 
     @property
     def nbytes(self) -> int:
@@ -71,8 +105,22 @@ class FlatGradBucket:
             p.grad = None
 
     def gather(self) -> None:
-        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=torch.float32,
-                                                                        device=self.flat.device) for p in self.params]
+        """Pack the fresh gradients into the flat buffer: ONE multi-tensor concatenation launch.  (Gradients as permanent
+        views of the bucket would instead cost one accumulate-add launch per parameter and step: autograd adds into an
+        existing .grad, it only hands over ownership when .grad is None.)  With flatten_params the gradient of a
+        parameter is laid out like the parameter (same strides), so bucket[i] is the gradient of flat_param[i]."""
+        self.check_aliasing()
+        grads = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                g = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
+            elif self.flat_param is not None and g.stride() != p.stride():
+                # autograd handed over a gradient in another layout than the parameter's: re-lay it out (one small copy)
+                g = self._storage_order(torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device).copy_(g))
+            else:
+                g = self._storage_order(g) if self.flat_param is not None else g.reshape(-1)
+            grads.append(g)
         torch.cat(grads, out=self.flat)
 
     def all_reduce(self) -> None:

@@ -91,6 +91,10 @@ class MVSNet(nn.Module):
         # and the features arrive in the layout the plane-sweep kernel reads (no NCHW->NHWC transpose)
         self.channels_last_features = channels_last_features
         self.feature = FeatureNet()
+        if channels_last_features:
+            # once, at construction: parameter storage must never be re-allocated inside forward() (an optimiser or a
+            # flat parameter/gradient bucket built before the first step would silently stop tracking the weights)
+            self.feature.to(memory_format=torch.channels_last)
         self.cost_regularization = CostRegNet()
         if self.refine:
             self.refine_network = RefineNet()
@@ -106,9 +110,6 @@ class MVSNet(nn.Module):
 
         # step 1. feature extraction (stock PyTorch)
         if self.channels_last_features:
-            if not getattr(self, "_feature_cl", False):
-                self.feature.to(memory_format=torch.channels_last)
-                self._feature_cl = True
             # all views through the shared-weight extractor as ONE batch (3x fewer launches, no per-view
             # gradient accumulation); BatchNorm keeps the reference's per-view statistics (grouped BN kernels)
             stacked = torch.cat(imgs, 0).contiguous(memory_format=torch.channels_last)

@@ -233,22 +233,27 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
     return gw
 
 
-# ---- weight gradients on a side stream -------------------------------------------------------------------------
+# ---- weight gradients on a side stream (opt-in) -----------------------------------------------------------------
 # In the backward pass a layer's weight gradient is a leaf of the dependency graph: nothing needs it before the optimiser
 # step, while the input gradient feeds the next layer's backward.  The deep U-Net levels launch fewer workgroups than
 # the chip has CUs and every weight gradient ends in two tiny reduction kernels, so running them on a second HIP stream
 # lets them fill the gaps of the main chain.  The side stream forks from the main stream when the output gradient is
-# ready and is joined by ONE end-of-backward callback (autograd engine), so every consumer after backward() sees
-# finished gradients.  Safe only if nothing consumes the gradient DURING the backward pass: a weight whose .grad already
-# exists (accumulation kernel on the main stream) or that was used by several forward calls (the engine sums the
-# contributions) takes the synchronous path.  MVS_ASYNC_WGRAD=0 switches it off.
-_ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
+# ready and is joined by ONE end-of-backward callback (autograd engine), so every consumer AFTER backward() sees
+# finished gradients.
+#
+# That is only correct if nothing reads the gradient DURING the backward pass, which this module cannot prove in
+# general: DDP reducer hooks sit on the AccumulateGrad node (invisible from the tensor), nn.DataParallel replicas reduce
+# mid-backward.  So it is OFF by default (MVS_ASYNC_WGRAD=1 or set_async_wgrad(True) switches it on -- bench.py does,
+# its step reads gradients only after backward()), and even when on a weight takes the synchronous path unless it is a
+# contiguous leaf without tensor / post-accumulate hooks, with no existing .grad (accumulation kernel on the main stream)
+# and a single forward use in this graph (several uses: the engine sums the contributions mid-backward).
+_ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "0") == "1"
 # Bookkeeping is per DEVICE, not per thread: the autograd engine runs backward nodes on its own worker threads and the
 # final callback on the thread that called backward(), so thread-local state would not connect them; one-thread-per-GPU
 # callers (nn.DataParallel style) touch disjoint entries.
 _SIDE_STREAMS = {}      # device index -> side stream (created once)
 _WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses since the last completed backward pass}
-_JOIN_PENDING = {}      # device index -> main stream that has to wait for the side stream at the end of the backward pass
+_BWD_OPEN = {}          # device index -> [main stream, side stream used?] while a backward pass with our nodes is running
 
 
 def set_async_wgrad(flag: bool) -> None:
@@ -258,22 +263,41 @@ def set_async_wgrad(flag: bool) -> None:
 
 def _note_weight_use(weight: torch.Tensor) -> None:
     if _ASYNC_WGRAD and weight.is_cuda:
-        uses = _WEIGHT_USES.setdefault(weight.device.index, {})
+        idx = weight.device.index
+        if idx in _BWD_OPEN:
+            # a forward while a backward pass is still "open": that pass died before its end-of-backward callback ran
+            # (an exception in a later node).  Close it here so that state never leaks into the next step.
+            _end_of_backward(idx)
+        uses = _WEIGHT_USES.setdefault(idx, {})
         uses[weight.data_ptr()] = uses.get(weight.data_ptr(), 0) + 1
 
 
-def _join_side_stream(idx: int) -> None:
-    main = _JOIN_PENDING.pop(idx, None)
-    if main is not None:
-        main.wait_stream(_SIDE_STREAMS[idx])
-    _WEIGHT_USES.pop(idx, None)
+def _end_of_backward(idx: int) -> None:
+    ent = _BWD_OPEN.pop(idx, None)
+    if ent is not None and ent[1]:
+        ent[0].wait_stream(_SIDE_STREAMS[idx])
+    _WEIGHT_USES.pop(idx, None)      # counts are per graph: every backward pass (async or not) resets them
+
+
+def _async_safe(weight: torch.Tensor) -> bool:
+    return (weight.is_leaf and weight.grad is None and weight.is_contiguous()
+            and not getattr(weight, "_backward_hooks", None)
+            and not getattr(weight, "_post_accumulate_grad_hooks", None))
 
 
 def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     lib = _lib_for(x)
+    if not (_ASYNC_WGRAD and x.is_cuda):
+        return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
     idx = x.device.index
-    ok = (_ASYNC_WGRAD and x.is_cuda and weight.grad is None
-          and _WEIGHT_USES.get(idx, {}).get(weight.data_ptr(), 0) <= 1)
+    main = torch.cuda.current_stream(x.device)
+    ent = _BWD_OPEN.get(idx)
+    if ent is None:
+        # first weight gradient of this backward pass: ONE callback closes the pass (joins the side stream if it was used,
+        # resets the per-graph use counts) whichever path the individual layers take
+        ent = _BWD_OPEN[idx] = [main, False]
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
+    ok = _async_safe(weight) and _WEIGHT_USES.get(idx, {}).get(weight.data_ptr(), 0) <= 1
     if ok and lib.profiler is not None:
         # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
         # not the kernel's plus whatever shares the chip with it on the other stream
@@ -283,7 +307,6 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
                                     _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
-    main = torch.cuda.current_stream(x.device)
     side = _SIDE_STREAMS.get(idx)
     if side is None:
         side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=x.device))
@@ -294,9 +317,7 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     for ten in (x, gy):
         ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
     gw.record_stream(main)
-    if idx not in _JOIN_PENDING:
-        _JOIN_PENDING[idx] = main
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side_stream(idx))
+    ent[1] = True
     return gw
 
 

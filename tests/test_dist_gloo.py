@@ -69,3 +69,23 @@ def test_flat_bucket_allreduce_matches_global_batch():
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     assert ret["nbytes"] == flat.numel() * 4
     assert torch.allclose(ret["flat"], flat, atol=1e-6, rtol=1e-5)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun must start N ranks by itself (VERDICT r1 missing #4)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["rank_sum"] == 3.0     # ranks 0 and 1 both took part in the collective
+    # a launcher that starts a different number of ranks than --gpus asks for is an error, not a warning
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -500,11 +500,11 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
     y2 = ops.conv2d_forward(x, w, None, stride)
     assert float((y2 - F.conv2d(x, w, None, stride=stride, padding=ks // 2)).abs().max()) < 2e-4
     if stride == 2:   # the direct form of the stride-2 input gradient (tuning knob "2" = 0) agrees with the parity-class MFMA passes
-        emul_lib.call("mvs_set_tuning", b"2", 0)
+        emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 0)
         try:
             gx = ops.conv2d_dgrad(gy, w, tuple(x.shape), 2)
         finally:
-            emul_lib.call("mvs_set_tuning", b"2", 1)
+            emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 1)
         assert float((gx - xr.grad).abs().max()) < 3e-4
 
 
@@ -542,11 +542,11 @@ def test_conv2d_wgrad_persistent_workgroups_walk_several_tiles(emul_lib):
     gy = torch.randn(2, 16, 20, 70, generator=g).contiguous(memory_format=torch.channels_last)
     w = torch.zeros(16, 8, 3, 3, requires_grad=True)
     F.conv2d(x, w, padding=1).backward(gy)
-    emul_lib.call("mvs_set_tuning", b"g", 3)
+    emul_lib.call("mvs_set_tuning", b"wgrad2d_groups", 3)
     try:
         gw = ops.conv2d_wgrad(x, gy, (16, 8, 3, 3), 1)
     finally:
-        emul_lib.call("mvs_set_tuning", b"g", 256)
+        emul_lib.call("mvs_set_tuning", b"wgrad2d_groups", 256)
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
 
 

@@ -119,3 +119,47 @@ def test_eval_plumbing_helpers(tmp_path):
     assert tensor2float({"loss": torch.tensor(1.5), "lr": 0.1}) == {"loss": 1.5, "lr": 0.1}
     with pytest.raises(NotImplementedError):
         tensor2numpy("x")
+
+
+def test_flat_bucket_keeps_channels_last_params_trainable():
+    """parameters flattened into one store must stay views of it -- also channels-last conv weights --
+    and one bucket + optimiser step must move EVERY parameter."""
+    import mvs_amd  # noqa: F401
+    from mvs_amd import dist as mdist
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                                torch.nn.Conv2d(8, 4, 5, stride=2, padding=2))
+    model.to(memory_format=torch.channels_last)          # layout conversion BEFORE the bucket is built
+    bucket = mdist.FlatGradBucket(model.parameters(), flatten_params=True)
+    assert model[0].weight.is_contiguous(memory_format=torch.channels_last)   # physical layout survived the flattening
+    opt = torch.optim.Adam([bucket.flat_param], lr=1e-2)
+    before = [p.detach().clone() for p in model.parameters()]
+    x = torch.randn(2, 3, 8, 8).contiguous(memory_format=torch.channels_last)
+    bucket.zero()
+    model(x).square().mean().backward()
+    ref_grads = [p.grad.clone() for p in model.parameters()]
+    bucket.gather()
+    opt.step()
+    for p, b, g in zip(model.parameters(), before, ref_grads):
+        assert not torch.equal(p.detach(), b), "a parameter did not move"
+        # Adam's first step moves every element by lr * sign(grad) (up to eps)
+        moved = (p.detach() - b)
+        nz = g.abs() > 1e-6
+        assert torch.allclose(moved[nz], -1e-2 * torch.sign(g[nz]), atol=1e-4)
+    # a re-allocation of parameter storage after the bucket was built must be caught, not silently ignored
+    model[3].weight.data = model[3].weight.data.clone()
+    bucket.zero()
+    model(x).square().mean().backward()
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        bucket.gather()
+
+
+def test_mvsnet_construction_fixes_feature_layout_once():
+    """The feature extractor is converted to channels-last at construction; forward() must not touch parameter storage."""
+    import mvs_amd  # noqa: F401
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    net = MVSNet(refine=False)
+    assert net.feature.conv0.conv.weight.is_contiguous(memory_format=torch.channels_last)
+    import inspect
+    assert "memory_format=torch.channels_last)" not in inspect.getsource(MVSNet._forward).replace(
+        "contiguous(memory_format=torch.channels_last)", "")
