@@ -32,6 +32,13 @@ static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
 #define MVS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget 512 / n per wave
 #define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating
+// wave-wide votes (every lane of the wave must reach them) and a compiler-level ordering point for a wave's own LDS
+// traffic (the DS queue of a wave is in order in hardware; this only stops the compiler from moving accesses across it)
+#define MVS_BALLOT(p) ((unsigned long long)__ballot(p))
+#define MVS_ANY(p) (__any(p) != 0)
+#define MVS_FFSLL(m) __ffsll((unsigned long long)(m))
+#define MVS_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#define MVS_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)   // a value known to be the same in every lane -> SGPR
 #define MVS_MFMA_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 // cbsz = 4: the A operand of block `abid` (lanes 4*abid .. 4*abid+3) is broadcast to all 16 blocks
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (abid), 0)

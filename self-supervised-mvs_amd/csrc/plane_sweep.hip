@@ -38,6 +38,7 @@ struct SweepArgs {
     float sx, ox, sy, oy;  // ix = px*sx + ox, iy = py*sy + oy
     int tiles_x, tiles_y;
     int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
+    int no_window;   // test knob "bwd_nowin": per-wave-window backward sends every flush down its global-atomic path
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
@@ -751,6 +752,360 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward, per-wave windows (default for 1..4 source views).
+//
+// What bounded the kernel above (profiles/r01_run19_pmc_sq_summary.json, profiles/r02_run1_atomic_rate.log): an LDS fp32
+// atomic costs ~3 LDS cycles PER ACTIVE LANE (ds_add_f32: 25 cycles with 8 lanes, 193 with 64, whatever the addresses),
+// against ~9 cycles for a whole ds_read_b128 / ds_write_b128 and 5.5 for a dense 64-lane ds_read_b32 + ds_write_b32 pair;
+// the flush of a 2x2 block was 16 atomics with a handful of lanes active each, i.e. the LDS array was busy 42 cycles
+// per instruction, 52 % of the kernel.  A plain read-add-write needs exclusive ownership of the window, so here
+//  * every WAVE owns its own LDS windows (one per source view: the footprint of the wave's small pixel block over the
+//    depth segment), so there is no inter-wave race and no barrier inside the plane loop;
+//  * the pixel groups of a wave that leave their block on the same plane flush ONE AFTER THE OTHER (a wave-uniform loop
+//    over the ballot; the DS queue of a wave is in order), so there is no intra-instruction race either: a flush is
+//    4 taps x (CPT/4) x {ds_read_b128, 4 adds, ds_write_b128}, no atomics;
+//  * a thread carries CPT = 8 channels for <= 2 source views (4 lanes per pixel: the per-pixel projection arithmetic is
+//    replicated 4x instead of 8x) and 4 channels for 3-4 views (register budget), ALL views in one workgroup: the
+//    upstream gradient is read exactly once and no view is ever re-sampled through L1;
+//  * at the end of a depth segment the four waves' windows are summed on the fly and written out with coalesced global
+//    atomics (64 consecutive floats per wave instruction: 330 G/s against 79 G/s for the 4-float pattern of a
+//    per-thread flush), grad_ref likewise goes through LDS so that a wave instruction covers whole 128-byte texels.
+// ------------------------------------------------------------------------------------------------
+template <int C, int CPT> struct PwCfg {
+    static constexpr int LPP = C / CPT;             // lanes per pixel
+    static constexpr int PPW = 64 / LPP;            // pixels per wave, as a BW x BH block
+    static constexpr int BW = PPW >= 32 ? 8 : 4, BH = PPW / BW;
+    static constexpr int V = CPT / 4;               // float4s per tap per thread
+    static constexpr int WAVE_FLOATS = 4992;        // 19.5 KiB of accumulation window per wave, shared by its views (2 workgroups per CU)
+};
+
+// One source view's register-resident 2x2 texel block of a thread: tap values + gradient accumulators (V float4 each).
+template <int V> struct PwBlock {
+    int cx, cy;
+    float4 t00[V], t01[V], t10[V], t11[V];
+    float4 g00[V], g01[V], g10[V], g11[V];
+};
+
+template <int C, int V, int CK>
+__device__ __forceinline__ void pw_tap_add(float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gp,
+                                           int xi, int yi, int W, const float4 (&g)[V]) {
+    const int wx = xi - w.x0, wy = yi - w.y0;
+    if (use_win && wx >= 0 && wx < w.w && wy >= 0 && wy < w.h) {
+        float* p = win + (wy * w.w + wx) * C;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float4 a = *reinterpret_cast<float4*>(p + CK * k);
+            a.x += g[k].x; a.y += g[k].y; a.z += g[k].z; a.w += g[k].w;
+            *reinterpret_cast<float4*>(p + CK * k) = a;
+        }
+    } else {
+        float* p = gp + ((size_t)yi * W + xi) * C;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 0, g[k].x); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 1, g[k].y);
+            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 2, g[k].z); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 3, g[k].w);
+        }
+    }
+}
+
+// The pixel groups (LPP consecutive lanes) whose `want` is set add their accumulators to the wave's window, one group
+// per iteration of a wave-uniform loop.  win / gp already include the lane's channel offset.
+template <int C, int V, int CK, int LPP>
+__device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlock<V>& blk, int H, int W,
+                                                float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gp) {
+    unsigned long long m = MVS_BALLOT(want);
+    while (m) {
+        const int grp = (MVS_FFSLL(m) - 1) / LPP;
+        if (lane / LPP == grp) {
+            const int cx = blk.cx, cy = blk.cy;
+            const bool xin0 = cx >= 0 && cx < W, xin1 = cx + 1 >= 0 && cx + 1 < W;
+            const bool yin0 = cy >= 0 && cy < H, yin1 = cy + 1 >= 0 && cy + 1 < H;
+            if (xin0 && yin0) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx, cy, W, blk.g00);
+            if (xin1 && yin0) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx + 1, cy, W, blk.g01);
+            if (xin0 && yin1) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx, cy + 1, W, blk.g10);
+            if (xin1 && yin1) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx + 1, cy + 1, W, blk.g11);
+        }
+        m &= ~((LPP == 64 ? ~0ull : ((1ull << LPP) - 1ull)) << (grp * LPP));
+        MVS_WAVE_SYNC();   // next group may touch the same texels: keep the DS operations in program order
+    }
+}
+
+// MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
+template <int C, int NS_T, int CPT, int MODE>
+__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(2) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
+    constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
+    using Cfg = PwCfg<C, CPT>;
+    constexpr int LPP = Cfg::LPP, BW = Cfg::BW, BH = Cfg::BH, V = Cfg::V;
+    constexpr int CK = 4 * LPP;                      // channel of float4 k of lane q: 4q + CK*k (as in the forward)
+    constexpr int VIEW_FLOATS = Cfg::WAVE_FLOATS / NS_T / C * C, WCAP = VIEW_FLOATS / C;
+    __shared__ __attribute__((aligned(16))) float lds[4 * NS_T * VIEW_FLOATS];   // [wave][view][texel][C]
+    __shared__ int s_win[4][NS_T][5];                // per wave and view: x0, y0, w, h, usable
+    __shared__ int s_fit[4];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = lane % LPP, pl = lane / LPP;
+    const int bx0 = (blockIdx.x % a.tiles_x) * (2 * BW) + (wv & 1) * BW, by0 = (blockIdx.x / a.tiles_x) * (2 * BH) + (wv >> 1) * BH;
+    const int xr = bx0 + pl % BW, yr = by0 + pl / BW;
+    const int b = blockIdx.z;
+    const bool live = xr < a.W && yr < a.H;          // lanes outside the image follow along (wave-wide exchanges) on a clamped pixel
+    const int x = min(xr, a.W - 1), y = min(yr, a.H - 1);
+    const int HW = a.H * a.W, pix = y * a.W + x;
+    const float xf = (float)x, yf = (float)y;
+    const int cq = 4 * q;
+    const size_t fbase = (size_t)b * HW * C + cq;
+    float4 r[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) r[k] = ld4(a.ref + fbase + (size_t)pix * C + CK * k);
+    const float inv_n = 1.0f / (float)(NS_T + 1);
+    const float two_n = live ? 2.0f * inv_n : 0.0f;  // dead lanes contribute exact zeros
+    const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
+    const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
+    float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
+#pragma unroll
+    for (int s = 0; s < NS_T; ++s) {
+        const float* R = rotb + s * 9;
+        rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
+        ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
+        rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
+        tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
+    }
+    float4 gr[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) gr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // corners of the wave's pixel block (clipped to the image) for its footprint bound
+    const float cxa = (float)min(bx0, a.W - 1), cxb = (float)min(bx0 + BW - 1, a.W - 1);
+    const float cya = (float)min(by0, a.H - 1), cyb = (float)min(by0 + BH - 1, a.H - 1);
+    float* const wwin = lds + (size_t)wv * NS_T * VIEW_FLOATS;     // this wave's windows
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int ds = blockIdx.y * a.dslab;
+    const int dend = min(a.D, ds + a.dslab);
+    while (ds < dend) {
+        // ---- segment [ds, de): the longest one for which every wave's windows fit (workgroup-uniform) ----
+        int de = dend;
+        Win w[NS_T];
+        bool use[NS_T];
+        for (int it = 0; it < 16; ++it) {
+            float da, db;
+            if (a.per_pixel) {
+                float lo = 3.0e38f, hi = -3.0e38f;
+                if (q == 0)
+                    for (int d = ds; d < de; ++d) {
+                        float v = a.depth[((size_t)b * a.D + d) * HW + pix];
+                        lo = fminf(lo, v); hi = fmaxf(hi, v);
+                    }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
+                da = lo; db = hi;                    // depth range of THIS wave's pixels: its windows only have to hold them
+            } else {
+                da = a.depth[b * a.D + ds];
+                db = a.depth[b * a.D + de - 1];
+            }
+            bool fits = true;
+#pragma unroll
+            for (int s = 0; s < NS_T; ++s) {
+                float lox, hix, loy, hiy;
+                corner_bounds(a, rotb + s * 9, trb + s * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
+                w[s] = make_window(a, lox, hix, loy, hiy);
+                // wave-uniform, but computed on the vector ALU: move to scalar registers (they live through the plane loop)
+                w[s].x0 = MVS_UNIFORM_I(w[s].x0); w[s].y0 = MVS_UNIFORM_I(w[s].y0);
+                w[s].w = MVS_UNIFORM_I(w[s].w); w[s].h = MVS_UNIFORM_I(w[s].h);
+                use[s] = (long)w[s].w * w[s].h <= WCAP;
+                fits = fits && use[s];
+                use[s] = use[s] && !a.no_window;
+            }
+            __syncthreads();                         // previous readers of s_fit are done
+            if (lane == 0) s_fit[wv] = fits ? 1 : 0;
+            __syncthreads();
+            const bool all_fit = s_fit[0] && s_fit[1] && s_fit[2] && s_fit[3];
+            if (all_fit || de - ds <= 1) break;
+            de = ds + (de - ds + 1) / 2;
+        }
+        // ---- zero this wave's windows; publish their geometry for the write-out ----
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            if (use[s]) {
+                float* ws = wwin + s * VIEW_FLOATS;
+                for (int i = lane * 4; i < w[s].w * w[s].h * C; i += 256) *reinterpret_cast<float4*>(ws + i) = z4;
+            }
+            if (lane == 0) {
+                s_win[wv][s][0] = w[s].x0; s_win[wv][s][1] = w[s].y0; s_win[wv][s][2] = w[s].w; s_win[wv][s][3] = w[s].h;
+                s_win[wv][s][4] = use[s] ? 1 : 0;
+            }
+        }
+        MVS_WAVE_SYNC();
+        // ---- walk the planes of the segment (no workgroup barrier in here) ----
+        {
+            PwBlock<V> blk[NS_T];
+#pragma unroll
+            for (int s = 0; s < NS_T; ++s) {
+                blk[s].cx = blk[s].cy = -0x40000000;
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    blk[s].t00[k] = blk[s].t01[k] = blk[s].t10[k] = blk[s].t11[k] = blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] =
+                        blk[s].g11[k] = z4;
+            }
+            const float* __restrict__ gptr = a.gvar + (((size_t)b * a.D + ds) * HW + pix) * C + cq;
+            const size_t gstep = (size_t)HW * C;
+            float4 g_next[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) g_next[k] = ld4(gptr + CK * k);
+#pragma clang loop unroll(disable)
+            for (int d = ds; d < de; ++d) {
+                const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
+                // phase 1 (nothing of this plane's channel math is live yet): where does each view sample, and which
+                // pixel groups left their 2x2 block -> flush + re-gather
+                float fwx[NS_T], fwy[NS_T];
+#pragma unroll
+                for (int s = 0; s < NS_T; ++s) {
+                    const float zz = fmaf(rz[s], dep, tz[s]);
+                    float iz = MVS_RCP(zz);
+                    iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
+                    const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
+                    const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
+                    const float fx = floorf(ix), fy = floorf(iy);
+                    fwx[s] = ix - fx; fwy[s] = iy - fy;
+                    const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
+                    const bool chg = x0 != blk[s].cx || y0 != blk[s].cy;
+                    if (MVS_ANY(chg)) {
+                        float* const gp = a.gsrc[s] + fbase;
+                        pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
+                                                       wwin + s * VIEW_FLOATS + cq, w[s], use[s], gp);
+                        if (chg) {
+                            blk[s].cx = x0; blk[s].cy = y0;
+                            const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                            const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                            const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+#pragma unroll
+                            for (int k = 0; k < V; ++k) {
+                                blk[s].t00[k] = (xin0 && yin0) ? ld4(f + CK * k) : z4;
+                                blk[s].t01[k] = (xin1 && yin0) ? ld4(f + C + CK * k) : z4;
+                                blk[s].t10[k] = (xin0 && yin1) ? ld4(f + a.W * C + CK * k) : z4;
+                                blk[s].t11[k] = (xin1 && yin1) ? ld4(f + a.W * C + C + CK * k) : z4;
+                                blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
+                            }
+                        }
+                    }
+                }
+                MVS_SCHED_FENCE();
+                // phase 2, one float4 of channels at a time (keeps the live temporaries to one chunk): bilinear samples of all
+                // views, their mean, then the gradients of the samples into the register accumulators.  The upstream gradient of
+                // the NEXT plane is requested as soon as this plane's chunk has been consumed (no second buffer).
+                float wt[NS_T][4];
+#pragma unroll
+                for (int s = 0; s < NS_T; ++s) {
+                    const float wx = fwx[s], wy = fwy[s];
+                    const float ex = 1.0f - wx, ey = 1.0f - wy;
+                    wt[s][0] = ey * ex; wt[s][1] = ey * wx; wt[s][2] = wy * ex; wt[s][3] = wy * wx;
+                }
+                const bool more = d + 1 < de;
+                if (more) gptr += gstep;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float4 S = WARP_ONLY ? z4 : (MS_ALIAS ? make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w) : r[k]);
+                    float4 v[NS_T];
+                    if (!WARP_ONLY) {
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s) {
+                            const PwBlock<V>& B = blk[s];
+                            v[s].x = fmaf(B.t11[k].x, wt[s][3], fmaf(B.t10[k].x, wt[s][2], fmaf(B.t01[k].x, wt[s][1], B.t00[k].x * wt[s][0])));
+                            v[s].y = fmaf(B.t11[k].y, wt[s][3], fmaf(B.t10[k].y, wt[s][2], fmaf(B.t01[k].y, wt[s][1], B.t00[k].y * wt[s][0])));
+                            v[s].z = fmaf(B.t11[k].z, wt[s][3], fmaf(B.t10[k].z, wt[s][2], fmaf(B.t01[k].z, wt[s][1], B.t00[k].z * wt[s][0])));
+                            v[s].w = fmaf(B.t11[k].w, wt[s][3], fmaf(B.t10[k].w, wt[s][2], fmaf(B.t01[k].w, wt[s][1], B.t00[k].w * wt[s][0])));
+                            S.x += v[s].x; S.y += v[s].y; S.z += v[s].z; S.w += v[s].w;
+                        }
+                    }
+                    const float4 g = g_next[k];
+                    if (more) g_next[k] = ld4(gptr + CK * k);
+                    float4 gs = make_float4(g.x * two_n, g.y * two_n, g.z * two_n, g.w * two_n);   // g * 2/N (0 on dead lanes)
+                    float4 Sm = make_float4(S.x * inv_n, S.y * inv_n, S.z * inv_n, S.w * inv_n);
+                    if (WARP_ONLY) {
+                        gs = live ? g : z4;          // plain homo_warping: the warped sample itself gets the gradient
+                    } else if (MS_ALIAS) {
+                        gr[k].x += gs.x * r[k].x * (1.0f - 2.0f * Sm.x); gr[k].y += gs.y * r[k].y * (1.0f - 2.0f * Sm.y);
+                        gr[k].z += gs.z * r[k].z * (1.0f - 2.0f * Sm.z); gr[k].w += gs.w * r[k].w * (1.0f - 2.0f * Sm.w);
+                    } else {
+                        gr[k].x += gs.x * (r[k].x - Sm.x); gr[k].y += gs.y * (r[k].y - Sm.y);
+                        gr[k].z += gs.z * (r[k].z - Sm.z); gr[k].w += gs.w * (r[k].w - Sm.w);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS_T; ++s) {
+                        float4 gv;
+                        if (WARP_ONLY) gv = gs;
+                        else gv = make_float4(gs.x * (v[s].x - Sm.x), gs.y * (v[s].y - Sm.y), gs.z * (v[s].z - Sm.z), gs.w * (v[s].w - Sm.w));
+                        PwBlock<V>& B = blk[s];
+                        B.g00[k].x = fmaf(gv.x, wt[s][0], B.g00[k].x); B.g00[k].y = fmaf(gv.y, wt[s][0], B.g00[k].y);
+                        B.g00[k].z = fmaf(gv.z, wt[s][0], B.g00[k].z); B.g00[k].w = fmaf(gv.w, wt[s][0], B.g00[k].w);
+                        B.g01[k].x = fmaf(gv.x, wt[s][1], B.g01[k].x); B.g01[k].y = fmaf(gv.y, wt[s][1], B.g01[k].y);
+                        B.g01[k].z = fmaf(gv.z, wt[s][1], B.g01[k].z); B.g01[k].w = fmaf(gv.w, wt[s][1], B.g01[k].w);
+                        B.g10[k].x = fmaf(gv.x, wt[s][2], B.g10[k].x); B.g10[k].y = fmaf(gv.y, wt[s][2], B.g10[k].y);
+                        B.g10[k].z = fmaf(gv.z, wt[s][2], B.g10[k].z); B.g10[k].w = fmaf(gv.w, wt[s][2], B.g10[k].w);
+                        B.g11[k].x = fmaf(gv.x, wt[s][3], B.g11[k].x); B.g11[k].y = fmaf(gv.y, wt[s][3], B.g11[k].y);
+                        B.g11[k].z = fmaf(gv.z, wt[s][3], B.g11[k].z); B.g11[k].w = fmaf(gv.w, wt[s][3], B.g11[k].w);
+                    }
+                    MVS_SCHED_FENCE();
+                }
+            }
+            // the blocks still held in registers
+#pragma unroll
+            for (int s = 0; s < NS_T; ++s)
+                pw_flush_groups<C, V, CK, LPP>(live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W, wwin + s * VIEW_FLOATS + cq,
+                                               w[s], use[s], a.gsrc[s] + fbase);
+        }
+        // ---- write the segment out: the four waves' windows summed on the fly, coalesced global atomics ----
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            int ux0 = 1 << 30, uy0 = 1 << 30, ux1 = -1, uy1 = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s_win[j][s][4]) {
+                    ux0 = min(ux0, s_win[j][s][0]); uy0 = min(uy0, s_win[j][s][1]);
+                    ux1 = max(ux1, s_win[j][s][0] + s_win[j][s][2]); uy1 = max(uy1, s_win[j][s][1] + s_win[j][s][3]);
+                }
+            const int uw = ux1 - ux0, uh = uy1 - uy0;
+            if (uw <= 0 || uh <= 0) continue;
+            int jx0[4], jy0[4], jw[4], jh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                jx0[j] = s_win[j][s][0]; jy0[j] = s_win[j][s][1];
+                jw[j] = s_win[j][s][4] ? s_win[j][s][2] : 0; jh[j] = s_win[j][s][3];
+            }
+            float* gp = a.gsrc[s] + (size_t)b * HW * C;
+            for (int i = tid; i < uw * uh * C; i += 256) {
+                const int c = i % C, t = i / C;
+                const int txl = ux0 + t % uw, tyl = uy0 + t / uw;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lx = txl - jx0[j], ly = tyl - jy0[j];
+                    if (lx >= 0 && lx < jw[j] && ly >= 0 && ly < jh[j])
+                        acc += lds[(j * NS_T + s) * VIEW_FLOATS + (ly * jw[j] + lx) * C + c];
+                }
+                if (acc != 0.f) MVS_GLOBAL_ATOMIC_ADD(gp + ((size_t)tyl * a.W + txl) * C + c, acc);
+            }
+        }
+        __syncthreads();
+        ds = de;
+    }
+    if (!WARP_ONLY) {
+        // grad_ref: one atomic per (pixel, channel, depth slab); through LDS so that a wave instruction covers whole texels
+        float* stage = wwin;                          // PPW x C floats of this wave's (now idle) window space
+#pragma unroll
+        for (int k = 0; k < V; ++k) *reinterpret_cast<float4*>(stage + pl * C + cq + CK * k) = gr[k];
+        MVS_WAVE_SYNC();
+        constexpr int PPW = Cfg::PPW;
+        for (int i = lane; i < PPW * C; i += 64) {
+            const int p = i / C, c = i % C;
+            const int px = bx0 + p % BW, py = by0 + p / BW;
+            const float val = stage[i];
+            if (px < a.W && py < a.H && val != 0.f) MVS_GLOBAL_ATOMIC_ADD(a.gref + ((size_t)b * HW + (size_t)py * a.W + px) * C + c, val);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // MVS_SWEEP_FWD=direct selects the tap-through-L1 kernel (kept for A/B measurements); default: LDS-staged
 // forward variants: 0 taps through L1 every plane, 1 LDS-staged windows, 2 register-cached taps (4 ch/thread),
@@ -772,7 +1127,9 @@ extern int g_conv_xcd;
 extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
-static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = default backward kernel
+static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
+static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
+static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
 // is an error, never a silent hit on another knob.  Process-wide; not part of the data path's contract.
 extern "C" int mvs_set_tuning(const char* key, int value) {
@@ -782,7 +1139,8 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
         {"conv_split", &g_conv_split, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
-        {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 3},
+        {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -859,8 +1217,39 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     return mvs_check_launch("plane_sweep_variance_fwd");
 }
 
+template <int C, int NS_T, int CPT>
+static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
+    using Cfg = PwCfg<C, CPT>;
+    a.tiles_x = mvs_cdiv(a.W, 2 * Cfg::BW);
+    a.tiles_y = mvs_cdiv(a.H, 2 * Cfg::BH);
+    // depth slabs: >= ~2048 workgroups (2 resident per CU, several rounds), each >= 16 planes: every extra slab
+    // re-gathers the blocks, writes its windows out once more and adds one grad_ref atomic per pixel and channel
+    const int tiles = a.tiles_x * a.tiles_y * a.B;
+    int nslab = mvs_cdiv(2048, tiles);
+    if (nslab > a.D / 16) nslab = a.D / 16;
+    if (nslab < 1) nslab = 1;
+    a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
+    a.no_window = g_sweep_bwd_nowin;
+    dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
+    if (a.warp_only) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2>), grid, block, 0, st, a);
+    else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1>), grid, block, 0, st, a);
+    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0>), grid, block, 0, st, a);
+    return mvs_check_launch("plane_sweep_variance_bwd_pw");
+}
+
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
+    if (g_sweep_bwd_variant == 0 && a.NS <= 4) {
+        // 8 channels per thread while the register file holds two views' blocks; 4 beyond that
+        constexpr int CPT_HI = C >= 16 ? 8 : 4;
+        switch (a.NS) {
+            case 1: return launch_bwd_pw<C, 1, CPT_HI>(a, st);
+            case 2: return launch_bwd_pw<C, 2, CPT_HI>(a, st);
+            case 3: return launch_bwd_pw<C, 3, 4>(a, st);
+            default: return launch_bwd_pw<C, 4, 4>(a, st);
+        }
+    }
+    // more than four source views (or knob "sweep_bwd" = 1): view pairs per workgroup, LDS-atomic windows
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);
     a.tiles_y = mvs_cdiv(a.H, Tile<C>::TH);
     const int ngroups = mvs_cdiv(a.NS, 2);

@@ -125,6 +125,26 @@ static inline int __shfl(int v, int src, int width = 64) {
     memcpy(&v, &f, 4);
     return v;
 }
+// wave-wide votes: every lane of the wave calls them (the kernels keep out-of-range lanes alive for that)
+static inline unsigned long long emul_ballot(bool p) {
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    w->fa[s][emul::lane] = p ? 1.0f : 0.0f;
+    pthread_barrier_wait(&w->bar);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (w->fa[s][l] != 0.0f) m |= 1ull << l;
+    return m;
+}
+static inline void emul_wave_sync() {
+    emul::xcnt += 2;   // keeps the double-buffer parity of the exchange slots
+    pthread_barrier_wait(&emul::cur_wave->bar);
+}
+#define MVS_BALLOT(p) emul_ballot(p)
+#define MVS_ANY(p) (emul_ballot(p) != 0ull)
+#define MVS_FFSLL(m) __builtin_ffsll((long long)(m))
+#define MVS_WAVE_SYNC() emul_wave_sync()
+#define MVS_UNIFORM_I(x) (x)
 #define MVS_QUAD_BCAST_I(v, s) __shfl((int)(v), (emul::lane & ~3) | (s))
 #define MVS_QUAD_BCAST_F(v, s) __shfl((float)(v), (emul::lane & ~3) | (s))
 #define MVS_SCHED_FENCE() ((void)0)

@@ -28,7 +28,9 @@ def _cams(b, ns, h, w, gen):
 
 
 @pytest.mark.parametrize("c,ns,per_pixel,alias,ac", [(8, 1, False, False, False), (16, 2, True, True, False),
-                                                     (32, 2, False, False, True), (32, 4, False, False, False)])
+                                                     (32, 2, False, False, True), (32, 4, False, False, False),
+                                                     (32, 3, True, True, False), (16, 3, False, False, False),
+                                                     (16, 6, False, False, False)])
 def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
     from mvs_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -56,6 +58,37 @@ def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
                                      align_corners=ac)
     assert_as_accurate_as_fp32_reference(var.detach(), exp.detach(), t64, what="variance volume")
     assert float((var - exp).abs().max()) < 2e-4
+    for a, t in zip(got, [ref] + srcs):
+        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("c,ns,step,hw", [(32, 2, 400.0, (13, 21)), (16, 3, 150.0, (10, 18))])
+def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, variant):
+    """Footprints larger than an accumulation window: depth segmentation + global-atomic path (both backward kernels)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(11)
+    b, d = 1, 12
+    h, w = hw
+    rot, trans = _cams(b, ns, h, w, g)
+    ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+    srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
+    depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path)
+    emul_lib.call("mvs_set_tuning", b"sweep_bwd", variant & 1)
+    emul_lib.call("mvs_set_tuning", b"bwd_nowin", variant >> 1)
+    try:
+        var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+        gup = torch.randn(var.shape, generator=g)
+        var.backward(gup)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        emul_lib.call("mvs_set_tuning", b"bwd_nowin", 0)
+    got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
+    for t in [ref] + srcs:
+        t.grad = None
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
     for a, t in zip(got, [ref] + srcs):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 

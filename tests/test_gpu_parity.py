@@ -43,6 +43,10 @@ def _cams(b, ns, h, w):
     (32, 4, False, False, False, (12, 20, 28)),       # N=5 (config 3 view count)
     (32, 6, False, False, False, (6, 16, 24)),        # N=7 (config 5 view count)
     (16, 5, False, True, False, (6, 16, 24)),         # runtime-NS path
+    (32, 3, False, False, False, (10, 19, 27)),       # N=4; ragged tile edges (dead lanes of the backward's pixel blocks)
+    (32, 3, True, True, False, (8, 21, 30)),          # per-pixel hypotheses, 3 source views, alias quirk
+    (16, 4, True, False, False, (8, 20, 28)),
+    (32, 1, False, False, False, (24, 17, 23)),
 ])
 def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
     from mvs_amd import ops
@@ -75,6 +79,40 @@ def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
     # white-noise features (unit variance, steep gradients): the two fp32 chains differ by a few ulp of the
     # sample coordinate
     assert float((var.cpu() - exp).abs().max()) < 3e-4
+    for a, t in zip([refg] + srcg, [refc] + srcc):
+        assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("c,ns,step", [(32, 2, 60.0), (32, 2, 400.0), (16, 3, 150.0), (32, 4, 90.0)])
+def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
+    """Backward with footprints that do not fit one accumulation window: depth segmentation and, for the widest range,
+    the global-atomic path for taps outside the window.  variant 0 = per-wave windows, 1 = view-pair kernel (knob)."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(11)
+    b, d, h, w = 1, 40, 26, 38
+    rot, trans = _cams(b, ns, h, w)
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    refg = ref.to(dev).requires_grad_(True)
+    srcg = [s.to(dev).requires_grad_(True) for s in srcs]
+    # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path)
+    lib.call("mvs_set_tuning", b"sweep_bwd", variant & 1)
+    lib.call("mvs_set_tuning", b"bwd_nowin", variant >> 1)
+    try:
+        var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
+        gup = torch.randn(var.shape, generator=g)
+        var.backward(gup.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        lib.call("mvs_set_tuning", b"bwd_nowin", 0)
+    refc = ref.clone().requires_grad_(True)
+    srcc = [s.clone().requires_grad_(True) for s in srcs]
+    exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
     for a, t in zip([refg] + srcg, [refc] + srcc):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 

@@ -80,12 +80,32 @@ def main():
         var = ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth)
     if os.environ.get('MVS_BENCH_SWEEP_ONLY'):
         return
-    # backward of the sweep
-    fr = [f.clone().requires_grad_(True) for f in feats]
-    v = ops.plane_sweep_variance(fr[0], fr[1:], rot, trans, depth)
-    gv = torch.randn_like(v)
-    add("sweep_bwd", lambda: torch.autograd.grad(v, fr, gv, retain_graph=True), "hbm", C * vox * 4 + 2 * (NS + 1) * C * H * W * 4)
-    del v, gv, fr
+    # backward of the sweep: per-wave windows (default) vs the round-1 view-pair kernel, depth-slab sizes, and N = 5
+    def sweep_bwd_case(ns_, label):
+        K5, E5 = R.synthetic_cameras(ns_ + 1, H, W, 4 * W)
+        P5 = E5.clone()
+        P5[:, :3, :4] = K5 @ E5[:, :3, :4]
+        rt5 = [ops.relative_projection(P5[s:s + 1], P5[0:1]) for s in range(1, ns_ + 1)]
+        rot5 = torch.stack([r for r, _ in rt5], 1).to(dev)
+        trans5 = torch.stack([t for _, t in rt5], 1).to(dev)
+        f5 = [F.avg_pool2d(torch.randn(B, C, H, W, generator=g), 3, 1, 1).to(dev).contiguous(memory_format=torch.channels_last)
+              .requires_grad_(True) for _ in range(ns_ + 1)]
+        v5 = ops.plane_sweep_variance(f5[0], f5[1:], rot5, trans5, depth)
+        gv5 = torch.randn_like(v5)
+        nbytes = C * vox * 4 + 2 * (ns_ + 1) * C * H * W * 4
+        for variant, dslab in ((1, 0), (0, 0), (0, 16), (0, 24), (0, 32), (0, 48), (0, 64), (0, 0), (1, 0)):
+            lib.call("mvs_set_tuning", b"sweep_bwd", variant)
+            lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
+            add("sweep_bwd N=%d [%s%s]%s" % (ns_ + 1, "per-wave windows" if variant == 0 else "view pairs + LDS atomics",
+                                             ", dslab %d" % dslab if dslab else "", label),
+                lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
+        lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        lib.call("mvs_set_tuning", b"bwd_dslab", 0)
+
+    sweep_bwd_case(NS, "")
+    sweep_bwd_case(4, "")
+    if os.environ.get('MVS_BENCH_BWD_ONLY'):
+        return
     # conv0 family
     w0 = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.05).to(dev)
     fl0 = 2 * 27 * 32 * 8 * vox
