@@ -778,7 +778,9 @@ template <int C, int CPT> struct PwCfg {
     static constexpr int PPW = 64 / LPP;            // pixels per wave, as a BW x BH block
     static constexpr int BW = PPW >= 32 ? 8 : 4, BH = PPW / BW;
     static constexpr int V = CPT / 4;               // float4s per tap per thread
-    static constexpr int WAVE_FLOATS = 4992;        // 19.5 KiB of accumulation window per wave, shared by its views (2 workgroups per CU)
+    // accumulation window per wave, shared by its views: 19.5 KiB (2 workgroups per CU) with 8 channels per thread,
+    // 12.5 KiB (3 workgroups per CU) with 4 (half the pixels per wave: smaller footprints)
+    static constexpr int WAVE_FLOATS = CPT == 8 ? 4992 : 3200;
 };
 
 // One source view's register-resident 2x2 texel block of a thread: tap values + gradient accumulators (V float4 each).
@@ -788,30 +790,11 @@ template <int V> struct PwBlock {
     float4 g00[V], g01[V], g10[V], g11[V];
 };
 
-template <int C, int V, int CK>
-__device__ __forceinline__ void pw_tap_add(float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gp,
-                                           int xi, int yi, int W, const float4 (&g)[V]) {
-    const int wx = xi - w.x0, wy = yi - w.y0;
-    if (use_win && wx >= 0 && wx < w.w && wy >= 0 && wy < w.h) {
-        float* p = win + (wy * w.w + wx) * C;
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float4 a = *reinterpret_cast<float4*>(p + CK * k);
-            a.x += g[k].x; a.y += g[k].y; a.z += g[k].z; a.w += g[k].w;
-            *reinterpret_cast<float4*>(p + CK * k) = a;
-        }
-    } else {
-        float* p = gp + ((size_t)yi * W + xi) * C;
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 0, g[k].x); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 1, g[k].y);
-            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 2, g[k].z); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 3, g[k].w);
-        }
-    }
-}
-
 // The pixel groups (LPP consecutive lanes) whose `want` is set add their accumulators to the wave's window, one group
-// per iteration of a wave-uniform loop.  win / gp already include the lane's channel offset.
+// per iteration of a wave-uniform loop.  win / gp already include the lane's channel offset.  Within an iteration all
+// LDS reads of the block (4 taps x V float4) are issued before the first add: ONE LDS round trip per flush (taps handled
+// one after the other cost eight dependent round trips, ~1000 cycles).  A tap outside the window (or all of them when
+// the window is unusable) goes to global memory with atomics; a tap outside the image is dropped (zero padding).
 template <int C, int V, int CK, int LPP>
 __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlock<V>& blk, int H, int W,
                                                 float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gp) {
@@ -822,19 +805,56 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
             const int cx = blk.cx, cy = blk.cy;
             const bool xin0 = cx >= 0 && cx < W, xin1 = cx + 1 >= 0 && cx + 1 < W;
             const bool yin0 = cy >= 0 && cy < H, yin1 = cy + 1 >= 0 && cy + 1 < H;
-            if (xin0 && yin0) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx, cy, W, blk.g00);
-            if (xin1 && yin0) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx + 1, cy, W, blk.g01);
-            if (xin0 && yin1) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx, cy + 1, W, blk.g10);
-            if (xin1 && yin1) pw_tap_add<C, V, CK>(win, w, use_win, gp, cx + 1, cy + 1, W, blk.g11);
+            const int lx = cx - w.x0, ly = cy - w.y0;
+            const bool wx0 = lx >= 0 && lx < w.w, wx1 = lx + 1 >= 0 && lx + 1 < w.w;
+            const bool wy0 = ly >= 0 && ly < w.h, wy1 = ly + 1 >= 0 && ly + 1 < w.h;
+            const bool img[4] = {xin0 && yin0, xin1 && yin0, xin0 && yin1, xin1 && yin1};
+            const bool inw[4] = {img[0] && use_win && wx0 && wy0, img[1] && use_win && wx1 && wy0,
+                                 img[2] && use_win && wx0 && wy1, img[3] && use_win && wx1 && wy1};
+            const int off[4] = {(ly * w.w + lx) * C, (ly * w.w + lx + 1) * C, ((ly + 1) * w.w + lx) * C, ((ly + 1) * w.w + lx + 1) * C};
+            float4 acc[4][V];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* p = win + (inw[t] ? off[t] : 0);      // a tap that does not go to the window reads texel 0 (discarded)
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[t][k] = *reinterpret_cast<const float4*>(p + CK * k);
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                acc[0][k].x += blk.g00[k].x; acc[0][k].y += blk.g00[k].y; acc[0][k].z += blk.g00[k].z; acc[0][k].w += blk.g00[k].w;
+                acc[1][k].x += blk.g01[k].x; acc[1][k].y += blk.g01[k].y; acc[1][k].z += blk.g01[k].z; acc[1][k].w += blk.g01[k].w;
+                acc[2][k].x += blk.g10[k].x; acc[2][k].y += blk.g10[k].y; acc[2][k].z += blk.g10[k].z; acc[2][k].w += blk.g10[k].w;
+                acc[3][k].x += blk.g11[k].x; acc[3][k].y += blk.g11[k].y; acc[3][k].z += blk.g11[k].z; acc[3][k].w += blk.g11[k].w;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (inw[t]) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) *reinterpret_cast<float4*>(win + off[t] + CK * k) = acc[t][k];
+                }
+            if ((img[0] && !inw[0]) || (img[1] && !inw[1]) || (img[2] && !inw[2]) || (img[3] && !inw[3])) {
+                // rare: footprint larger than the window allowance, or rounding at the hull of the projected box
+                const float4* gsrc4[4] = {blk.g00, blk.g01, blk.g10, blk.g11};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (img[t] && !inw[t]) {
+                        float* p = gp + ((size_t)(cy + (t >> 1)) * W + cx + (t & 1)) * C;
+#pragma unroll
+                        for (int k = 0; k < V; ++k) {
+                            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 0, gsrc4[t][k].x); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 1, gsrc4[t][k].y);
+                            MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 2, gsrc4[t][k].z); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 3, gsrc4[t][k].w);
+                        }
+                    }
+            }
         }
-        m &= ~((LPP == 64 ? ~0ull : ((1ull << LPP) - 1ull)) << (grp * LPP));
+        m &= ~(((1ull << LPP) - 1ull) << (grp * LPP));
         MVS_WAVE_SYNC();   // next group may touch the same texels: keep the DS operations in program order
     }
 }
 
 // MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
 template <int C, int NS_T, int CPT, int MODE>
-__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(2) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
+__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD((CPT == 4 && NS_T <= 2) ? 3 : 2) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
     constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
     using Cfg = PwCfg<C, CPT>;
     constexpr int LPP = Cfg::LPP, BW = Cfg::BW, BH = Cfg::BH, V = Cfg::V;
@@ -1128,6 +1148,7 @@ extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
+static int g_sweep_bwd_cpt = 8;       // knob "bwd_cpt": channels per thread of the per-wave-window backward for <= 2 source views
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
@@ -1140,7 +1161,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1240,8 +1261,12 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
     if (g_sweep_bwd_variant == 0 && a.NS <= 4) {
-        // 8 channels per thread while the register file holds two views' blocks; 4 beyond that
+        // 8 channels per thread while the register file holds two views' blocks; 4 beyond that (knob "bwd_cpt": 4 | 8)
         constexpr int CPT_HI = C >= 16 ? 8 : 4;
+        if (g_sweep_bwd_cpt == 4 || CPT_HI == 4) {
+            if (a.NS == 1) return launch_bwd_pw<C, 1, 4>(a, st);
+            if (a.NS == 2) return launch_bwd_pw<C, 2, 4>(a, st);
+        }
         switch (a.NS) {
             case 1: return launch_bwd_pw<C, 1, CPT_HI>(a, st);
             case 2: return launch_bwd_pw<C, 2, CPT_HI>(a, st);

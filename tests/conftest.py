@@ -51,3 +51,30 @@ def assert_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=4.0, floor=
         "%s max err %.3e vs reference fp32 err %.3e" % (what, float(e_ours.max()), float(e_ref.max()))
     assert float(e_ours.mean()) <= slack * float(e_ref.mean()) + floor * 0.1, \
         "%s mean err %.3e vs reference fp32 err %.3e" % (what, float(e_ours.mean()), float(e_ref.mean()))
+
+
+def assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=4.0, floor=2e-5, what=""):
+    """Gradient parity criterion of the same kind as the forward one: with an fp64 evaluation of the reference's formulas
+    as the truth, the L1 error of every HIP gradient tensor must be of the order of the error the reference's own fp32
+    backward makes on it (train-mode BatchNorm over small batches amplifies fp32 rounding, so a blanket relative bound
+    is either too loose for well-conditioned tensors or too tight for ill-conditioned ones):
+
+        ||ours - t||_1  <=  slack * ||ref32 - t||_1  +  floor * ||t||_1        for every tensor of the dicts,
+
+    where the reference's error on a tensor is not taken below its median error over all tensors of the model (a single
+    tensor on which the reference's rounding happened to cancel is no yardstick).
+
+    ours / ref32 / truth64: {name: tensor} (CPU).  Returns {name: (err_ours, err_ref32)} relative to ||t||_1."""
+    bad, report = [], {}
+    for k, t in truth64.items():
+        t = t.double()
+        norm = float(t.abs().sum()) + 1e-300
+        e_o = float((ours[k].double() - t).abs().sum()) / norm
+        e_r = float((ref32[k].double() - t).abs().sum()) / norm
+        report[k] = (e_o, e_r)
+    typical = sorted(e for _, e in report.values())[len(report) // 2]
+    for k, (e_o, e_r) in report.items():
+        if e_o > slack * max(e_r, typical) + floor:
+            bad.append("%s: HIP err %.3e vs fp32-reference err %.3e (median %.3e)" % (k, e_o, e_r, typical))
+    assert not bad, "%s gradients less accurate than the fp32 reference: %s" % (what, "; ".join(bad))
+    return report

@@ -149,3 +149,14 @@ def test_unsup_loss_oracle_vs_golden(name):
     warped, mask = R.unsup_inverse_warp(R.quarter_image(imgs[:, 1]), kinv, proj, g["depth"])
     assert torch.equal(mask, g["mask1"])
     assert float((warped - g["warped1"]).abs().max()) < 2e-4
+
+
+def test_g3b_ms_homo_warping_with_gradient():
+    """jdacs-ms homo_warping (modules.py:62-104) incl. d/d src_feature, two cases generated by the imported reference."""
+    g = load_golden("g3b_ms_homo_warping")
+    for tag in "ab":
+        src = g[tag + "_src"].clone().requires_grad_(True)
+        w = R.homo_warping_ms(src, g[tag + "_ref_in"], g[tag + "_src_in"], g[tag + "_ref_ex"], g[tag + "_src_ex"], g[tag + "_planes"])
+        close(w, g[tag + "_warped"])
+        w.backward(g[tag + "_grad_out"])
+        close(src.grad, g[tag + "_grad_src"], atol=1e-4)

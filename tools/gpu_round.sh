@@ -64,6 +64,11 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "k2b" ]; then
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sweep or homo" > gpurun_out/pytest_k2.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_k2.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_k2.log | tail -12
+  MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd" gpurun_out/kernels_k2.log
+fi
 if [ "$what" = "k2" ]; then
   # round 2: the rewritten backward of the sweep -- parity, A/B against the round-1 kernel, depth-slab sweep, bench
   timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider -k "sweep or homo or golden_mvsnet or cvp or config2 or config3" > gpurun_out/pytest_k2.log 2>&1
@@ -76,7 +81,8 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(d['ms_per_step'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"
   done
 fi
-if [ "$what" = "sq" ]; then
+if [ "$what" = "sq" ] || [ "$what" = "sqsweep" ]; then
+  [ "$what" = "sqsweep" ] && export MVS_PMC_SWEEP_ONLY=1
   # where the cycles of the big kernels go: SQ busy / wait / MFMA-busy / LDS counters + effective clock (GRBM_GUI_ACTIVE)
   (cd /tmp && timeout 120 rocprofv3 -L > "$OLDPWD/gpurun_out/rocprof_counters.txt" 2>&1); grep -c . gpurun_out/rocprof_counters.txt
   i=0

@@ -29,6 +29,8 @@ for _ in range(3):
     fr = [f.clone().requires_grad_(True) for f in feats]
     var = ops.plane_sweep_variance(fr[0], fr[1:], rot, trans, depth)
     torch.autograd.grad(var, fr, torch.ones_like(var))
+    if os.environ.get("MVS_PMC_SWEEP_ONLY"):
+        continue
     with torch.no_grad():
         v = var.detach()
         lib = ops._lib_for(v)
