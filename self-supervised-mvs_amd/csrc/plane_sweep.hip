@@ -853,8 +853,8 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
 }
 
 // MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
-template <int C, int NS_T, int CPT, int MODE>
-__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD((CPT == 4 && NS_T <= 2) ? 3 : 2) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
+template <int C, int NS_T, int CPT, int MODE, bool PF, int WPS>
+__global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
     constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
     using Cfg = PwCfg<C, CPT>;
     constexpr int LPP = Cfg::LPP, BW = Cfg::BW, BH = Cfg::BH, V = Cfg::V;
@@ -967,44 +967,102 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD((CPT == 4 && NS_T <= 2) ? 3
                     blk[s].t00[k] = blk[s].t01[k] = blk[s].t10[k] = blk[s].t11[k] = blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] =
                         blk[s].g11[k] = z4;
             }
+            // where view s samples at depth `dep`: base texel + fractions (the forward kernel's arithmetic)
+            auto locate = [&](int s, float dep, int& x0, int& y0, float& wx, float& wy) {
+                const float zz = fmaf(rz[s], dep, tz[s]);
+                float iz = MVS_RCP(zz);
+                iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
+                const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
+                const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
+                const float fx = floorf(ix), fy = floorf(iy);
+                wx = ix - fx; wy = iy - fy;
+                x0 = MVS_F2I(fx); y0 = MVS_F2I(fy);
+            };
+            // the 2x2 block with base texel (x0, y0) of view s: zero where a tap is outside the image
+            auto gather = [&](int s, int x0, int y0, float4 (&o00)[V], float4 (&o01)[V], float4 (&o10)[V], float4 (&o11)[V]) {
+                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    o00[k] = (xin0 && yin0) ? ld4(f + CK * k) : z4;
+                    o01[k] = (xin1 && yin0) ? ld4(f + C + CK * k) : z4;
+                    o10[k] = (xin0 && yin1) ? ld4(f + a.W * C + CK * k) : z4;
+                    o11[k] = (xin1 && yin1) ? ld4(f + a.W * C + C + CK * k) : z4;
+                }
+            };
             const float* __restrict__ gptr = a.gvar + (((size_t)b * a.D + ds) * HW + pix) * C + cq;
             const size_t gstep = (size_t)HW * C;
             float4 g_next[V];
 #pragma unroll
             for (int k = 0; k < V; ++k) g_next[k] = ld4(gptr + CK * k);
-#pragma clang loop unroll(disable)
-            for (int d = ds; d < de; ++d) {
-                const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
-                // phase 1 (nothing of this plane's channel math is live yet): where does each view sample, and which
-                // pixel groups left their 2x2 block -> flush + re-gather
-                float fwx[NS_T], fwy[NS_T];
+            // PF: the block a lane will need on the NEXT plane is requested one plane ahead into staging registers, so the
+            // L2 round trip of a re-gather (every plane SOME pixel of the wave leaves its block) overlaps a plane of arithmetic
+            // instead of stalling the whole wave.  nx / ny / nwx / nwy: the sample position of the plane about to be processed.
+            int nx[NS_T], ny[NS_T];
+            float nwx[NS_T], nwy[NS_T];
+            float4 s00[PF ? NS_T : 1][V], s01[PF ? NS_T : 1][V], s10[PF ? NS_T : 1][V], s11[PF ? NS_T : 1][V];
+            const float* __restrict__ dptr = a.depth + (a.per_pixel ? ((size_t)b * a.D + ds) * HW + pix : (size_t)b * a.D + ds);
+            const size_t dstep = a.per_pixel ? (size_t)HW : 1;
+            float dep_next = dptr[0];
+            if (PF) {
 #pragma unroll
                 for (int s = 0; s < NS_T; ++s) {
-                    const float zz = fmaf(rz[s], dep, tz[s]);
-                    float iz = MVS_RCP(zz);
-                    iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
-                    const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
-                    const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
-                    const float fx = floorf(ix), fy = floorf(iy);
-                    fwx[s] = ix - fx; fwy[s] = iy - fy;
-                    const int x0 = MVS_F2I(fx), y0 = MVS_F2I(fy);
-                    const bool chg = x0 != blk[s].cx || y0 != blk[s].cy;
-                    if (MVS_ANY(chg)) {
-                        float* const gp = a.gsrc[s] + fbase;
-                        pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                       wwin + s * VIEW_FLOATS + cq, w[s], use[s], gp);
-                        if (chg) {
-                            blk[s].cx = x0; blk[s].cy = y0;
-                            const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
-                            const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
-                            const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                    locate(s, dep_next, nx[s], ny[s], nwx[s], nwy[s]);
+                    gather(s, nx[s], ny[s], s00[PF ? s : 0], s01[PF ? s : 0], s10[PF ? s : 0], s11[PF ? s : 0]);
+                }
+                if (ds + 1 < de) dep_next = dptr[dstep];
+            }
+#pragma clang loop unroll(disable)
+            for (int d = ds; d < de; ++d) {
+                float fwx[NS_T], fwy[NS_T];
+                if (PF) {
+                    // (a) lanes whose sample point left their block: flush the accumulators, take over the staged block
 #pragma unroll
-                            for (int k = 0; k < V; ++k) {
-                                blk[s].t00[k] = (xin0 && yin0) ? ld4(f + CK * k) : z4;
-                                blk[s].t01[k] = (xin1 && yin0) ? ld4(f + C + CK * k) : z4;
-                                blk[s].t10[k] = (xin0 && yin1) ? ld4(f + a.W * C + CK * k) : z4;
-                                blk[s].t11[k] = (xin1 && yin1) ? ld4(f + a.W * C + C + CK * k) : z4;
-                                blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
+                    for (int s = 0; s < NS_T; ++s) {
+                        const bool chg = nx[s] != blk[s].cx || ny[s] != blk[s].cy;
+                        if (MVS_ANY(chg)) {
+                            pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
+                                                           wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                            if (chg) {
+                                blk[s].cx = nx[s]; blk[s].cy = ny[s];
+#pragma unroll
+                                for (int k = 0; k < V; ++k) {
+                                    blk[s].t00[k] = s00[PF ? s : 0][k]; blk[s].t01[k] = s01[PF ? s : 0][k];
+                                    blk[s].t10[k] = s10[PF ? s : 0][k]; blk[s].t11[k] = s11[PF ? s : 0][k];
+                                    blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
+                                }
+                            }
+                        }
+                        fwx[s] = nwx[s]; fwy[s] = nwy[s];
+                    }
+                    // (b) look one plane ahead: request the blocks that will be entered there
+                    if (d + 1 < de) {
+                        const float dep1 = dep_next;
+                        if (d + 2 < de) dep_next = dptr[(size_t)(d + 2 - ds) * dstep];
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s) {
+                            locate(s, dep1, nx[s], ny[s], nwx[s], nwy[s]);
+                            if (nx[s] != blk[s].cx || ny[s] != blk[s].cy)
+                                gather(s, nx[s], ny[s], s00[PF ? s : 0], s01[PF ? s : 0], s10[PF ? s : 0], s11[PF ? s : 0]);
+                        }
+                    }
+                } else {
+                    // synchronous form (3-4 source views: no registers left for staging)
+                    const float dep = dptr[(size_t)(d - ds) * dstep];
+#pragma unroll
+                    for (int s = 0; s < NS_T; ++s) {
+                        int x0, y0;
+                        locate(s, dep, x0, y0, fwx[s], fwy[s]);
+                        const bool chg = x0 != blk[s].cx || y0 != blk[s].cy;
+                        if (MVS_ANY(chg)) {
+                            pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
+                                                           wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                            if (chg) {
+                                blk[s].cx = x0; blk[s].cy = y0;
+                                gather(s, x0, y0, blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
+#pragma unroll
+                                for (int k = 0; k < V; ++k) blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
                             }
                         }
                     }
@@ -1148,7 +1206,8 @@ extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
-static int g_sweep_bwd_cpt = 8;       // knob "bwd_cpt": channels per thread of the per-wave-window backward for <= 2 source views
+static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": channels per thread of the per-wave-window backward for <= 2 source views
+static int g_sweep_bwd_pf = 1;        // knob "bwd_pf": one-plane lookahead staging of the next 2x2 block in the per-wave-window backward
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
@@ -1161,7 +1220,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 1},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1238,7 +1297,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     return mvs_check_launch("plane_sweep_variance_fwd");
 }
 
-template <int C, int NS_T, int CPT>
+template <int C, int NS_T, int CPT, bool PF, int WPS>
 static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     using Cfg = PwCfg<C, CPT>;
     a.tiles_x = mvs_cdiv(a.W, 2 * Cfg::BW);
@@ -1252,27 +1311,32 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
     a.no_window = g_sweep_bwd_nowin;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
-    if (a.warp_only) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2>), grid, block, 0, st, a);
-    else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1>), grid, block, 0, st, a);
-    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0>), grid, block, 0, st, a);
+    if (a.warp_only) {
+        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, PF, WPS>), grid, block, 0, st, a);
+    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1, PF, WPS>), grid, block, 0, st, a);
+    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, PF, WPS>), grid, block, 0, st, a);
     return mvs_check_launch("plane_sweep_variance_bwd_pw");
 }
 
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
     if (g_sweep_bwd_variant == 0 && a.NS <= 4) {
-        // 8 channels per thread while the register file holds two views' blocks; 4 beyond that (knob "bwd_cpt": 4 | 8)
+        // <= 2 source views: 4 channels per thread + one-plane lookahead staging of the next block (knobs "bwd_cpt" 4|8,
+        // "bwd_pf" 0|1 keep the other forms for A/B); 3-4 views: 4 channels per thread, synchronous re-gather at 2 waves
+        // per SIMD or staged at 1 wave per SIMD
+        const bool pf = g_sweep_bwd_pf != 0;
         constexpr int CPT_HI = C >= 16 ? 8 : 4;
-        if (g_sweep_bwd_cpt == 4 || CPT_HI == 4) {
-            if (a.NS == 1) return launch_bwd_pw<C, 1, 4>(a, st);
-            if (a.NS == 2) return launch_bwd_pw<C, 2, 4>(a, st);
+        if (a.NS <= 2) {
+            const bool c8 = g_sweep_bwd_cpt == 8 && CPT_HI == 8;
+            if (a.NS == 1) {
+                if (c8) return pf ? launch_bwd_pw<C, 1, CPT_HI, true, 2>(a, st) : launch_bwd_pw<C, 1, CPT_HI, false, 2>(a, st);
+                return pf ? launch_bwd_pw<C, 1, 4, true, 2>(a, st) : launch_bwd_pw<C, 1, 4, false, 3>(a, st);
+            }
+            if (c8) return pf ? launch_bwd_pw<C, 2, CPT_HI, true, 1>(a, st) : launch_bwd_pw<C, 2, CPT_HI, false, 2>(a, st);
+            return pf ? launch_bwd_pw<C, 2, 4, true, 2>(a, st) : launch_bwd_pw<C, 2, 4, false, 3>(a, st);
         }
-        switch (a.NS) {
-            case 1: return launch_bwd_pw<C, 1, CPT_HI>(a, st);
-            case 2: return launch_bwd_pw<C, 2, CPT_HI>(a, st);
-            case 3: return launch_bwd_pw<C, 3, 4>(a, st);
-            default: return launch_bwd_pw<C, 4, 4>(a, st);
-        }
+        if (a.NS == 3) return pf ? launch_bwd_pw<C, 3, 4, true, 1>(a, st) : launch_bwd_pw<C, 3, 4, false, 2>(a, st);
+        return pf ? launch_bwd_pw<C, 4, 4, true, 1>(a, st) : launch_bwd_pw<C, 4, 4, false, 2>(a, st);
     }
     // more than four source views (or knob "sweep_bwd" = 1): view pairs per workgroup, LDS-atomic windows
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);

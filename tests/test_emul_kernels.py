@@ -62,7 +62,7 @@ def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("c,ns,step,hw", [(32, 2, 400.0, (13, 21)), (16, 3, 150.0, (10, 18))])
 def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, variant):
     """Footprints larger than an accumulation window: depth segmentation + global-atomic path (both backward kernels)."""
@@ -75,10 +75,11 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
     depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
-    # variant 3 = the per-wave-window kernel with 4 channels per thread also for <= 2 source views
+    # variant 3 = ... with 8 channels per thread for <= 2 source views, variant 4 = ... without the lookahead staging
     emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
-    emul_lib.call("mvs_set_tuning", b"bwd_cpt", 4 if variant == 3 else 8)
+    emul_lib.call("mvs_set_tuning", b"bwd_cpt", 8 if variant == 3 else 4)
+    emul_lib.call("mvs_set_tuning", b"bwd_pf", 0 if variant == 4 else 1)
     try:
         var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
         gup = torch.randn(var.shape, generator=g)
@@ -86,7 +87,8 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     finally:
         emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_nowin", 0)
-        emul_lib.call("mvs_set_tuning", b"bwd_cpt", 8)
+        emul_lib.call("mvs_set_tuning", b"bwd_cpt", 4)
+        emul_lib.call("mvs_set_tuning", b"bwd_pf", 1)
     got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
     for t in [ref] + srcs:
         t.grad = None

@@ -35,6 +35,16 @@ def _cams(b, ns, h, w):
     return torch.stack(rots, 1), torch.stack(transs, 1)
 
 
+def _param_grads(module, skip=()):
+    return {k: p.grad.detach().cpu() for k, p in module.named_parameters() if p.grad is not None and not k.endswith(tuple(skip))}
+
+
+def _check_param_grads(net, oracle32, oracle64, skip, what):
+    """HIP gradients vs the oracle's fp32 gradients, judged against the oracle evaluated in fp64 (conftest criterion)."""
+    truth = _param_grads(oracle64, skip)
+    return assert_grads_as_accurate_as_fp32_reference(_param_grads(net, skip), _param_grads(oracle32, skip), truth, what=what)
+
+
 @pytest.mark.parametrize("c,ns,per_pixel,alias,ac,dims", [
     (8, 1, False, False, False, (5, 12, 20)),
     (16, 2, True, True, False, (8, 24, 36)),
@@ -83,7 +93,7 @@ def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("c,ns,step", [(32, 2, 60.0), (32, 2, 400.0), (16, 3, 150.0), (32, 4, 90.0)])
 def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     """Backward with footprints that do not fit one accumulation window: depth segmentation and, for the widest range,
@@ -99,10 +109,11 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     refg = ref.to(dev).requires_grad_(True)
     srcg = [s.to(dev).requires_grad_(True) for s in srcs]
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
-    # variant 3 = the per-wave-window kernel with 4 channels per thread also for <= 2 source views
+    # variant 3 = ... with 8 channels per thread for <= 2 source views, variant 4 = ... without the lookahead staging
     lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
-    lib.call("mvs_set_tuning", b"bwd_cpt", 4 if variant == 3 else 8)
+    lib.call("mvs_set_tuning", b"bwd_cpt", 8 if variant == 3 else 4)
+    lib.call("mvs_set_tuning", b"bwd_pf", 0 if variant == 4 else 1)
     try:
         var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
         gup = torch.randn(var.shape, generator=g)
@@ -111,7 +122,8 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     finally:
         lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         lib.call("mvs_set_tuning", b"bwd_nowin", 0)
-        lib.call("mvs_set_tuning", b"bwd_cpt", 8)
+        lib.call("mvs_set_tuning", b"bwd_cpt", 4)
+        lib.call("mvs_set_tuning", b"bwd_pf", 1)
     refc = ref.clone().requires_grad_(True)
     srcc = [s.clone().requires_grad_(True) for s in srcs]
     exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
@@ -151,6 +163,33 @@ def test_golden_homo_warping_and_proj_cost(dev):
     cost.backward(g["grad_out"].to(dev))
     for a, k in ((ref, "grad_ref"), (srcs[0], "grad_src0"), (srcs[1], "grad_src1")):
         assert float((a.grad.cpu() - g[k]).abs().max()) < 2e-3 * max(1.0, float(g[k].abs().max()))
+
+
+def test_golden_ms_homo_warping(dev):
+    """the jdacs-ms `homo_warping` wrapper itself (jdacs-ms/models/modules.py:62-104) on the GPU against
+    the fixtures the imported reference produced: `g3.warped_ms` (forward) and `g3b` (two cases, forward + d/d src)."""
+    from mvs_amd.jdacs_ms.models.modules import homo_warping
+    g = load_golden("g3_proj_cost")
+    w = homo_warping(g["src_fea0"].to(dev), g["ref_in"].to(dev), g["src_in"][:, 0].to(dev), g["ref_ex"].to(dev),
+                     g["src_ex"][:, 0].to(dev), g["planes"].to(dev))
+    assert float((w.cpu() - g["warped_ms"]).abs().max()) < 1e-3
+    g = load_golden("g3b_ms_homo_warping")
+    for tag in "ab":
+        t = {k[2:]: v for k, v in g.items() if k.startswith(tag + "_")}
+        src = t["src"].to(dev).requires_grad_(True)
+        w = homo_warping(src, t["ref_in"].to(dev), t["src_in"].to(dev), t["ref_ex"].to(dev), t["src_ex"].to(dev), t["planes"].to(dev))
+        assert w.shape == t["warped"].shape
+        with torch.no_grad():
+            rot, trans = R.relative_projection(R.ms_projection(t["src_in"], t["src_ex"]), R.ms_projection(t["ref_in"], t["ref_ex"]))
+            t64 = R.warp_features(t["src"].double(), rot.double(), trans.double(), t["planes"].double())
+        # on-device inverse of the ill-conditioned P_src P_ref^-1 (DESIGN.md section 3): loose absolute bound on the values,
+        # plus the accuracy criterion with the rotation shared bit-for-bit
+        assert float((w.detach().cpu() - t["warped"]).abs().max()) < 1e-3
+        from mvs_amd import ops
+        w2 = ops.HomoWarp.apply(src, rot.to(dev), trans.to(dev), t["planes"].to(dev), False)
+        assert_as_accurate_as_fp32_reference(w2.detach().cpu(), t["warped"], t64, what="ms homo_warping " + tag)
+        w.backward(t["grad_out"].to(dev))
+        assert float((src.grad.cpu() - t["grad_src"]).abs().max()) < 1e-3 * max(1.0, float(t["grad_src"].abs().max()))
 
 
 def test_golden_softargmin(dev):
@@ -237,7 +276,7 @@ def test_conv_cout8_forms_and_tile_orders(dev, cin, dims, k8, xcd):
         lib.call("mvs_set_tuning", b"xcd", _lib.DEFAULT_TUNING["xcd"])
 
 
-def _run_regnet_golden(dev, net, g, has_second):
+def _run_regnet_golden(dev, net, g, has_second, oracle_cls):
     net.load_state_dict(state_dict_from(g))
     net = net.to(dev).train()
     x = g["x"].to(dev).requires_grad_(True)
@@ -245,9 +284,18 @@ def _run_regnet_golden(dev, net, g, has_second):
     yt = g["y_train"] if g["y_train"].dim() == 5 else g["y_train"].unsqueeze(1)
     assert float((y.cpu() - yt).abs().max()) < 1e-3 * max(1.0, float(yt.abs().max()))
     y.backward(g["grad_out"].view_as(y).to(dev))
+    # truth: the oracle's regulariser in fp64 on the same inputs; yardstick: the reference's own fp32 gradients (fixture)
+    o64 = oracle_cls()
+    o64.load_state_dict({k: v for k, v in state_dict_from(g).items()})
+    o64 = o64.double().train()
+    x64 = g["x"].double().requires_grad_(True)
+    y64 = o64(x64)
+    y64.backward(g["grad_out"].view_as(y64).double())
+    ours = {"x": x.grad.cpu(), **{k: p.grad.cpu() for k, p in net.named_parameters()}}
+    ref32 = {"x": g["grad_x"], **{k: g["grad." + k] for k, _ in net.named_parameters()}}
+    truth = {"x": x64.grad, **{k: p.grad for k, p in o64.named_parameters()}}
+    assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth, what="regulariser golden")
     assert rel_l1(x.grad.cpu(), g["grad_x"]) < 5e-3
-    for k, p in net.named_parameters():
-        assert rel_l1(p.grad.cpu(), g["grad." + k]) < 5e-3, k
     sd = net.state_dict()
     for k, v in g.items():
         if k.startswith("after1.") and "num_batches" not in k:
@@ -266,7 +314,7 @@ def _run_regnet_golden(dev, net, g, has_second):
 
 def test_golden_costregnet_mvs(dev):
     from mvs_amd.jdacs.models.mvsnet import CostRegNet
-    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_mvs"), True)
+    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_mvs"), True, R.OracleCostRegNet)
 
 
 def _oracle64_mvsnet(g, loss_fn):
@@ -383,40 +431,67 @@ def test_config2_full_size_properties_and_gpu_oracle(dev):
     assert float((dep - e_dep).abs().max()) < 1e-2 and float((conf - e_conf).abs().max()) < 1e-4
 
 
-def test_config2_train_step_vs_gpu_oracle(dev):
-    """MVSNet fwd+bwd at a reduced config-2 aspect (N=3, 256x320, D=96; full size is bench.py's job):
-    depth rel-L1 <= 1e-3 and parameter gradients vs the oracle's torch ops on the same GPU."""
-    from mvs_amd.jdacs.models.mvsnet import MVSNet
+def _mvsnet_train_step_three_ways(dev, n, ih, iw, nd, seed, dev64):
+    """One MVSNet training step (forward, mvsnet_loss, backward) through (a) the HIP path, (b) the oracle's fp32 torch ops on
+    the same GPU ("the reference GPU path"), (c) the oracle in fp64 on `dev64` (the truth).  Returns (net, o, oracle32, r,
+    oracle64, t)."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
     torch.manual_seed(0)
     net = MVSNet(refine=False)
     with torch.no_grad():
         net.cost_regularization.prob.weight.mul_(50.0)
     oracle = R.OracleMVSNet(refine=False)
     oracle.load_state_dict(net.state_dict())
-    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 3, 256, 320, 96, seed=1)
+    oracle64 = R.OracleMVSNet(refine=False)
+    oracle64.load_state_dict(net.state_dict())
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=seed)
     net = net.to(dev).train()
     oracle = oracle.to(dev).train()
+    oracle64 = oracle64.double().to(dev64).train()
+    cap = {}
+    hk = net.cost_regularization.register_forward_hook(lambda m, i, o: cap.update(logits=o.squeeze(1)))
     o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
-    r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
-    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    hk.remove()
+    o["logits"] = cap["logits"]
+    r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev), return_intermediates=True)
+    t = oracle64(imgs.double().to(dev64), proj.double().to(dev64), dv.double().to(dev64), return_intermediates=True)
     gt = r["depth"].detach() + 3.0
     mask = torch.ones_like(gt)
-    from mvs_amd.jdacs.models.mvsnet import mvsnet_loss
     mvsnet_loss(o["depth"], gt, mask).backward()
     R.mvsnet_loss(r["depth"], gt, mask).backward()
-    bad = []
-    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
-        if k.endswith("prob.bias"):
-            continue
-        e = rel_l1(p.grad, q.grad)
-        if e > 5e-2:
-            bad.append((k, e))
-    assert not bad, bad
+    R.mvsnet_loss(t["depth"], gt.double().to(dev64), mask.double().to(dev64)).backward()
+    return net, o, oracle, r, oracle64, t
+
+
+def test_config2_train_step_vs_gpu_oracle(dev):
+    """MVSNet fwd+bwd at a reduced config-2 aspect (N=3, 256x320, D=96): depth rel-L1 <= 1e-3, logits and parameter
+    gradients as accurate as the oracle's fp32 torch ops on the same GPU, both judged against the oracle in fp64 (CPU)."""
+    net, o, oracle, r, oracle64, t = _mvsnet_train_step_three_ways(dev, 3, 256, 320, 96, 1, torch.device("cpu"))
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    assert_as_accurate_as_fp32_reference(o["logits"].detach().cpu(), r["logits"].detach().cpu(), t["logits"].detach(), floor=1e-5,
+                                         what="logits (256x320, D=96)")
+    _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet 256x320 D=96")
+
+
+def test_config2_full_size_train_step_vs_gpu_oracle(dev):
+    """BASELINE configs[1] at its real size (N=3, 640x512, D=192, fp32): forward AND backward of the whole model against the
+    oracle's torch ops on the same GPU (the 409 ms/step "reference GPU path"), with the oracle in fp64 on the GPU as the
+    truth for the gradient criterion."""
+    net, o, oracle, r, oracle64, t = _mvsnet_train_step_three_ways(dev, 3, 512, 640, 192, 1, dev)
+    assert o["depth"].shape == (1, 128, 160)
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3                                   # BASELINE tolerance
+    assert rel_l1(o["depth"].double(), t["depth"]) < 1e-3
+    assert float((o["photometric_confidence"] - r["photometric_confidence"]).abs().mean()) < 2e-3
+    assert_as_accurate_as_fp32_reference(o["logits"].detach().cpu(), r["logits"].detach().cpu(), t["logits"].detach().cpu(), floor=1e-5,
+                                         what="logits (config 2, full size)")
+    rep = _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet config 2 full size")
+    worst = max(rep.items(), key=lambda kv: kv[1][0])
+    print("config-2 full-size gradients: worst HIP error %.2e (%s), fp32 torch-ops error there %.2e" % (worst[1][0], worst[0], worst[1][1]))
 
 
 def test_golden_costregnet_cvp(dev):
     from mvs_amd.jdacs_ms.models.network import CostRegNet
-    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_cvp"), False)
+    _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_cvp"), False, R.OracleCostRegNetMS)
 
 
 def test_golden_cvpmvsnet_end_to_end(dev):
@@ -441,8 +516,11 @@ def test_golden_cvpmvsnet_end_to_end(dev):
     assert float((out["prob_confidence"].cpu() - g["conf"]).abs().mean()) < 5e-3
 
 
-def test_cvp_three_level_train_step_vs_gpu_oracle(dev):
-    """CVP-MVSNet N=5 (nsrc 4), 3 levels, fwd+bwd vs the oracle's torch ops on the same GPU."""
+@pytest.mark.parametrize("ih,iw,with_grad", [(128, 160, True), (864, 1152, False)])
+def test_cvp_three_level_train_step_vs_gpu_oracle(dev, ih, iw, with_grad):
+    """CVP-MVSNet N=5 (nsrc 4), 3 levels, vs the oracle's torch ops on the same GPU: forward + backward (gradient criterion
+    against the oracle in fp64) at 128x160, and the forward at BASELINE configs[3]'s real size (final level 1152x864,
+    D = (48, 8, 8))."""
     from mvs_amd.jdacs_ms.models.network import CVPMVSNet
     torch.manual_seed(0)
     args = R.cvp_args(nsrc=4, nscale=3, mode="train")
@@ -450,29 +528,34 @@ def test_cvp_three_level_train_step_vs_gpu_oracle(dev):
     oracle = R.OracleCVPMVSNet(args)
     oracle.load_state_dict(net.state_dict())
     g = torch.Generator().manual_seed(4)
-    ih, iw = 128, 160
-    ref_img = torch.randn(1, 3, ih, iw, generator=g)
-    src_imgs = torch.randn(1, 4, 3, ih, iw, generator=g)
+    # smooth random images (white noise at 1152x864 makes the refinement levels' depth updates ill-conditioned)
+    ref_img = F.avg_pool2d(torch.randn(1, 3, ih, iw, generator=g), 5, 1, 2)
+    src_imgs = F.avg_pool2d(torch.randn(4, 3, ih, iw, generator=g), 5, 1, 2).unsqueeze(0)
     K, E = R.synthetic_cameras(5, ih, iw, iw)
     ins = [ref_img, src_imgs, K.unsqueeze(0), K.view(1, 1, 3, 3).repeat(1, 4, 1, 1), E[0].unsqueeze(0),
            E[1:].unsqueeze(0), torch.tensor([425.0]), torch.tensor([425.0 + 47 * 13.5])]
-    ins = [t.to(dev) for t in ins]
     net = net.to(dev).train()
     oracle = oracle.to(dev).train()
-    o = net(*ins)
-    r = oracle(*ins)
+    if not with_grad:
+        with torch.no_grad():
+            o = net(*[t.to(dev) for t in ins])
+            r = oracle(*[t.to(dev) for t in ins])
+        assert o["depth_est_list"][0].shape == (1, ih, iw)
+        for a, b in zip(o["depth_est_list"], r["depth_est_list"]):
+            assert rel_l1(a, b) < 1e-3
+        return
+    o = net(*[t.to(dev) for t in ins])
+    r = oracle(*[t.to(dev) for t in ins])
     for a, b in zip(o["depth_est_list"], r["depth_est_list"]):
         assert rel_l1(a, b) < 1e-3
+    oracle64 = R.OracleCVPMVSNet(args)
+    oracle64.load_state_dict(net.state_dict())
+    oracle64 = oracle64.double().train()
+    t = oracle64(*[x.double() for x in ins])
     sum(d.mean() for d in o["depth_est_list"]).backward()
     sum(d.mean() for d in r["depth_est_list"]).backward()
-    bad = []
-    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
-        if k.endswith("prob0.bias"):
-            continue
-        e = rel_l1(p.grad, q.grad)
-        if e > 5e-2:
-            bad.append((k, e))
-    assert not bad, bad
+    sum(d.mean() for d in t["depth_est_list"]).backward()
+    _check_param_grads(net, oracle, oracle64, ("prob0.bias",), "CVP-MVSNet 3 levels N=5")
 
 
 def test_config3_shape_batch2_five_views_vs_gpu_oracle(dev):
@@ -495,14 +578,12 @@ def test_config3_shape_batch2_five_views_vs_gpu_oracle(dev):
     assert rel_l1(o["depth"], r["depth"]) < 1e-3
     o["depth"].mean().backward()
     r["depth"].mean().backward()
-    bad = []
-    for (k, p), (_, q) in zip(net.named_parameters(), oracle.named_parameters()):
-        if k.endswith("prob.bias"):
-            continue
-        e = rel_l1(p.grad, q.grad)
-        if e > 5e-2:
-            bad.append((k, e))
-    assert not bad, bad
+    oracle64 = R.OracleMVSNet(refine=False)
+    oracle64.load_state_dict({k: v.cpu() for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k},
+                             strict=False)
+    oracle64 = oracle64.double().train()
+    oracle64(imgs.double(), proj.double(), dv.double())["depth"].mean().backward()
+    _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet N=5 batch 2")
     sd, so = net.state_dict(), oracle.state_dict()
     for k in sd:
         if "running" in k:
@@ -511,8 +592,10 @@ def test_config3_shape_batch2_five_views_vs_gpu_oracle(dev):
             assert int(sd[k]) == int(so[k]), k
 
 
-def test_config5_shape_seven_views_eval(dev):
-    """BASELINE config 5 shape class (N=7, large image, D=128) in fp32 eval mode at 800x608 vs the GPU oracle."""
+@pytest.mark.parametrize("ih,iw,nd", [(608, 800, 128), (1184, 1600, 256)])
+def test_config5_shape_seven_views_eval(dev, ih, iw, nd):
+    """BASELINE configs[4] shape (N=7 views) in fp32 eval mode vs the GPU oracle: at 800x608 D=128 and at the config's real
+    size 1600x1184, D=256 (3.9 GB fp32 cost volume resident in HBM, no depth-slab streaming)."""
     from mvs_amd.jdacs.models.mvsnet import MVSNet
     torch.manual_seed(0)
     net = MVSNet(refine=False)
@@ -520,7 +603,7 @@ def test_config5_shape_seven_views_eval(dev):
         net.cost_regularization.prob.weight.mul_(50.0)
     oracle = R.OracleMVSNet(refine=False)
     oracle.load_state_dict(net.state_dict())
-    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 7, 608, 800, 128, seed=5)
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 7, ih, iw, nd, seed=5)
     net = net.to(dev)
     oracle = oracle.to(dev)
     net.train()
@@ -533,9 +616,11 @@ def test_config5_shape_seven_views_eval(dev):
     with torch.no_grad():
         o = net(imgs.to(dev), proj.to(dev), dv.to(dev))
         r = oracle(imgs.to(dev), proj.to(dev), dv.to(dev))
-    assert o["depth"].shape == (1, 152, 200)
+    assert o["depth"].shape == (1, ih // 4, iw // 4)
     assert rel_l1(o["depth"], r["depth"]) < 1e-3
     assert float((o["photometric_confidence"] - r["photometric_confidence"]).abs().mean()) < 5e-3
+    del o, r
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("name", ["g8_unsup_loss", "g8_unsup_loss_n4"])
