@@ -163,3 +163,37 @@ def test_mvsnet_construction_fixes_feature_layout_once():
     import inspect
     assert "memory_format=torch.channels_last)" not in inspect.getsource(MVSNet._forward).replace(
         "contiguous(memory_format=torch.channels_last)", "")
+
+
+@pytest.mark.parametrize("how", ["launcher", "sitecustomize"])
+@pytest.mark.parametrize("sub,stmt,expect", [
+    ("jdacs", "from models.mvsnet import MVSNet, mvsnet_loss\nfrom models.module import homo_warping, ConvBnReLU3D\nm = MVSNet(refine=False)",
+     "mvs_amd.jdacs.models.mvsnet"),
+    ("jdacs-ms", "from models.network import CVPMVSNet, sL1_loss, MSE_loss\nfrom models.modules import proj_cost, calDepthHypo\nm = CVPMVSNet",
+     "mvs_amd.jdacs_ms.models.network"),
+])
+def test_dropin_runs_reference_import_lines_unchanged(tmp_path, sub, stmt, expect, how):
+    """`from models.mvsnet import MVSNet` (jdacs/train.py:28) / `from models.network import CVPMVSNet` (jdacs-ms/train.py:24) in an
+    UNCHANGED script resolve to the drop-in modules, while submodules that are not on the path (models/augmentations.py ...) still
+    come from the script's own `models/` package.  Stand-in tree here: the reference itself is not on the GPU box."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / sub
+    (work / "models").mkdir(parents=True)
+    (work / "models" / "__init__.py").write_text("")
+    (work / "models" / "augmentations.py").write_text("MARK = 'from the working tree'\n")
+    # the working tree's own hot-path files must NOT be the ones that get imported
+    for name in ("mvsnet", "module", "network", "modules"):
+        (work / "models" / (name + ".py")).write_text("raise ImportError('the reference file was imported, not the drop-in')\n")
+    (work / "train.py").write_text(stmt + "\nfrom models.augmentations import MARK\n"
+                                   "print((m if isinstance(m, type) else type(m)).__module__, '|', MARK)\n")
+    env = dict(os.environ)
+    if how == "launcher":
+        cmd = [sys.executable, os.path.join(root, "dropin", "run.py"), "train.py"]
+    else:
+        env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "dropin"), root])
+        cmd = [sys.executable, "train.py"]
+    r = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("%s | from the working tree" % expect), r.stdout
