@@ -1056,11 +1056,13 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                         locate(s, dep, x0, y0, fwx[s], fwy[s]);
                         const bool chg = x0 != blk[s].cx || y0 != blk[s].cy;
                         if (MVS_ANY(chg)) {
+                            // request the new block first (the flush below needs the accumulators and the OLD base texel, not
+                            // the tap values): the L2 round trip of the gather overlaps the LDS round trips of the flush
+                            if (chg) gather(s, x0, y0, blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
                             pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
                                                            wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
                             if (chg) {
                                 blk[s].cx = x0; blk[s].cy = y0;
-                                gather(s, x0, y0, blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
 #pragma unroll
                                 for (int k = 0; k < V; ++k) blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
                             }
@@ -1207,7 +1209,7 @@ extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": channels per thread of the per-wave-window backward for <= 2 source views
-static int g_sweep_bwd_pf = 1;        // knob "bwd_pf": one-plane lookahead staging of the next 2x2 block in the per-wave-window backward
+static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": one-plane lookahead staging of the next 2x2 block in the per-wave-window backward
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key

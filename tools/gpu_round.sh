@@ -64,6 +64,16 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "r2full" ]; then
+  # full GPU parity suite (incl. the full-size config 2 / 4 / 5 cases), K2 A/B, bench
+  timeout 2400 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 900 --durations=15 > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error|worst HIP" gpurun_out/pytest_gpu.log | tail -20; grep -A16 "slowest" gpurun_out/pytest_gpu.log | head -18
+  MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd" gpurun_out/kernels_k2.log
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" gpurun_out/bench.json; grep "ms/step" gpurun_out/bench.err | head -50
+fi
 if [ "$what" = "k2b" ]; then
   timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sweep or homo" > gpurun_out/pytest_k2.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_k2.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_k2.log | tail -12
