@@ -24,23 +24,49 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
-# config 2 of BASELINE.json
-NVIEWS, IMG_H, IMG_W, NDEPTH, FEAT_C = 3, 512, 640, 192, 32
+# BASELINE.json configs (index = --config): [1] is the headline (`metric` is quoted on it) and the default
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+FEAT_C = 32
+CONFIGS = {
+    2: dict(views=3, image=(512, 640), planes=192, kind="train",
+            what="MVSNet N=3 640x512 D=192 fp32 forward+loss+backward+allreduce+Adam, 1 sample/GPU/step (BASELINE configs[1])"),
+    3: dict(views=5, image=(512, 640), planes=192, kind="selfsup",
+            what="JDACS self-supervised step: MVSNet N=5 640x512 D=192 fp32 forward + UnSupLoss (photometric+SSIM+smoothness) + "
+                 "backward + allreduce + Adam, 1 sample/GPU/step (BASELINE configs[2]: batch 8 over 8 GPUs)"),
+    4: dict(views=5, image=(864, 1152), planes=(48, 8, 8), kind="cvp_infer",
+            what="JDACS-MS / CVP-MVSNet 3-level pyramid inference, final 1152x864, D=(48,8,8), N=5, fp32 (BASELINE configs[3]; "
+                 "the reference runs this size in jdacs-ms/test.py only)"),
+    5: dict(views=7, image=(1184, 1600), planes=256, kind="infer",
+            what="MVSNet N=7 1600x1184 D=256 inference, cost volume resident in HBM (BASELINE configs[4])"),
+}
+NVIEWS, (IMG_H, IMG_W), NDEPTH = CONFIGS[2]["views"], CONFIGS[2]["image"], CONFIGS[2]["planes"]
 
 
-def algorithmic_work():
-    """Per-launch algorithmic bytes / flops (stated in DESIGN.md)."""
-    hf, wf = IMG_H // 4, IMG_W // 4
-    vox = NDEPTH * hf * wf
-    return {
-        "sweep_fwd": ("hbm", NVIEWS * FEAT_C * hf * wf * 4 + FEAT_C * vox * 4),            # 511 180 800 B
-        "sweep_bwd": ("hbm", FEAT_C * vox * 4 + 2 * NVIEWS * FEAT_C * hf * wf * 4),       # 519 045 120 B
-        "conv0_fwd": ("mfma", 2 * 27 * 32 * 8 * vox),                                     # 54.4 GFLOP
-        "conv0_wgrad": ("mfma", 2 * 27 * 32 * 8 * vox),
-        "conv0_dgrad": ("mfma", 2 * 27 * 32 * 8 * vox),
+def algorithmic_work(cfg):
+    """Per-launch algorithmic bytes / flops of the tagged kernels (stated in DESIGN.md) and their call tags."""
+    c = CONFIGS[cfg]
+    if c["kind"] == "cvp_infer":
+        return {}, {}
+    n, (ih, iw), nd = c["views"], c["image"], c["planes"]
+    hf, wf = ih // 4, iw // 4
+    vox = nd * hf * wf
+    dims = "1x%dx%dx%d" % (nd, hf, wf)
+    work = {
+        "sweep_fwd": ("hbm", n * FEAT_C * hf * wf * 4 + FEAT_C * vox * 4),            # config 2: 511 180 800 B
+        "conv0_fwd": ("mfma", 2 * 27 * 32 * 8 * vox),                                 # config 2: 54.4 GFLOP
     }
+    tags = {
+        "sweep_fwd": ("mvs_plane_sweep_variance_fwd", "sweep_fwd:N%d:C32:%s" % (n, dims)),
+        "conv0_fwd": ("mvs_conv3d_fwd", "fwd:32>8:s1:%s" % dims),
+    }
+    if c["kind"] in ("train", "selfsup"):
+        work.update({"sweep_bwd": ("hbm", FEAT_C * vox * 4 + 2 * n * FEAT_C * hf * wf * 4),   # config 2: 519 045 120 B
+                     "conv0_wgrad": ("mfma", 2 * 27 * 32 * 8 * vox), "conv0_dgrad": ("mfma", 2 * 27 * 32 * 8 * vox)})
+        tags.update({"sweep_bwd": ("mvs_plane_sweep_variance_bwd", "sweep_bwd:N%d:C32:%s" % (n, dims)),
+                     "conv0_wgrad": ("mvs_conv3d_wgrad", "wgrad:32>8:s1:%s" % dims),
+                     "conv0_dgrad": ("mvs_conv3d_dgrad", "dgrad:32>8:s1:%s" % dims)})
+    return work, tags
 
 
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
@@ -84,25 +110,76 @@ def pmc_traffic():
     return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py; FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)"
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this box from lscpu / os."""
+    import subprocess
+    model, cores, sockets = "unknown", None, 1
+    try:
+        for ln in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Core(s) per socket":
+                cores = int(v)
+            elif k == "Socket(s)":
+                sockets = int(v)
+    except Exception:
+        pass
+    logical = os.cpu_count() or 1
+    phys = cores * sockets if cores else logical
+    try:
+        phys = min(phys, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return model, max(1, phys), logical
+
+
 def cpu_baseline(net_state, seed):
-    """The oracle (a torch-ops port of the reference path) timed on this box's host cores on a bounded
-    sample of the same workload: ONE config-2 training sample (forward + loss + backward)."""
+    """The oracle (a torch-ops port of the reference path, pinned against the imported reference) timed on this box's host
+    cores, SURVEY 8(d) protocol: torch threads = physical cores, 1 warm-up + 3 timed iterations, median.  Bounded sample of
+    the benchmarked workload: ONE config-2 training sample (forward + loss + backward) per iteration; plus the config-1 line
+    (eval forward N=3, 160x128, D=48: BASELINE configs[0], the reference's own CPU-runnable case)."""
     from oracle import ref_torch as R
-    cores = torch.get_num_threads()
-    oracle = R.OracleMVSNet(refine=False)
-    oracle.load_state_dict(net_state)
-    oracle.train()
-    small = R.synthetic_mvsnet_inputs(1, NVIEWS, 64, 96, 16, seed=seed)
-    oracle(*small)["depth"].mean().backward()  # thread-pool / allocator warm-up on a tiny case
-    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=seed)
-    gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0)
-    t0 = time.perf_counter()
-    out = oracle(imgs, proj, dv)
-    R.mvsnet_loss(out["depth"], gt, torch.ones_like(gt)).backward()
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "depth-samples/s", "cores": cores, "kind": "port",
-            "sample": "1 sample of the same workload (MVSNet N=3 640x512 D=192 fp32 fwd+loss+bwd), "
-                      "oracle/ref_torch.py on CPU, %.1f s" % dt}
+    model, phys, logical = host_cpu()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(phys)
+    try:
+        oracle = R.OracleMVSNet(refine=False)
+        oracle.load_state_dict(net_state)
+        oracle.train()
+        imgs, proj, dv = R.synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=seed)
+        gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0)
+
+        def sample():
+            for p in oracle.parameters():
+                p.grad = None
+            t0 = time.perf_counter()
+            out = oracle(imgs, proj, dv)
+            R.mvsnet_loss(out["depth"], gt, torch.ones_like(gt)).backward()
+            return time.perf_counter() - t0
+        sample()                                   # warm-up (thread pool, allocator, oneDNN primitive cache)
+        ts = sorted(sample() for _ in range(3))
+        dt = ts[1]
+        # config 1: eval forward at 160x128, D=48
+        oracle.eval()
+        i1, p1, d1 = R.synthetic_mvsnet_inputs(1, 3, 128, 160, 48, seed=seed)
+        with torch.no_grad():
+            oracle(i1, p1, d1)
+            t1 = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                oracle(i1, p1, d1)
+                t1.append(time.perf_counter() - t0)
+        c1 = sorted(t1)[2]
+    finally:
+        torch.set_num_threads(old_threads)
+    return {"value": 1.0 / dt, "unit": "depth-samples/s", "cores": phys, "kind": "port", "cpu_model": model, "logical_cpus": logical,
+            "seconds_per_sample": dt, "timed_runs_s": [round(t, 3) for t in ts],
+            "sample": "1 warm-up + 3 timed samples (median) of the same workload (MVSNet N=3 640x512 D=192 fp32 fwd+loss+bwd), "
+                      "oracle/ref_torch.py on %d CPU threads = physical cores" % phys,
+            "config1": {"value": 1.0 / c1, "unit": "depth-samples/s", "seconds_per_sample": c1,
+                        "what": "BASELINE configs[0]: MVSNet eval forward N=3 160x128 D=48 on the same CPU, median of 5 after 1 warm-up"}}
 
 
 def main():
@@ -110,10 +187,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs index + 1: 2 (default, the headline metric's config) MVSNet N=3 train step; 3 JDACS "
+                         "self-supervised step N=5; 4 CVP-MVSNet 3-level inference at 1152x864; 5 MVSNet N=7 1600x1184 D=256 inference")
+    ap.add_argument("--dtype", type=str, default="", choices=["", "f32", "bf16"],
+                    help="storage dtype of the cost volume / regulariser activations for --config 5 (default bf16 there; f32 elsewhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gpu-reference", action="store_true",
-                    help="also time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, "
-                         "MIOpen conv3d) = 'the reference GPU path'; reported as reference_gpu_path")
+    ap.add_argument("--gpu-reference", type=int, default=-1,
+                    help="time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, MIOpen conv3d) = "
+                         "'the reference GPU path' -> reference_gpu_path.  Default: on for the default N=1 config-2 run, off otherwise")
     ap.add_argument("--feature-channels-last", type=int, default=1,
                     help="1: run the stock-PyTorch FeatureNet in channels-last (MIOpen NHWC kernels)")
     ap.add_argument("--graph", type=int, default=0,
@@ -173,35 +255,92 @@ def main():
     dev = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = True  # as the reference does (jdacs/train.py:35); FeatureNet uses MIOpen
 
+    cfg = CONFIGS[args.config]
+    nviews, (img_h, img_w), ndepth = cfg["views"], cfg["image"], cfg["planes"]
+    dtype = args.dtype or ("bf16" if args.config == 5 else "f32")
+    if dtype == "bf16" and args.config != 5:
+        raise SystemExit("bench.py: bf16 storage is the inference path of --config 5")
     torch.manual_seed(0)
-    net = MVSNet(refine=False, channels_last_features=bool(args.feature_channels_last))
-    with torch.no_grad():
-        net.cost_regularization.prob.weight.mul_(50.0)
-    state0 = {k: v.clone() for k, v in net.state_dict().items()}
-    net = net.to(dev).train()
-    mdist.broadcast_parameters(net)
-    # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
-    bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
-    # capturable: the step counter lives on the GPU, so a captured optimizer step stays correct when replayed
-    opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
+    train = cfg["kind"] in ("train", "selfsup")
+    bucket = opt = None
+    if cfg["kind"] == "cvp_infer":
+        from types import SimpleNamespace
+        from mvs_amd.jdacs_ms.models.network import CVPMVSNet
+        from mvs_amd.synthetic import synthetic_cameras
+        net = CVPMVSNet(SimpleNamespace(nsrc=nviews - 1, nscale=3, mode="test"))
+        state0 = None
+        net = net.to(dev)
+        g = torch.Generator().manual_seed(1 + rank)
+        K, E = synthetic_cameras(nviews, img_h, img_w, img_w)
+        cvp_in = [torch.randn(1, 3, img_h, img_w, generator=g), torch.randn(1, nviews - 1, 3, img_h, img_w, generator=g),
+                  K.unsqueeze(0), K.view(1, 1, 3, 3).repeat(1, nviews - 1, 1, 1), E[0].unsqueeze(0), E[1:].unsqueeze(0),
+                  torch.tensor([425.0]), torch.tensor([425.0 + 47 * 13.5])]
+        cvp_in = [t.to(dev) for t in cvp_in]
+        with torch.no_grad():
+            net.train()
+            net(*cvp_in)              # one calibration pass: BatchNorm running statistics of the random-init model
+        net.eval()
 
-    imgs, proj, dv = synthetic_mvsnet_inputs(1, NVIEWS, IMG_H, IMG_W, NDEPTH, seed=1 + rank)
-    imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
-    gt = torch.full((1, IMG_H // 4, IMG_W // 4), 650.0, device=dev)
-    mask = torch.ones_like(gt)
+        def fwd_bwd():
+            with torch.no_grad():
+                out = net(*cvp_in)
+            return out["depth_est_list"][0].mean()
+    else:
+        net = MVSNet(refine=False, channels_last_features=bool(args.feature_channels_last))
+        with torch.no_grad():
+            net.cost_regularization.prob.weight.mul_(50.0)
+        state0 = {k: v.clone() for k, v in net.state_dict().items()}
+        net = net.to(dev).train()
+        mdist.broadcast_parameters(net)
+        imgs, proj, dv = synthetic_mvsnet_inputs(1, nviews, img_h, img_w, ndepth, seed=1 + rank)
+        if cfg["kind"] == "selfsup":
+            import torch.nn.functional as F
+            from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+            from mvs_amd.synthetic import synthetic_cameras
+            # smooth textured images: the photometric loss needs an image gradient to be a meaningful workload
+            imgs = F.avg_pool2d(imgs.view(nviews, 3, img_h, img_w), 9, 1, 4).view(1, nviews, 3, img_h, img_w) * 4
+            K, E = synthetic_cameras(nviews, img_h // 4, img_w // 4, img_w)
+            cams = torch.zeros(1, nviews, 2, 4, 4)
+            cams[:, :, 0] = E
+            cams[:, :, 1, :3, :3] = K
+            cams = cams.to(dev)
+            unsup = UnSupLoss()
+        imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
+        gt = torch.full((1, img_h // 4, img_w // 4), 650.0, device=dev)
+        mask = torch.ones_like(gt)
+        if train:
+            # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
+            bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
+            # capturable: the step counter lives on the GPU, so a captured optimizer step stays correct when replayed
+            opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
 
-    def fwd_bwd():
-        bucket.zero()
-        out = net(imgs, proj, dv)
-        loss = mvsnet_loss(out["depth"], gt, mask)
-        loss.backward()
-        bucket.gather()
-        return loss
+            def fwd_bwd():
+                bucket.zero()
+                out = net(imgs, proj, dv)
+                if cfg["kind"] == "selfsup":
+                    loss = unsup(imgs, cams, out["depth"])          # jdacs/train.py:199-210 (standard unsupervised loss)
+                else:
+                    loss = mvsnet_loss(out["depth"], gt, mask)
+                loss.backward()
+                bucket.gather()
+                return loss
+        else:
+            with torch.no_grad():
+                net(imgs, proj, dv)   # one calibration pass (train mode): BatchNorm running statistics of the random-init model
+            net.eval()
+            if dtype == "bf16":
+                net.storage_dtype = torch.bfloat16   # cost volume + regulariser activations stored in bf16, fp32 accumulation
+
+            def fwd_bwd():
+                with torch.no_grad():
+                    out = net(imgs, proj, dv)
+                return out["depth"].mean()
 
     def step():
         loss = fwd_bwd()
-        bucket.all_reduce()   # one RCCL all-reduce of the flat 1.35 MB bucket (no-op at world size 1)
-        opt.step()
+        if train:
+            bucket.all_reduce()   # one RCCL all-reduce of the flat 1.35 MB bucket (no-op at world size 1)
+            opt.step()
         return loss
 
     def barrier():
@@ -233,11 +372,13 @@ def main():
             with torch.cuda.graph(graph_a):
                 static_loss = fwd_bwd()
             with torch.cuda.graph(graph_b, pool=graph_a.pool()):
-                opt.step()
+                if train:
+                    opt.step()
 
             def step():  # noqa: F811
                 graph_a.replay()
-                bucket.all_reduce()
+                if train:
+                    bucket.all_reduce()
                 graph_b.replay()
                 return static_loss
             step()
@@ -261,14 +402,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # live HIP-event timing of the roofline kernels over the timed region, on the launch stream
-    work = algorithmic_work()
-    tagmap = {
-        "sweep_fwd": ("mvs_plane_sweep_variance_fwd", "sweep_fwd:N3:C32:1x192x128x160"),
-        "sweep_bwd": ("mvs_plane_sweep_variance_bwd", "sweep_bwd:N3:C32:1x192x128x160"),
-        "conv0_fwd": ("mvs_conv3d_fwd", "fwd:32>8:s1:1x192x128x160"),
-        "conv0_wgrad": ("mvs_conv3d_wgrad", "wgrad:32>8:s1:1x192x128x160"),
-        "conv0_dgrad": ("mvs_conv3d_dgrad", "dgrad:32>8:s1:1x192x128x160"),
-    }
+    work, tagmap = algorithmic_work(args.config)
     timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
     if not graph_mode:
         lib.profiler = timer   # live HIP-event brackets inside the timed region (eager mode)
@@ -311,7 +445,7 @@ def main():
                 kernels[key] = {"bound": bound, "ms": ms, "achieved": ach, "peak": peak, "unit": unit,
                                 "frac": ach / peak, "calls": calls}
         traffic, traffic_note = None, "not collected"
-        if args.pmc and world == 1:
+        if args.pmc and world == 1 and args.config == 2:    # tools/pmc_driver.py replays the config-2 kernels
             try:
                 traffic, traffic_note = pmc_traffic()
             except Exception as e:  # the bench line must still come out
@@ -330,27 +464,30 @@ def main():
                     "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                     "traffic": kernels[dom].get("traffic"), "traffic_unit": "bytes of HBM traffic per launch", "traffic_source": traffic_note,
                     "ms": kernels[dom]["ms"]}
+        metric = {2: "depth-samples/sec (N=3, 640x512, D=192)", 3: "depth-samples/sec (JDACS self-supervised step, N=5, 640x512, D=192)",
+                  4: "depth-samples/sec (CVP-MVSNet 3-level inference, N=5, 1152x864, D=(48,8,8))",
+                  5: "depth-samples/sec (MVSNet inference, N=7, 1600x1184, D=256)"}[args.config]
         res = {
-            "metric": "depth-samples/sec (N=3, 640x512, D=192)", "value": world * args.steps / dt,
+            "metric": metric, "value": world * args.steps / dt,
             "unit": "depth-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MVSNet N=3 640x512 D=192 fp32 forward+loss+backward+allreduce+Adam, "
-                                   "1 sample/GPU/step (BASELINE configs[1])",
-                       "views": NVIEWS, "image": [IMG_H, IMG_W], "depth_planes": NDEPTH,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": cfg["what"], "baseline_config_index": args.config - 1,
+                       "views": nviews, "image": [img_h, img_w], "depth_planes": ndepth,
                        "global_batch": world, "parallelism": "dp%d" % world},
             "ranks": (dist.get_world_size() if world > 1 else 1),
-            "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if world > 1 else "none (1 rank)",
+            "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if (world > 1 and train) else "none",
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
-            "grad_bucket_bytes": bucket.nbytes,
+            "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:   # rank 0 at N=1 only (bench contract)
             try:
                 res["cpu_baseline"] = cpu_baseline(state0, 1)
             except Exception as e:  # the bench line must still come out
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
-        if args.gpu_reference:
+        want_ref = args.gpu_reference == 1 or (args.gpu_reference < 0 and world == 1 and args.config == 2 and not args.no_cpu_baseline)
+        if want_ref and args.config == 2:
             try:
                 from oracle import ref_torch as R
                 oracle = R.OracleMVSNet(refine=False)

@@ -35,8 +35,10 @@ typedef struct ihipStream_t* hipStream_t; /* same opaque type as <hip/hip_runtim
 int mvs_version(void);              /* 100 == 0.1.0 */
 const char* mvs_last_error(void);   /* thread-local, valid until the next failing call */
 int mvs_is_emulation(void);         /* 0 in the product library */
-/* A/B knobs for measurements/tests: "sweep_fwd" 0 taps through L1 | 1 LDS windows | 2,3 register-cached taps
- * (default 3); "nt" 1 = non-temporal volume stores; "conv_split" 0 = never split Cout tiles over workgroups */
+/* A/B knobs for measurements/tests (full-string keys; an unknown key is MVS_ERR_UNSUPPORTED): "sweep_fwd" 0 taps through
+ * L1 | 1 LDS windows | 2,3 register-cached taps (default 3) | 6 quad-shared projection; "sweep_bwd" 0 per-wave windows |
+ * 1 view pairs + LDS atomics; "bwd_cpt" 4|8, "bwd_pf" 0|1, "bwd_dslab", "bwd_nowin"; "nt", "tile_w", "dslab";
+ * "conv_split", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups".  Process-wide, not part of the data path's contract. */
 int mvs_set_tuning(const char* key, int value);
 
 /* ---- K1/K2: homography warp + variance cost volume -------------------------------------------
@@ -52,6 +54,12 @@ int mvs_set_tuning(const char* key, int value);
 int mvs_plane_sweep_variance_fwd(const float* ref, const float* const* srcs, const float* rot, const float* trans,
                                  const float* depth, int depth_is_per_pixel, int B, int N, int C, int D, int H,
                                  int W, int align_corners, int ms_alias, float* var_out, hipStream_t stream);
+/* The same volume stored in bf16 ([B,D,H,W,C], round to nearest even): the inference path of BASELINE configs[4] (MVSNet
+ * N=7, 1600x1184, D=256: 1.94 GB instead of 3.9 GB).  C in {16,32}; 1, 2, 3, 4 or 6 source views.  The reference has no
+ * reduced-precision path; this replaces the same lines as mvs_plane_sweep_variance_fwd. */
+int mvs_plane_sweep_variance_fwd_bf16(const float* ref, const float* const* srcs, const float* rot, const float* trans,
+                                      const float* depth, int depth_is_per_pixel, int B, int N, int C, int D, int H,
+                                      int W, int align_corners, int ms_alias, void* var_out_bf16, hipStream_t stream);
 /* Backward of the above w.r.t. the feature maps (the reference builds the sampling grid under
  * no_grad, module.py:115).  grad_ref and grad_srcs[i] ([B,H,W,C]) must be ZERO-FILLED by the caller
  * (accumulated with atomics). */
@@ -98,6 +106,19 @@ int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int
                       int Cout, int stride, hipStream_t stream);
 int mvs_convT3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
                       int Cout, int stride, hipStream_t stream);
+
+/* ---- bf16-storage inference path of CostRegNet (BASELINE configs[4]) ------------------------------------------------
+ * The same layers (jdacs/models/mvsnet.py:40-63) evaluated as in jdacs/eval.py:143 (eval mode, no_grad) with activations
+ * stored in bf16 and fp32 accumulation (v_mfma_f32_16x16x32_bf16).  x, skip: bf16 [B,D,H,W,C]; w: the fp32 parameter;
+ * y: bf16, or fp32 when out_is_f32 (the probability layer's logits).  transposed: stride 2 only.  Epilogue as
+ * mvs_conv3d_fwd without statistics.  Supported (Cin -> Cout): the network's layer shapes -- stride 1: 32->8, 8->8, 16->8,
+ * 16->16, 32->32, 64->64, 8->1, 16->1; stride 2: 8->16, 16->32, 32->64; transposed: 64->32, 32->16, 16->8.
+ * ws: mvs_conv3d_bf16_workspace_bytes(...) bytes (packed bf16 weight image), 16-byte aligned. */
+long long mvs_conv3d_bf16_workspace_bytes(int Cin, int Cout, int stride, int transposed);
+int mvs_conv3d_bf16_fwd(const void* x_bf16, const float* w, void* y, void* ws, int B, int D, int H, int W, int Cin, int Cout,
+                        int stride, int transposed, const float* scale, const float* shift, const void* skip_bf16, int relu,
+                        int out_is_f32, hipStream_t stream);
+int mvs_cast_f32_bf16(const float* x, void* y_bf16, long long n, hipStream_t stream);   /* n % 4 == 0 */
 
 /* ---- BatchNorm3d (+ReLU, + post-ReLU skip add) on channels-last [V][C], V = B*D*H*W ------------
  * Replace nn.BatchNorm3d + F.relu of ConvBnReLU3D (module.py:35-42) and of the deconv blocks

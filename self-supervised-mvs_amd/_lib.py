@@ -23,6 +23,10 @@ SIGNATURES = {
     "mvs_is_emulation": (_i, []),
     "mvs_set_tuning": (_i, [C.c_char_p, _i]),
     "mvs_plane_sweep_variance_fwd": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
+    "mvs_plane_sweep_variance_fwd_bf16": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
+    "mvs_conv3d_bf16_workspace_bytes": (_ll, [_i] * 4),
+    "mvs_conv3d_bf16_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _s]),
+    "mvs_cast_f32_bf16": (_i, [_f, _f, _ll, _s]),
     "mvs_plane_sweep_variance_bwd": (_i, [_f, _f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                           _f, C.POINTER(C.c_void_p), _s]),
     "mvs_homo_warp_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),

@@ -42,6 +42,15 @@ static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
 #define MVS_MFMA_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 // cbsz = 4: the A operand of block `abid` (lanes 4*abid .. 4*abid+3) is broadcast to all 16 blocks
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (abid), 0)
+// bf16 MFMA (inference path): 8 bf16 per lane for A and B, k = 8*(lane>>4)+j for both; D col = lane&15, row = 4*(lane>>4)+r
+typedef __bf16 mvs_bf16x8 __attribute__((ext_vector_type(8)));
+#define MVS_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// two fp32 -> packed bf16 pair (lo in bits 0..15), round to nearest even: v_cvt_pk_bf16_f32
+typedef __bf16 mvs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mvs_f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ unsigned mvs_cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((mvs_f32x2){lo, hi}, mvs_bf16x2));
+}
 #define MVS_NT_STORE4(ptr, o) \
     __builtin_nontemporal_store((f32x4){(o).x, (o).y, (o).z, (o).w}, reinterpret_cast<f32x4*>(ptr))
 // Address-space-explicit float atomics: a generic (flat) pointer makes hipcc emit flat_atomic_add_f32 even

@@ -39,6 +39,7 @@ struct SweepArgs {
     int tiles_x, tiles_y;
     int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
     int no_window;   // test knob "bwd_nowin": per-wave-window backward sends every flush down its global-atomic path
+    int bf16_out;    // forward: the volume is stored in bf16 (inference path)
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
 };
 
@@ -204,8 +205,11 @@ template <int C, int CPT> struct TileC {
 // lanes, so lane q computes only view q % NS_T and the others fetch (wx, wy, x0, y0) with quad-broadcast DPP moves
 // instead of recomputing them: ~20 (NS_T = 2) / ~70 (NS_T = 4) fewer VALU instructions per plane in a kernel whose VALU
 // is busy 73 % of the time.  Bit-identical results.  Variant 6 of the "sweep_fwd" knob; not yet measured on the GPU.
-template <int C, int NS_T, int CPT, bool QS = false>
+// BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns 8
+// CONSECUTIVE channels so that its 8 values are one 16-byte store and the 4 lanes of a pixel write one 64-byte segment.
+template <int C, int NS_T, int CPT, bool QS = false, bool BF = false>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
+    static_assert(!BF || CPT == 8, "bf16 store: 8 channels per thread");
     constexpr int V = CPT / 4;                     // float4s per tap per thread
     static_assert(!QS || (C == 32 && CPT == 8 && (NS_T == 2 || NS_T == 4)), "quad sharing needs 4 lanes per pixel");
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const float xf = (float)x, yf = (float)y;
     // channel of float4 k of lane q: 4q + 4*LPP*k, so that ONE store instruction writes whole 64-byte segments
     // (with CPT*q + 4k every store instruction wrote 16 of each 32 bytes: 5 % slower, profiles/r01_run19_kernels.log)
-    const int cq = 4 * q;
-    constexpr int ck = 4 * LPP;
+    const int cq = BF ? CPT * q : 4 * q;
+    constexpr int ck = BF ? 4 : 4 * LPP;
     const size_t fbase = (size_t)b * HW * C + cq;
     float4 r[V], r2[V];
 #pragma unroll
@@ -325,7 +329,9 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
             }
         }
-        float* __restrict__ outp = a.var + (((size_t)b * a.D + d) * HW + pix) * C + cq;
+        const size_t oidx = (((size_t)b * a.D + d) * HW + pix) * C + cq;
+        float* __restrict__ outp = a.var + oidx;
+        unsigned packed[2 * V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float4 o;
@@ -334,10 +340,18 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
             m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
             m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
+            if (BF) {
+                packed[2 * k] = mvs_cvt_pk_bf16(o.x, o.y);
+                packed[2 * k + 1] = mvs_cvt_pk_bf16(o.z, o.w);
+                continue;
+            }
             if (QS && !live) continue;
             if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
             else *reinterpret_cast<float4*>(outp + ck * k) = o;
         }
+        if (BF && (!QS || live))
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.var) + oidx) =
+                make_uint4(packed[0], packed[1], packed[2 % (2 * V)], packed[3 % (2 * V)]);
     }
 }
 
@@ -1262,6 +1276,27 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             a.dslab = slab;
         }
         dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
+        if (a.bf16_out) {
+            MVS_REQUIRE(CPT8 == 8, MVS_ERR_UNSUPPORTED, "plane_sweep bf16 volume: needs >= 16 feature channels");
+            constexpr int CB = CPT8 == 8 ? C : 16;       // (C = 8 never gets here; keeps the template instantiable)
+            const int ppbb = TileC<CB, 8>::PPB;
+            a.tile_w = TileC<CB, 8>::TW;
+            a.tiles_x = mvs_cdiv(a.W, a.tile_w);
+            a.tiles_y = mvs_cdiv(a.H, ppbb / a.tile_w);
+            const long tilesb = (long)a.tiles_x * a.tiles_y * a.B;
+            int slab = a.D;
+            while (slab > 8 && tilesb * mvs_cdiv(a.D, slab) < 5000) slab = (slab + 1) / 2;
+            a.dslab = g_sweep_dslab > 0 ? g_sweep_dslab : slab;
+            dim3 gridb(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
+            switch (a.NS) {
+                case 1: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 1, 8, false, true>), gridb, block, 0, st, a); break;
+                case 2: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 2, 8, false, true>), gridb, block, 0, st, a); break;
+                case 3: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 3, 8, false, true>), gridb, block, 0, st, a); break;
+                case 4: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 4, 8, false, true>), gridb, block, 0, st, a); break;
+                case 6: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 6, 8, false, true>), gridb, block, 0, st, a); break;
+            }
+            return mvs_check_launch("plane_sweep_variance_fwd_cached (bf16 volume)");
+        }
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
@@ -1276,6 +1311,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 #undef MVS_CACHED_CASE
         return mvs_check_launch("plane_sweep_variance_fwd_cached");
     }
+    MVS_REQUIRE(!a.bf16_out, MVS_ERR_UNSUPPORTED, "plane_sweep bf16 volume: only the register-cached forward (knob sweep_fwd >= 2) "
+                "with 1, 2, 3, 4 or 6 source views stores bf16");
     if (!a.warp_only && variant == 1) {
         bool done = true;
         switch (a.NS) {
@@ -1400,6 +1437,24 @@ extern "C" int mvs_plane_sweep_variance_fwd(const float* ref, const float* const
     if (C == 32) return launch_fwd<32>(a, stream);
     if (C == 16) return launch_fwd<16>(a, stream);
     return launch_fwd<8>(a, stream);
+}
+
+// Same with the volume stored in bf16 [B,D,H,W,C] (inference path, BASELINE configs[4]); 1, 2, 3, 4 or 6 source views,
+// C = 16 or 32, per-plane or per-pixel hypotheses.
+extern "C" int mvs_plane_sweep_variance_fwd_bf16(const float* ref, const float* const* srcs, const float* rot,
+                                                 const float* trans, const float* depth, int depth_is_per_pixel,
+                                                 int B, int N, int C, int D, int H, int W, int align_corners,
+                                                 int ms_alias, void* var_out_bf16, hipStream_t stream) {
+    SweepArgs a = {};
+    int rc = fill_args(a, ref, srcs, rot, trans, depth, depth_is_per_pixel, B, N, C, D, H, W, align_corners, ms_alias);
+    if (rc) return rc;
+    MVS_REQUIRE(var_out_bf16, MVS_ERR_NULL, "plane_sweep fwd bf16: null output");
+    MVS_REQUIRE(C == 16 || C == 32, MVS_ERR_UNSUPPORTED, "plane_sweep fwd bf16: C must be 16 or 32, got %d", C);
+    MVS_REQUIRE(a.NS <= 4 || a.NS == 6, MVS_ERR_UNSUPPORTED, "plane_sweep fwd bf16: 1, 2, 3, 4 or 6 source views, got %d", a.NS);
+    a.var = (float*)var_out_bf16;
+    a.bf16_out = 1;
+    if (C == 32) return launch_fwd<32>(a, stream);
+    return launch_fwd<16>(a, stream);
 }
 
 // grad_ref and grad_srcs[i] must be ZERO-FILLED by the caller (accumulated atomically)

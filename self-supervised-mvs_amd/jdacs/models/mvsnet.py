@@ -54,6 +54,8 @@ class CostRegNet(nn.Module):
     def forward(self, x):
         if x.dim() != 5 or x.shape[1] != 32:
             raise ValueError("CostRegNet expects [B,32,D,H,W], got %s" % (tuple(x.shape),))
+        if x.dtype == torch.bfloat16 and self.training:
+            raise RuntimeError("CostRegNet: bf16 activations are the eval-mode inference path")
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("CostRegNet needs D,H,W divisible by 8, got %s" % (tuple(x.shape[2:]),))
         keep = {}
@@ -90,6 +92,9 @@ class MVSNet(nn.Module):
         # optional: run the (stock PyTorch) 2-D feature extractor in channels-last so MIOpen picks NHWC kernels
         # and the features arrive in the layout the plane-sweep kernel reads (no NCHW->NHWC transpose)
         self.channels_last_features = channels_last_features
+        # torch.bfloat16: eval-mode inference stores the cost volume and the regulariser's activations in bf16 (fp32
+        # accumulation, fp32 logits / soft-argmin) -- BASELINE configs[4]; training and the default are fp32
+        self.storage_dtype = torch.float32
         self.feature = FeatureNet()
         if channels_last_features:
             # once, at construction: parameter storage must never be re-allocated inside forward() (an optimiser or a
@@ -124,8 +129,11 @@ class MVSNet(nn.Module):
             rt = [ops.relative_projection(p, ref_proj) for p in src_projs]
             rot = torch.stack([r for r, _ in rt], 1)
             trans = torch.stack([t for _, t in rt], 1)
+        if self.storage_dtype == torch.bfloat16 and (self.training or torch.is_grad_enabled()):
+            raise RuntimeError("MVSNet.storage_dtype = bfloat16 is the inference path: call .eval() and run under torch.no_grad()")
         volume_variance = ops.plane_sweep_variance(ref_feature, src_features, rot, trans, depth_values,
-                                                   align_corners=self.align_corners, ms_alias=False)
+                                                   align_corners=self.align_corners, ms_alias=False,
+                                                   out_dtype=self.storage_dtype)
 
         # step 3. cost volume regularisation (MFMA implicit-GEMM convs)
         cost_reg = self.cost_regularization(volume_variance).squeeze(1)

@@ -26,7 +26,18 @@ def _lib_for(t: torch.Tensor) -> _lib.MvsLib:
         raise RuntimeError("mvs_amd: tensor on %s but the HIP library serves '%s' devices; the hot path has no "
                            "CPU fallback" % (t.device, lib.device_type))
     if t.dtype != torch.float32:
-        raise TypeError("mvs_amd: fp32 tensors required, got %s" % t.dtype)
+        raise TypeError("mvs_amd: fp32 tensors required, got %s (bf16 storage exists for the inference path only: "
+                        "MVSNet.storage_dtype / ops.conv3d_forward_bf16)" % t.dtype)
+    return lib
+
+
+def _lib_for_bf16(t: torch.Tensor) -> _lib.MvsLib:
+    lib = _lib.get()
+    if t.device.type != lib.device_type:
+        raise RuntimeError("mvs_amd: tensor on %s but the HIP library serves '%s' devices; the hot path has no "
+                           "CPU fallback" % (t.device, lib.device_type))
+    if t.dtype != torch.bfloat16:
+        raise TypeError("mvs_amd: bf16 tensor expected, got %s" % t.dtype)
     return lib
 
 
@@ -120,9 +131,34 @@ class PlaneSweepVariance(torch.autograd.Function):
         return (None, None, None, None, None, gref, *gsrcs)
 
 
-def plane_sweep_variance(ref, srcs, rot, trans, depth, align_corners=False, ms_alias=False):
-    """ref [B,C,H,W]; srcs list of [B,C,H,W]; rot [B,N-1,3,3]; trans [B,N-1,3]; depth [B,D]|[B,D,H,W]."""
+def plane_sweep_variance(ref, srcs, rot, trans, depth, align_corners=False, ms_alias=False, out_dtype=torch.float32):
+    """ref [B,C,H,W]; srcs list of [B,C,H,W]; rot [B,N-1,3,3]; trans [B,N-1,3]; depth [B,D]|[B,D,H,W].
+    out_dtype=torch.bfloat16: the inference path's bf16 volume (no gradient; BASELINE configs[4])."""
+    if out_dtype == torch.bfloat16:
+        return plane_sweep_variance_bf16(ref, srcs, rot, trans, depth, align_corners, ms_alias)
+    if out_dtype != torch.float32:
+        raise TypeError("plane_sweep_variance: out_dtype must be float32 or bfloat16, got %s" % out_dtype)
     return PlaneSweepVariance.apply(depth, rot, trans, align_corners, ms_alias, ref, *srcs)
+
+
+def plane_sweep_variance_bf16(ref, srcs, rot, trans, depth, align_corners=False, ms_alias=False):
+    """Forward only: variance volume [B,C,D,H,W] stored in bf16 (channels_last_3d), computed in fp32 from fp32 features."""
+    lib = _lib_for(ref)
+    if torch.is_grad_enabled() and (ref.requires_grad or any(s.requires_grad for s in srcs)):
+        raise RuntimeError("mvs_amd: the bf16 cost volume is an inference path (call it under torch.no_grad())")
+    b, c, h, w = ref.shape
+    n = len(srcs) + 1
+    ref_c = as_cl2(ref)
+    srcs_c = [as_cl2(s) for s in srcs]
+    depth_c, per_pixel = _depth_arg(depth, b, h, w)
+    nd = depth_c.shape[1]
+    rot_c = rot.reshape(b, n - 1, 9).contiguous().float()
+    trans_c = trans.reshape(b, n - 1, 3).contiguous().float()
+    var = torch.empty((b, c, nd, h, w), dtype=torch.bfloat16, device=ref.device, memory_format=CL3)
+    lib.call("mvs_plane_sweep_variance_fwd_bf16", _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c), _p(depth_c), per_pixel, b,
+             n, c, nd, h, w, int(align_corners), int(ms_alias), _p(var), _stream(ref),
+             tag="sweep_fwd_bf16:N%d:C%d:%dx%dx%dx%d" % (n, c, b, nd, h, w))
+    return var
 
 
 class HomoWarp(torch.autograd.Function):
@@ -203,6 +239,45 @@ def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None
              cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(parts), _stream(x),
              tag=_ctag("fwdT" if transposed else "fwd", cin, cout, stride, b, d, h, w))
     return y, parts
+
+
+def conv3d_forward_bf16(x, weight, stride=1, transposed=False, scale=None, shift=None, skip=None, relu=False, out_f32=False):
+    """Inference-only C-ABI call: x bf16 [B,Cin,D,H,W] (channels_last_3d), fp32 weight -> y bf16 (fp32 if out_f32) with the
+    folded BatchNorm / bias / ReLU / skip epilogue.  fp32 accumulation on the bf16 MFMA."""
+    lib = _lib_for_bf16(x)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("mvs_amd: the bf16 regulariser is an inference path (call it under torch.no_grad())")
+    x = as_cl3(x)
+    b, cin, d, h, w = x.shape
+    wt = weight.detach().contiguous().float()
+    cout = wt.shape[1] if transposed else wt.shape[0]
+    if (wt.shape[0] if transposed else wt.shape[1]) != cin or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError("weight shape %s does not match %d input channels / 3x3x3" % (tuple(wt.shape), cin))
+    nbytes = lib.raw("mvs_conv3d_bf16_workspace_bytes", cin, cout, stride, int(transposed))
+    if nbytes < 0:
+        raise ValueError("conv3d bf16: unsupported channels %d -> %d" % (cin, cout))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    od, oh, ow = _out_dims(d, h, w, stride, transposed)
+    y = torch.empty((b, cout, od, oh, ow), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device, memory_format=CL3)
+    if skip is not None:
+        if skip.dtype != torch.bfloat16 or skip.shape != y.shape:
+            raise ValueError("skip must be bf16 with the output's shape %s, got %s %s" % (tuple(y.shape), skip.dtype, tuple(skip.shape)))
+        skip = as_cl3(skip)
+    lib.call("mvs_conv3d_bf16_fwd", _p(x), _p(wt), _p(y), _p(ws), b, d, h, w, cin, cout, stride, int(transposed),
+             _p(None if scale is None else scale.contiguous()), _p(None if shift is None else shift.contiguous()), _p(skip),
+             int(relu), int(out_f32), _stream(x), tag=_ctag("fwdT_bf16" if transposed else "fwd_bf16", cin, cout, stride, b, d, h, w))
+    return y
+
+
+def conv_bn_relu3d_eval_bf16(x, weight, gamma, beta, running_mean, running_var, skip, stride, transposed, eps):
+    """Eval-mode ConvBnReLU3D / deconv block on bf16 activations: BatchNorm folded into the conv epilogue."""
+    lib = _lib_for_bf16(x)
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    scale = torch.empty(cout, dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    lib.call("mvs_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), cout, _p(scale), _p(shift),
+             _stream(x))
+    return conv3d_forward_bf16(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
 
 
 def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False):

@@ -17,6 +17,9 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef void* hipStream_t;
@@ -38,6 +41,8 @@ struct Wave {
     pthread_barrier_t bar;
     float fa[2][64];
     float fb[2][64];
+    float fa8[2][64][8];
+    float fb8[2][64][8];
 };
 struct Block {
     pthread_barrier_t bar;
@@ -125,6 +130,36 @@ static inline int __shfl(int v, int src, int width = 64) {
     memcpy(&v, &f, 4);
     return v;
 }
+// v_mfma_f32_16x16x32_bf16: A[i = l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][n = l&15]; D: col = l&15, row = 4*(l>>4)+r.
+// fp32 accumulation of exact bf16 products (the hardware's internal summation order is not specified; tests use a tolerance).
+struct __attribute__((aligned(16))) mvs_bf16x8 { unsigned short v[8]; };
+static inline float emul_bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline f32x4 emul_mfma_16x16x32_bf16(mvs_bf16x8 a, mvs_bf16x8 b, f32x4 c) {
+    emul::Wave* w = emul::cur_wave;
+    unsigned s = emul::xcnt++ & 1u;
+    int l = emul::lane;
+    for (int j = 0; j < 8; ++j) { w->fa8[s][l][j] = emul_bf2f(a.v[j]); w->fb8[s][l][j] = emul_bf2f(b.v[j]); }
+    pthread_barrier_wait(&w->bar);
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int j = 0; j < 8; ++j) acc = fmaf(w->fa8[s][kg * 16 + row][j], w->fb8[s][kg * 16 + col][j], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define MVS_MFMA_16x16x32_BF16(a, b, c) emul_mfma_16x16x32_bf16((a), (b), (c))
+static inline unsigned emul_f2bf(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+static inline unsigned mvs_cvt_pk_bf16(float lo, float hi) { return emul_f2bf(lo) | (emul_f2bf(hi) << 16); }
+
 // wave-wide votes: every lane of the wave calls them (the kernels keep out-of-range lanes alive for that)
 static inline unsigned long long emul_ballot(bool p) {
     emul::Wave* w = emul::cur_wave;

@@ -637,3 +637,76 @@ def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, di
     assert torch.equal(y0, y1)
     if can_dgrad:
         assert torch.equal(gx0, gx1)
+
+
+# ---- bf16-storage inference path (BASELINE configs[4]) -------------------------------------------------------------------
+BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)),
+                   (8, 16, 2, False, (6, 8, 34)), (32, 64, 2, False, (4, 6, 18)), (64, 32, 2, True, (2, 3, 9)), (16, 8, 2, True, (3, 4, 17))]
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", BF16_CONV_CASES)
+def test_conv3d_bf16_inference(emul_lib, cin, cout, stride, transposed, dims):
+    """bf16 activations / fp32 accumulation vs torch's fp32 convolution of the SAME bf16-rounded operands: what is left is the
+    summation order and the bf16 rounding of the output (<= 2^-8 relative)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(7)
+    d, h, w = dims
+    x = torch.randn(2, cin, d, h, w, generator=g).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    wt = torch.randn(wshape, generator=g) * (0.3 / (cin ** 0.5))
+    scale = 0.5 + torch.rand(cout, generator=g)
+    shift = torch.randn(cout, generator=g) * 0.1
+    wr = wt.bfloat16().float()
+    if transposed:
+        ref = F.conv_transpose3d(x.float(), wr, stride=2, padding=1, output_padding=1)
+    else:
+        ref = F.conv3d(x.float(), wr, stride=stride, padding=1)
+    ref_bn = torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+    skip = torch.randn(ref.shape, generator=g).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    with torch.no_grad():
+        y = ops.conv3d_forward_bf16(x, wt, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
+        yb = ops.conv3d_forward_bf16(x, wt, stride, transposed, shift=shift, out_f32=True)     # bias only, fp32 out (prob layer form)
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    exp = ref_bn + skip.float()
+    assert float((y.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
+    assert float((yb - (ref + shift.view(1, -1, 1, 1, 1))).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_plane_sweep_variance_bf16_volume(emul_lib):
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for c, ns, per_pixel in ((32, 2, False), (16, 6, True), (32, 3, False)):
+        b, d, h, w = 1, 5, 11, 19
+        rot, trans = _cams(b, ns, h, w, g)
+        ref = torch.randn(b, c, h, w, generator=g)
+        srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+        depth = (450 + 30 * torch.rand(b, 1, h, w, generator=g) + 20.0 * torch.arange(d).view(1, d, 1, 1)) if per_pixel \
+            else (430 + 35.0 * torch.arange(d)).unsqueeze(0)
+        with torch.no_grad():
+            v32 = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+            v16 = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, out_dtype=torch.bfloat16)
+        assert v16.dtype == torch.bfloat16 and v16.shape == v32.shape
+        assert torch.equal(v16, v32.bfloat16())        # same arithmetic, rounded once at the store
+
+
+def test_mvsnet_bf16_inference_vs_fp32(emul_lib):
+    """End to end on a tiny case: eval-mode MVSNet with bf16 storage vs the fp32 path (the oracle of this path)."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 3, 64, 96, 16, seed=1)
+    net.train()
+    with torch.no_grad():
+        net(imgs, proj, dv)                 # calibration pass: BatchNorm running statistics
+    net.eval()
+    with torch.no_grad():
+        o32 = net(imgs, proj, dv)
+        net.storage_dtype = torch.bfloat16
+        o16 = net(imgs, proj, dv)
+    assert o16["depth"].dtype == torch.float32
+    assert rel_l1(o16["depth"], o32["depth"]) < 1e-2
+    net.train()
+    with pytest.raises(RuntimeError, match="inference path"):
+        net(imgs, proj, dv)

@@ -127,7 +127,7 @@ if [ "$what" = "final" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED" gpurun_out/pytest_gpu.log | tail -8
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -n 3 gpurun_out/smoke.log
-  timeout 900 python bench.py --steps 20 --warmup 5 --time-all-kernels --gpu-reference --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
+  timeout 900 python bench.py --steps 20 --warmup 5 --time-all-kernels --gpu-reference 1 --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; grep "ms/step" gpurun_out/bench.err | head -16
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
   rm -rf gpurun_out/prof
@@ -146,7 +146,7 @@ if [ "$what" = "tests" ] || [ "$what" = "all" ]; then
   tail -n 5 gpurun_out/smoke.log
 fi
 if [ "$what" = "bench" ] || [ "$what" = "all" ]; then
-  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --gpu-reference --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
+  timeout 900 python bench.py --steps 10 --warmup 3 --time-all-kernels --gpu-reference 1 --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; tail -n 60 gpurun_out/bench.err
   timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --feature-channels-last 1 > gpurun_out/bench_featcl.json 2> gpurun_out/bench_featcl.err
   echo "bench(feature channels-last) exit $?"; cat gpurun_out/bench_featcl.json | cut -c1-260
