@@ -60,6 +60,11 @@ def algorithmic_work(cfg):
         "sweep_fwd": ("mvs_plane_sweep_variance_fwd", "sweep_fwd:N%d:C32:%s" % (n, dims)),
         "conv0_fwd": ("mvs_conv3d_fwd", "fwd:32>8:s1:%s" % dims),
     }
+    if cfg == 5:
+        # bf16 storage: the sweep writes C*vox*2 bytes; conv0 at bf16 MFMA rates is HBM bound (reads 32, writes 8 channels in bf16)
+        work.update({"sweep_fwd_bf16": ("hbm", n * FEAT_C * hf * wf * 4 + FEAT_C * vox * 2), "conv0_fwd_bf16": ("hbm", (FEAT_C + 8) * vox * 2)})
+        tags.update({"sweep_fwd_bf16": ("mvs_plane_sweep_variance_fwd_bf16", "sweep_fwd_bf16:N%d:C32:%s" % (n, dims)),
+                     "conv0_fwd_bf16": ("mvs_conv3d_bf16_fwd", "fwd_bf16:32>8:s1:%s" % dims)})
     if c["kind"] in ("train", "selfsup"):
         work.update({"sweep_bwd": ("hbm", FEAT_C * vox * 4 + 2 * n * FEAT_C * hf * wf * 4),   # config 2: 519 045 120 B
                      "conv0_wgrad": ("mfma", 2 * 27 * 32 * 8 * vox), "conv0_dgrad": ("mfma", 2 * 27 * 32 * 8 * vox)})
@@ -72,6 +77,7 @@ def algorithmic_work(cfg):
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
     "sweep_fwd": "plane_sweep_variance_fwd_cached_kernel", "sweep_bwd": "plane_sweep_variance_bwd_pw_kernel",
     "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2>",
+    "sweep_fwd_bf16": "plane_sweep_variance_fwd_cached_kernel<32, 6, 8, false, true>", "conv0_fwd_bf16": "conv_bf16_kernel<0, 32, 8>",
 }
 
 
@@ -182,6 +188,21 @@ def cpu_baseline(net_state, seed):
                         "what": "BASELINE configs[0]: MVSNet eval forward N=3 160x128 D=48 on the same CPU, median of 5 after 1 warm-up"}}
 
 
+def calibrate_bn(net, *inputs):
+    """Inference workloads: one train-mode pass with BatchNorm momentum 1, so the random-init model is evaluated with
+    meaningful running statistics (with the defaults its logits are constant over depth: a degenerate workload)."""
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    with torch.no_grad():
+        net(*inputs)
+    for m, mo in zip(bns, old):
+        m.momentum = mo
+    net.eval()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,10 +297,7 @@ def main():
                   K.unsqueeze(0), K.view(1, 1, 3, 3).repeat(1, nviews - 1, 1, 1), E[0].unsqueeze(0), E[1:].unsqueeze(0),
                   torch.tensor([425.0]), torch.tensor([425.0 + 47 * 13.5])]
         cvp_in = [t.to(dev) for t in cvp_in]
-        with torch.no_grad():
-            net.train()
-            net(*cvp_in)              # one calibration pass: BatchNorm running statistics of the random-init model
-        net.eval()
+        calibrate_bn(net, *cvp_in)    # BatchNorm running statistics := batch statistics of the random-init model
 
         def fwd_bwd():
             with torch.no_grad():
@@ -325,9 +343,7 @@ def main():
                 bucket.gather()
                 return loss
         else:
-            with torch.no_grad():
-                net(imgs, proj, dv)   # one calibration pass (train mode): BatchNorm running statistics of the random-init model
-            net.eval()
+            calibrate_bn(net, imgs, proj, dv)   # BatchNorm running statistics := batch statistics of the random-init model
             if dtype == "bf16":
                 net.storage_dtype = torch.bfloat16   # cost volume + regulariser activations stored in bf16, fp32 accumulation
 

@@ -817,9 +817,32 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
         const int grp = (MVS_FFSLL(m) - 1) / LPP;
         if (lane / LPP == grp) {
             const int cx = blk.cx, cy = blk.cy;
+            const int lx = cx - w.x0, ly = cy - w.y0;
+            if (use_win && lx >= 0 && lx + 1 < w.w && ly >= 0 && ly + 1 < w.h && cx >= 0 && cx + 1 < W && cy >= 0 && cy + 1 < H) {
+                // common case: the whole 2x2 block lies inside the image and the window -> no per-tap tests
+                float* p0 = win + (ly * w.w + lx) * C;
+                float* p1 = p0 + w.w * C;
+                float4 a00[V], a01[V], a10[V], a11[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    a00[k] = *reinterpret_cast<const float4*>(p0 + CK * k); a01[k] = *reinterpret_cast<const float4*>(p0 + C + CK * k);
+                    a10[k] = *reinterpret_cast<const float4*>(p1 + CK * k); a11[k] = *reinterpret_cast<const float4*>(p1 + C + CK * k);
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    a00[k].x += blk.g00[k].x; a00[k].y += blk.g00[k].y; a00[k].z += blk.g00[k].z; a00[k].w += blk.g00[k].w;
+                    a01[k].x += blk.g01[k].x; a01[k].y += blk.g01[k].y; a01[k].z += blk.g01[k].z; a01[k].w += blk.g01[k].w;
+                    a10[k].x += blk.g10[k].x; a10[k].y += blk.g10[k].y; a10[k].z += blk.g10[k].z; a10[k].w += blk.g10[k].w;
+                    a11[k].x += blk.g11[k].x; a11[k].y += blk.g11[k].y; a11[k].z += blk.g11[k].z; a11[k].w += blk.g11[k].w;
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    *reinterpret_cast<float4*>(p0 + CK * k) = a00[k]; *reinterpret_cast<float4*>(p0 + C + CK * k) = a01[k];
+                    *reinterpret_cast<float4*>(p1 + CK * k) = a10[k]; *reinterpret_cast<float4*>(p1 + C + CK * k) = a11[k];
+                }
+            } else {
             const bool xin0 = cx >= 0 && cx < W, xin1 = cx + 1 >= 0 && cx + 1 < W;
             const bool yin0 = cy >= 0 && cy < H, yin1 = cy + 1 >= 0 && cy + 1 < H;
-            const int lx = cx - w.x0, ly = cy - w.y0;
             const bool wx0 = lx >= 0 && lx < w.w, wx1 = lx + 1 >= 0 && lx + 1 < w.w;
             const bool wy0 = ly >= 0 && ly < w.h, wy1 = ly + 1 >= 0 && ly + 1 < w.h;
             const bool img[4] = {xin0 && yin0, xin1 && yin0, xin0 && yin1, xin1 && yin1};
@@ -859,6 +882,7 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
                             MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 2, gsrc4[t][k].z); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 3, gsrc4[t][k].w);
                         }
                     }
+            }
             }
         }
         m &= ~(((1ull << LPP) - 1ull) << (grp * LPP));
@@ -994,9 +1018,17 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
             };
             // the 2x2 block with base texel (x0, y0) of view s: zero where a tap is outside the image
             auto gather = [&](int s, int x0, int y0, float4 (&o00)[V], float4 (&o01)[V], float4 (&o10)[V], float4 (&o11)[V]) {
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                if (x0 >= 0 && x0 + 1 < a.W && y0 >= 0 && y0 + 1 < a.H) {   // common case: all four taps inside the image
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        o00[k] = ld4(f + CK * k); o01[k] = ld4(f + C + CK * k);
+                        o10[k] = ld4(f + a.W * C + CK * k); o11[k] = ld4(f + a.W * C + C + CK * k);
+                    }
+                    return;
+                }
                 const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
                 const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
-                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     o00[k] = (xin0 && yin0) ? ld4(f + CK * k) : z4;

@@ -82,3 +82,20 @@ def assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=8.0, 
             bad.append("%s: HIP err %.3e vs fp32-reference err %.3e (median %.3e)" % (k, e_o, e_r, typical))
     assert not bad, "%s gradients less accurate than the fp32 reference: %s" % (what, "; ".join(bad))
     return report
+
+
+def calibrate_batchnorm(net, *inputs):
+    """One train-mode forward with BatchNorm momentum 1 (running statistics := this batch's statistics), then back to eval.
+    A random-init model evaluated with the DEFAULT running statistics (mean 0, var 1) is degenerate -- feature std 0.03, logits
+    constant over depth to 1e-6, depth == mean(depth_values) everywhere -- and would let any kernel pass
+    an eval-mode comparison."""
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    with torch.no_grad():
+        net(*inputs)
+    for m, mo in zip(bns, old):
+        m.momentum = mo
+    net.eval()

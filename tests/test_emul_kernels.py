@@ -697,16 +697,15 @@ def test_mvsnet_bf16_inference_vs_fp32(emul_lib):
     with torch.no_grad():
         net.cost_regularization.prob.weight.mul_(50.0)
     imgs, proj, dv = R.synthetic_mvsnet_inputs(1, 3, 64, 96, 16, seed=1)
-    net.train()
-    with torch.no_grad():
-        net(imgs, proj, dv)                 # calibration pass: BatchNorm running statistics
-    net.eval()
+    from conftest import calibrate_batchnorm
+    calibrate_batchnorm(net, imgs, proj, dv)    # running statistics := batch statistics (non-degenerate eval model)
     with torch.no_grad():
         o32 = net(imgs, proj, dv)
         net.storage_dtype = torch.bfloat16
         o16 = net(imgs, proj, dv)
     assert o16["depth"].dtype == torch.float32
-    assert rel_l1(o16["depth"], o32["depth"]) < 1e-2
+    assert float(o32["depth"].std()) > 2 * float(dv[0, 1] - dv[0, 0])     # the model is not degenerate
+    assert rel_l1(o16["depth"], o32["depth"]) < 5e-3
     net.train()
     with pytest.raises(RuntimeError, match="inference path"):
         net(imgs, proj, dv)
