@@ -129,13 +129,30 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
         }
         s_tapoff[tid] = ((dz * G::RH + dy) * G::RW + dx) * PITCH;
     }
+    // Weight fragments live in global memory (L2): a k-step that waits for its own fragment pays the full L2 round trip
+    // (first version: 25 k cycles per conv0 tile, 10x the LDS + MFMA time).  Small images (<= 28 fragments: conv0, the
+    // 8- and 16-channel layers) are therefore fetched into registers ONCE, here, so that their round trip overlaps the halo
+    // staging; larger ones run through a ring of PD fragments requested PD k-steps ahead.
+    constexpr int KS1 = (27 * CIN + 31) / 32;            // k-steps of the single class of S1 / S2
+    constexpr bool PRELOAD = GEOM != GEOM_TR2 && KS1 * MB <= 28;
+    constexpr int PD = 4;
+    mvs_bf16x8 areg[PRELOAD ? KS1 : 1][MB];
+    if constexpr (PRELOAD) {
+        const bf16_t* __restrict__ wk0 = a.wp + (size_t)(tid & 63) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) areg[ks][m] = *reinterpret_cast<const mvs_bf16x8*>(wk0 + ((size_t)ks * MB + m) * 512);
+        MVS_SCHED_FENCE();   // keep ALL the fragment loads up here (the scheduler otherwise sinks each next to its MFMA)
+    }
     // ---- stage the halo region (zero outside the volume): all loads first, then the LDS writes ----
     {
         const int g0d = q0d * G::IS - G::PAD, g0h = q0h * G::IS - G::PAD, g0w = q0w * G::IS - G::PAD;
         const bf16_t* __restrict__ xb = a.x + (size_t)b * a.Di * a.Hi * a.Wi * CIN;
         constexpr int NITEMS = NR * CH;
         constexpr int NIT = (NITEMS + 255) / 256;
-        constexpr int BATCH = NIT < 12 ? NIT : 12;
+        constexpr int BMAX = (PRELOAD && KS1 * MB > 16) ? 6 : 12;   // register room next to the preloaded weight fragments
+        constexpr int BATCH = NIT < BMAX ? NIT : BMAX;
 #pragma unroll 1
         for (int k0 = 0; k0 < NIT; k0 += BATCH) {
             uint4 v[BATCH];
@@ -181,19 +198,47 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) acc[r][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bf16_t* __restrict__ wk = a.wp + ((size_t)kbase * MB * 64 + lane) * 8;
-#pragma unroll 2
-        for (int ks = 0; ks < nks; ++ks) {
-            const int kflat = 32 * ks + 8 * kg;
-            const int boff = s_tapoff[cls * 32 + kflat / CIN] + kflat % CIN;
-            mvs_bf16x8 afrag[MB], bfrag[NBW];
+        if constexpr (PRELOAD) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) afrag[m] = *reinterpret_cast<const mvs_bf16x8*>(wk + ((size_t)ks * MB + m) * 512);
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int kflat = 32 * ks + 8 * kg;
+                const int boff = s_tapoff[kflat / CIN] + kflat % CIN;
+                mvs_bf16x8 bfrag[NBW];
 #pragma unroll
-            for (int r = 0; r < NBW; ++r) bfrag[r] = *reinterpret_cast<const mvs_bf16x8*>(halo + rowbase[r] + boff);
+                for (int r = 0; r < NBW; ++r) bfrag[r] = *reinterpret_cast<const mvs_bf16x8*>(halo + rowbase[r] + boff);
 #pragma unroll
-            for (int r = 0; r < NBW; ++r)
+                for (int r = 0; r < NBW; ++r)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) acc[r][m] = MVS_MFMA_16x16x32_BF16(afrag[m], bfrag[r], acc[r][m]);
+                    for (int m = 0; m < MB; ++m) acc[r][m] = MVS_MFMA_16x16x32_BF16(areg[ks][m], bfrag[r], acc[r][m]);
+            }
+        } else {
+            mvs_bf16x8 ring[PD][MB];
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int kc = u < nks ? u : nks - 1;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) ring[u][m] = *reinterpret_cast<const mvs_bf16x8*>(wk + ((size_t)kc * MB + m) * 512);
+            }
+            for (int ks0 = 0; ks0 < nks; ks0 += PD) {
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < nks) {
+                        const int kflat = 32 * ks + 8 * kg;
+                        const int boff = s_tapoff[cls * 32 + kflat / CIN] + kflat % CIN;
+                        mvs_bf16x8 bfrag[NBW];
+#pragma unroll
+                        for (int r = 0; r < NBW; ++r) bfrag[r] = *reinterpret_cast<const mvs_bf16x8*>(halo + rowbase[r] + boff);
+#pragma unroll
+                        for (int r = 0; r < NBW; ++r)
+#pragma unroll
+                            for (int m = 0; m < MB; ++m) acc[r][m] = MVS_MFMA_16x16x32_BF16(ring[u][m], bfrag[r], acc[r][m]);
+                        const int kn = ks + PD < nks ? ks + PD : nks - 1;   // past the end: re-read the last fragment (harmless)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) ring[u][m] = *reinterpret_cast<const mvs_bf16x8*>(wk + ((size_t)kn * MB + m) * 512);
+                    }
+                }
+            }
         }
         kbase += nks;
         // ---- epilogue: folded BatchNorm (or bias) + ReLU + skip, 4 consecutive channels of one voxel per lane ----

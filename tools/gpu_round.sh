@@ -64,6 +64,17 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "bf16b" ]; then
+  MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "bf16 or golden_mvsnet or config1 or config5 or sweep or homo" -s > gpurun_out/pytest_bf16.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_bf16.log; grep -E "passed|failed|FAILED|Error|bf16 vs" gpurun_out/pytest_bf16.log | tail -20
+  MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd" gpurun_out/kernels_k2.log | head -8
+  for c in 5; do
+    timeout 900 python bench.py --config $c --steps 10 --warmup 3 --time-all-kernels > "gpurun_out/bench_config_$c.json" 2> "gpurun_out/bench_config_$c.err"
+    echo "bench --config $c exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['metric'], d['value'], d['ms_per_step'], d['dtype'], {k:(round(v['ms'],3), round(v['frac'],3)) for k,v in d['kernels'].items()}, d['roofline'])" "gpurun_out/bench_config_$c.json"; grep "ms/step" "gpurun_out/bench_config_$c.err" | head -12
+  done
+fi
 if [ "$what" = "bf16" ]; then
   MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "bf16 or golden_mvsnet or ms_homo" -s > gpurun_out/pytest_bf16.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_bf16.log; grep -E "passed|failed|FAILED|Error|bf16 vs" gpurun_out/pytest_bf16.log | tail -20
