@@ -202,6 +202,20 @@ int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int 
 int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
                      int stride, hipStream_t stream);
 
+/* ---- geometric-consistency filter on the path's depth maps ---------------------------------------------
+ * Replaces reproject_with_depth + check_geometric_consistency (jdacs/eval.py:169-224) for ALL source views of one
+ * reference view, and the accumulation of filter_depth (eval.py:372-385): per pixel and source view, project with the
+ * reference depth, look the source depth up (cv2.remap INTER_LINEAR semantics: 1/32-pixel fixed point, border 0), project
+ * back, test |p' - p| < pix_thresh and |d' - d| / d < rel_thresh (1 and 0.01 in the reference).
+ * depth_ref [H,W]; depth_srcs: HOST array of V device pointers [H,W]; mats: DEVICE array of 18 + 42 V doubles =
+ * K_ref^-1 [9], K_ref [9], then per view E_src E_ref^-1 (rows 0-2) [12], K_src [9], K_src^-1 [9], E_ref E_src^-1 (rows 0-2)
+ * [12], each formed in float32 like numpy does in the reference.  Outputs: count [H,W] int32 (geo_mask_sum), depth_sum
+ * [H,W] fp32 (sum of the consistent reprojected depths); optional (NULL to skip) masks [V,H,W] uint8, reproj [V,H,W] fp32
+ * (0 where inconsistent), xy_src [V,2,H,W] fp32 (x2d_src, y2d_src). */
+int mvs_geo_consistency(const float* depth_ref, const float* const* depth_srcs, const double* mats, int V, int H, int W,
+                        float pix_thresh, float rel_thresh, int* count, float* depth_sum, unsigned char* masks, float* reproj,
+                        float* xy_src, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

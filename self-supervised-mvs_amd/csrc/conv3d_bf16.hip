@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     // 8- and 16-channel layers) are therefore fetched into registers ONCE, here, so that their round trip overlaps the halo
     // staging; larger ones run through a ring of PD fragments requested PD k-steps ahead.
     constexpr int KS1 = (27 * CIN + 31) / 32;            // k-steps of the single class of S1 / S2
-    constexpr bool PRELOAD = GEOM != GEOM_TR2 && KS1 * MB <= 28;
+    // (measured, run 9: preloading conv0's 27 fragments cost a wave of occupancy and was 35 % SLOWER than fetching them in the
+    //  loop, 2.39 vs 1.77 ms at config 5 -- only images of <= 8 fragments are preloaded)
+    constexpr bool PRELOAD = GEOM != GEOM_TR2 && KS1 * MB <= 8;
     constexpr int PD = 4;
     mvs_bf16x8 areg[PRELOAD ? KS1 : 1][MB];
     if constexpr (PRELOAD) {

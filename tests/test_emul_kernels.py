@@ -709,3 +709,26 @@ def test_mvsnet_bf16_inference_vs_fp32(emul_lib):
     net.train()
     with pytest.raises(RuntimeError, match="inference path"):
         net(imgs, proj, dv)
+
+
+def test_geo_consistency_filter_golden(emul_lib):
+    """the HIP geometric-consistency filter vs the fixture the reference's own functions produced."""
+    import numpy as np
+    from conftest import GOLDEN
+    from mvs_amd.jdacs.fusion import geo_filter as GF
+    z = np.load(os.path.join(GOLDEN, "g10_geo_filter.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    nsrc = z["depth_src"].shape[0]
+    dref = t(z["depth_ref"])
+    srcs = [t(z["depth_src"][v]) for v in range(nsrc)]
+    for v in range(nsrc):
+        mask, rep, xs, ys = GF.check_geometric_consistency(dref, z["K"][0], z["E"][0], srcs[v], z["K"][v + 1], z["E"][v + 1])
+        assert float((mask.numpy() != z["mask%d" % (v + 1)]).mean()) < 1e-3     # a pixel exactly at a threshold may flip
+        same = mask.numpy() == z["mask%d" % (v + 1)]
+        assert np.allclose(rep.numpy()[same], z["reproj%d" % (v + 1)][same], rtol=1e-6, atol=1e-4)
+        assert np.allclose(xs.numpy(), z["x_src%d" % (v + 1)], atol=1e-4) and np.allclose(ys.numpy(), z["y_src%d" % (v + 1)], atol=1e-4)
+    r = GF.filter_depth_view(dref, t(z["conf_ref"]), z["K"][0], z["E"][0], srcs, list(z["K"][1:]), list(z["E"][1:]))
+    assert float((r["geo_count"].numpy() != z["geo_count"]).mean()) < 2e-3
+    ok = r["geo_count"].numpy() == z["geo_count"]
+    assert np.allclose(r["depth_avg"].numpy()[ok], z["depth_avg"][ok], rtol=1e-6)
+    assert float((r["final_mask"].numpy() != z["final_mask"]).mean()) < 2e-3

@@ -1,4 +1,6 @@
 """Oracle (oracle/ref_torch.py) vs fixtures generated from the imported reference.  CPU only."""
+import os
+
 import pytest
 import torch
 
@@ -160,3 +162,20 @@ def test_g3b_ms_homo_warping_with_gradient():
         close(w, g[tag + "_warped"])
         w.backward(g[tag + "_grad_out"])
         close(src.grad, g[tag + "_grad_src"], atol=1e-4)
+
+
+def test_g10_geometric_consistency_filter():
+    """oracle/geo_filter_np.py vs the outputs of the reference's own functions (jdacs/eval.py:169-224, executed by
+    tests/golden/make_golden_geo.py) and of the aggregation lines eval.py:379-388."""
+    import numpy as np
+    from oracle import geo_filter_np as G
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_geo_filter.npz"))
+    nsrc = z["depth_src"].shape[0]
+    for v in range(1, nsrc + 1):
+        mask, rep, xs, ys = G.check_geometric_consistency(z["depth_ref"], z["K"][0], z["E"][0], z["depth_src"][v - 1], z["K"][v], z["E"][v])
+        assert np.array_equal(mask, z["mask%d" % v]) and np.array_equal(rep, z["reproj%d" % v])
+        assert np.array_equal(xs, z["x_src%d" % v]) and np.array_equal(ys, z["y_src%d" % v])
+        assert 0.05 < mask.mean() < 0.999 or v == 1          # the fixture exercises both outcomes
+    r = G.filter_depth_view(z["depth_ref"], z["conf_ref"], z["K"][0], z["E"][0], list(z["depth_src"]), list(z["K"][1:]), list(z["E"][1:]))
+    assert np.array_equal(r["geo_count"], z["geo_count"]) and np.array_equal(r["final_mask"], z["final_mask"])
+    assert np.array_equal(r["depth_avg"], z["depth_avg"])
