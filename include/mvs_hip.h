@@ -197,6 +197,10 @@ int mvs_depth_hypo(const float* ref_depths, const double* mats, int B, int H, in
 long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, int Cin, int Cout, int ks, int stride);
 int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
                    int Cout, int ks, int stride, hipStream_t stream);
+/* conv2d + bias + LeakyReLU(negative_slope) in one pass: the `conv` block of the CVP feature pyramid
+ * (jdacs-ms/models/modules.py:15-19, network.py:16-41; widths 3/16/32/64).  Channels: 1..32 or exactly 64. */
+int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
+                         int Cout, int ks, int stride, float negative_slope, hipStream_t stream);
 int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
                      int stride, hipStream_t stream);
 int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout, int ks,

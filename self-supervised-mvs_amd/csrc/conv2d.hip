@@ -21,6 +21,8 @@ struct Conv2dArgs {
     int N, Hi, Wi, Ho, Wo, Cin, Cout;   // Ho x Wo: the grid the tiles walk (== the output map for a forward pass)
     int nth, ntw, nb_total;
     int os, py, px, YH, YW;             // output pixel of grid point (oy,ox) is (oy*os + py, ox*os + px) of a YH x YW map
+    int act;                            // 1: LeakyReLU(slope) after the bias (jdacs-ms/models/modules.py:15-19)
+    float slope;
 };
 
 template <int KS, int S>
@@ -167,7 +169,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = (nb0 + nb) * 16 + l15;
-                if (co < a.Cout) o[co] = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
+                if (co < a.Cout) {
+                    float v = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
+                    if (a.act) v = v > 0.f ? v : v * a.slope;
+                    o[co] = v;
+                }
             }
         }
     }
@@ -208,7 +214,8 @@ struct Wgrad2dArgs {
     const float* x;     // [N,Hi,Wi,CX]
     const float* g;     // [N,Ho,Wo,CG]
     float* part;        // [groups][rows = NT*CXP][CGP]
-    int N, Hi, Wi, Ho, Wo, CX, CG, nth, ntw;
+    int N, Hi, Wi, Ho, Wo, CX, CG, nth, ntw;   // CX / CG: channels of THIS pass (a slice of <= 32 when the layer has more)
+    int xs, x0, gs, g0;                         // channel stride and first channel of the slice in x and g
 };
 
 // CXP: CX rounded up to a multiple of 4 (LDS image), MT: m-tiles (16 rows of (tap, cx)) per wave, NB: 16-wide CG tiles
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
         __syncthreads();
         {   // X halo tile: float4 loads (CX % 4 == 0) issued in batches before the LDS writes; odd pixel stride -> scalar writes
             constexpr int XQ = CXP / 4, NIT = (NR * XQ + 255) / 256, BATCH = NIT < 10 ? NIT : 10;
-            const bool vec = (a.CX & 3) == 0;
+            const bool vec = (a.CX & 3) == 0 && (a.xs & 3) == 0 && (a.x0 & 3) == 0;
 #pragma unroll 1
             for (int k0 = 0; k0 < NIT; k0 += BATCH) {
                 float4 v[BATCH];
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
                         const int px = i / XQ, c0 = 4 * (i % XQ), rx = px % G::RW, ry = px / G::RW;
                         const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P;
                         if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
-                            const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.CX + c0;
+                            const float* __restrict__ src = a.x + (((size_t)n * a.Hi + iy) * a.Wi + ix) * a.xs + a.x0 + c0;
                             if (vec) v[k] = *reinterpret_cast<const float4*>(src);
                             else {
                                 if (c0 < a.CX) v[k].x = src[0];
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
         }
         for (int i = tid; i < NPOS * CGP; i += 256) {
             const int p = i / CGP, co = i % CGP, oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
-            gt[i] = (co < a.CG && oy < a.Ho && ox < a.Wo) ? a.g[(((size_t)n * a.Ho + oy) * a.Wo + ox) * a.CG + co] : 0.f;
+            gt[i] = (co < a.CG && oy < a.Ho && ox < a.Wo) ? a.g[(((size_t)n * a.Ho + oy) * a.Wo + ox) * a.gs + a.g0 + co] : 0.f;
         }
         __syncthreads();
         for (int ks = 0; ks < NPOS / 4; ++ks) {
@@ -310,8 +317,9 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
 }
 
 // gw[co][ci][tap] = sum over the partial images part[p][(tap*CXP + ci)][co]  (fixed order)
+// (CX, CG: the slice; the result goes to gw[(co0 + co)][(ci0 + ci)][tap] of a layer with CXT input channels)
 __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int NT, int CX, int CXP,
-                                                                  int CG, int CGP, float* __restrict__ gw) {
+                                                                  int CG, int CGP, float* __restrict__ gw, int CXT, int ci0, int co0) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= CG * CX * NT) return;
     const int tap = e % NT, ci = (e / NT) % CX, co = e / (NT * CX);
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
         s2 += part[(size_t)(p + 2) * stride + off]; s3 += part[(size_t)(p + 3) * stride + off];
     }
     for (; p < nparts; ++p) s0 += part[(size_t)p * stride + off];
-    gw[e] = (s0 + s1) + (s2 + s3);
+    gw[((size_t)(co0 + co) * CXT + ci0 + ci) * NT + tap] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -337,9 +345,12 @@ static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) ||
 static int c2_cc(int ks, int cin) { return ks == 5 ? 8 : (cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32))); }
 
 extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, int Cin, int Cout, int ks, int stride) {
-    if (!c2_shape_ok(ks, stride) || Cin < 1 || Cin > 32 || Cout < 1 || Cout > 32) return -1;
+    if (!c2_shape_ok(ks, stride) || Cin < 1 || Cin > 64 || Cout < 1 || Cout > 64) return -1;
     const int nt = ks * ks;
-    if (op == 2) return (long long)C2_WGRAD_GROUPS * nt * ((Cin + 3) / 4 * 4) * ((Cout + 15) / 16 * 16);
+    if (op == 2) {   // one <= 32 x <= 32 channel slice at a time
+        const int cxs = Cin > 32 ? 32 : (Cin + 3) / 4 * 4, cgs = Cout > 32 ? 32 : (Cout + 15) / 16 * 16;
+        return (long long)C2_WGRAD_GROUPS * nt * cxs * cgs;
+    }
     const int ci = op == 1 ? Cout : Cin, co = op == 1 ? Cin : Cout;   // an input gradient is a forward-style pass on gy
     if (op == 1 && stride == 2) {                                      // four parity-class 3x3 weight images
         const int cc3 = c2_cc(3, ci);
@@ -356,8 +367,9 @@ static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
 }
 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
-                        int Cout, int ks, int stride, int transposed, hipStream_t st) {
+                        int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f) {
     Conv2dArgs a = {};
+    a.act = act; a.slope = slope;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
     a.os = 1; a.py = 0; a.px = 0; a.YH = a.Ho; a.YW = a.Wo;
@@ -367,8 +379,9 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
     const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
     MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1);
     a.wp = ws;
-    const int nb = a.nb_total;   // <= 2 (Cout <= 32)
-    dim3 grid(N * a.nth * a.ntw, 1);
+    const int nb = a.nb_total <= 2 ? a.nb_total : 2;   // 16-wide Cout tiles per workgroup; the rest over blockIdx.y
+    dim3 grid(N * a.nth * a.ntw, mvs_cdiv(a.nb_total, nb));
+    MVS_REQUIRE(a.nb_total % nb == 0, MVS_ERR_UNSUPPORTED, "conv2d: %d output channels not supported (1..32, 33..64 in steps of 32)", Cout);
     if (ks == 5) c2_launch<5, 2, 8>(a, nb, grid, st);
     else if (cc == 4) c2_launch<3, 1, 4>(a, nb, grid, st);
     else if (cc == 8) c2_launch<3, 1, 8>(a, nb, grid, st);
@@ -380,7 +393,9 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
 static int c2_check(const char* what, int N, int H, int W, int Cin, int Cout, int ks, int stride) {
     MVS_REQUIRE(c2_shape_ok(ks, stride), MVS_ERR_UNSUPPORTED, "%s: supports 3x3 stride 1 and 5x5 stride 2, got %dx%d stride %d", what, ks, ks, stride);
     MVS_REQUIRE(N > 0 && H > 0 && W > 0, MVS_ERR_SHAPE, "%s: bad shape N=%d H=%d W=%d", what, N, H, W);
-    MVS_REQUIRE(Cin >= 1 && Cin <= 32 && Cout >= 1 && Cout <= 32, MVS_ERR_UNSUPPORTED, "%s: channels must be 1..32, got %d -> %d", what, Cin, Cout);
+    MVS_REQUIRE(Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64, MVS_ERR_UNSUPPORTED, "%s: channels must be 1..64, got %d -> %d", what, Cin, Cout);
+    MVS_REQUIRE((Cin <= 32 || Cin == 64) && (Cout <= 32 || Cout == 64), MVS_ERR_UNSUPPORTED,
+                "%s: more than 32 channels means exactly 64 (the feature pyramid's widths), got %d -> %d", what, Cin, Cout);
     return MVS_OK;
 }
 
@@ -391,6 +406,16 @@ extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias,
     if (rc) return rc;
     MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_fwd: null pointer argument");
     return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
+}
+
+// the same followed by LeakyReLU(negative_slope): the `conv` block of the feature pyramid (jdacs-ms/models/modules.py:15-19,
+// jdacs-ms/models/network.py:16-41: 3 -> 64 -> 64 -> 64 -> 32 -> 32 -> 32 -> 16 -> 16 -> 16, bias, slope 0.1) in one pass
+extern "C" int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W,
+                                    int Cin, int Cout, int ks, int stride, float negative_slope, hipStream_t stream) {
+    int rc = c2_check("conv2d_lrelu_fwd", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_lrelu_fwd: null pointer argument");
+    return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 1, negative_slope);
 }
 
 // gx [N,H,W,Cin] from gy [N,Ho,Wo,Cout]
@@ -415,6 +440,7 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
             float* wpc = ws + (size_t)cls * total_w;
             MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls);
             a.wp = wpc;
+            MVS_REQUIRE(nbt <= 2, MVS_ERR_UNSUPPORTED, "conv2d_dgrad: the 5x5 stride-2 layers have <= 32 input channels");
             dim3 grid(N * a.nth * a.ntw, 1);
             if (cc == 8) c2_launch<3, 1, 8>(a, nbt, grid, stream);
             else if (cc == 16) c2_launch<3, 1, 16>(a, nbt, grid, stream);
@@ -441,29 +467,37 @@ extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, floa
     int rc = c2_check("conv2d_wgrad", N, H, W, Cin, Cout, ks, stride);
     if (rc) return rc;
     MVS_REQUIRE(x && gy && gw && ws, MVS_ERR_NULL, "conv2d_wgrad: null pointer argument");
-    Wgrad2dArgs a = {};
-    a.x = x; a.g = gy; a.part = ws; a.N = N; a.Hi = H; a.Wi = W; a.CX = Cin; a.CG = Cout;
-    a.Ho = stride == 1 ? H : (H - 1) / 2 + 1; a.Wo = stride == 1 ? W : (W - 1) / 2 + 1;
-    a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
+    const int Ho = stride == 1 ? H : (H - 1) / 2 + 1, Wo = stride == 1 ? W : (W - 1) / 2 + 1;
     const int gmax = g_conv2d_wgrad_groups < 1 ? 1 : (g_conv2d_wgrad_groups > C2_WGRAD_GROUPS ? C2_WGRAD_GROUPS : g_conv2d_wgrad_groups);
-    const int ntiles = N * a.nth * a.ntw, groups = ntiles < gmax ? ntiles : gmax;
-    const int cxp = (Cin + 3) / 4 * 4, nb = mvs_cdiv(Cout, 16);
-    bool ok = true;
-    if (ks == 3) {
-        if (cxp == 4) { if (nb == 1) c2_wgrad_launch<3, 1, 4, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 4, 2>(a, groups, stream); }
-        else if (cxp == 8) { if (nb == 1) c2_wgrad_launch<3, 1, 8, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 8, 2>(a, groups, stream); }
-        else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<3, 1, 16, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 16, 2>(a, groups, stream); }
-        else if (cxp == 32) { if (nb == 1) c2_wgrad_launch<3, 1, 32, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 32, 2>(a, groups, stream); }
-        else ok = false;
-    } else {
-        if (cxp == 8) { if (nb == 1) c2_wgrad_launch<5, 2, 8, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 8, 2>(a, groups, stream); }
-        else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<5, 2, 16, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 16, 2>(a, groups, stream); }
-        else ok = false;
-    }
-    MVS_REQUIRE(ok, MVS_ERR_UNSUPPORTED, "conv2d_wgrad: input channels %d not supported for the %dx%d layer", Cin, ks, ks);
-    rc = mvs_check_launch("conv2d_wgrad");
-    if (rc) return rc;
-    const int nt = ks * ks, n = Cout * Cin * nt;
-    MVS_LAUNCH(conv2d_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, groups, nt, Cin, cxp, Cout, nb * 16, gw);
+    const int nt = ks * ks;
+    // layers wider than 32 channels (the feature pyramid's 64) run as <= 32 x <= 32 channel slices, one after the other
+    for (int ci0 = 0; ci0 < Cin; ci0 += 32)
+        for (int co0 = 0; co0 < Cout; co0 += 32) {
+            Wgrad2dArgs a = {};
+            a.x = x; a.g = gy; a.part = ws; a.N = N; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo;
+            a.CX = Cin - ci0 < 32 ? Cin - ci0 : 32; a.CG = Cout - co0 < 32 ? Cout - co0 : 32;
+            a.xs = Cin; a.x0 = ci0; a.gs = Cout; a.g0 = co0;
+            a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
+            const int ntiles = N * a.nth * a.ntw, groups = ntiles < gmax ? ntiles : gmax;
+            const int cxp = (a.CX + 3) / 4 * 4, nb = mvs_cdiv(a.CG, 16);
+            bool ok = true;
+            if (ks == 3) {
+                if (cxp == 4) { if (nb == 1) c2_wgrad_launch<3, 1, 4, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 4, 2>(a, groups, stream); }
+                else if (cxp == 8) { if (nb == 1) c2_wgrad_launch<3, 1, 8, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 8, 2>(a, groups, stream); }
+                else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<3, 1, 16, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 16, 2>(a, groups, stream); }
+                else if (cxp == 32) { if (nb == 1) c2_wgrad_launch<3, 1, 32, 1>(a, groups, stream); else c2_wgrad_launch<3, 1, 32, 2>(a, groups, stream); }
+                else ok = false;
+            } else {
+                if (cxp == 8) { if (nb == 1) c2_wgrad_launch<5, 2, 8, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 8, 2>(a, groups, stream); }
+                else if (cxp == 16) { if (nb == 1) c2_wgrad_launch<5, 2, 16, 1>(a, groups, stream); else c2_wgrad_launch<5, 2, 16, 2>(a, groups, stream); }
+                else ok = false;
+            }
+            MVS_REQUIRE(ok, MVS_ERR_UNSUPPORTED, "conv2d_wgrad: input channels %d not supported for the %dx%d layer", Cin, ks, ks);
+            rc = mvs_check_launch("conv2d_wgrad");
+            if (rc) return rc;
+            const int n = a.CG * a.CX * nt;
+            MVS_LAUNCH(conv2d_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, groups, nt, a.CX, cxp, a.CG,
+                       nb * 16, gw, Cin, ci0, co0);
+        }
     return mvs_check_launch("conv2d_wgrad_reduce");
 }

@@ -18,11 +18,12 @@ ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >
 
 
 def conv2d_maybe_hip(conv: nn.Conv2d, x):
-    """nn.Conv2d through csrc/conv2d.hip when it is one of the feature extractors' shapes (3x3 s1 p1 or 5x5 s2 p2, <= 32
-    channels, fp32 on the GPU); the stock module otherwise."""
+    """nn.Conv2d through csrc/conv2d.hip when it is one of the feature extractors' shapes (3x3 s1 p1 or 5x5 s2 p2, <= 32 or
+    exactly 64 channels, fp32 on the GPU); the stock module otherwise."""
     k, s, p = conv.kernel_size, conv.stride, conv.padding
+    wide = lambda c: c <= 32 or c == 64
     ok = (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and conv.dilation == (1, 1)
-          and conv.in_channels <= 32 and conv.out_channels <= 32
+          and wide(conv.in_channels) and wide(conv.out_channels) and (k == (3, 3) or max(conv.in_channels, conv.out_channels) <= 32)
           and ((k, s, p) == ((3, 3), (1, 1), (1, 1)) or (k, s, p) == ((5, 5), (2, 2), (2, 2))))
     return ops.Conv2dFn.apply(x, conv.weight, conv.bias, s[0]) if ok else conv(x)
 

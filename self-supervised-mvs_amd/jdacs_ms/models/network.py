@@ -1,6 +1,8 @@
 """Drop-in for jdacs-ms/models/network.py: CVPMVSNet(args).forward(ref_img, src_imgs, ref_in, src_in,
 ref_ex, src_ex, depth_min, depth_max) -> {"depth_est_list": [finest..coarsest], "prob_confidence"}
 with identical state_dict names.  Cost volumes, the shared 3-D regulariser and soft-argmin run in HIP."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -24,7 +26,18 @@ class FeaturePyramid(nn.Module):
         for name, cin, cout in _PYRAMID_LAYERS:
             setattr(self, name, conv(cin, cout, kernel_size=3, stride=1))
 
+    # conv + bias + LeakyReLU of every block as ONE csrc/conv2d.hip pass (channels-last) instead of the stock
+    # MIOpen convolution + activation.  MVS_HIP_PYRAMID=1 / FeaturePyramid.hip_conv = True; default follows the measurement
+    # recorded in profiles/ (see DESIGN.md section 7).
+    hip_conv = os.environ.get("MVS_HIP_PYRAMID", "0") == "1"
+
     def _trunk(self, img):
+        if self.hip_conv and img.is_cuda and img.dtype == torch.float32:
+            x = img.contiguous(memory_format=torch.channels_last)
+            for name, *_ in _PYRAMID_LAYERS:
+                block = getattr(self, name)
+                x = ops.Conv2dLReLUFn.apply(x, block[0].weight, block[0].bias, block[1].negative_slope)
+            return x
         for name, *_ in _PYRAMID_LAYERS:
             img = getattr(self, name)(img)
         return img

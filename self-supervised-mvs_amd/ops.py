@@ -651,13 +651,14 @@ def depth_hypotheses(ref_depths: torch.Tensor, mats: torch.Tensor) -> torch.Tens
 def _c2_ws(lib, op, n, h, w, cin, cout, ks, stride, like):
     nfl = lib.raw("mvs_conv2d_workspace_floats", op, n, h, w, cin, cout, ks, stride)
     if nfl < 0:
-        raise ValueError("conv2d: unsupported shape (3x3 stride 1 or 5x5 stride 2, 1..32 channels): Cin=%d Cout=%d k=%d s=%d"
+        raise ValueError("conv2d: unsupported shape (3x3 stride 1 or 5x5 stride 2, 1..32 or 64 channels): Cin=%d Cout=%d k=%d s=%d"
                          % (cin, cout, ks, stride))
     return torch.empty(nfl, dtype=torch.float32, device=like.device)
 
 
-def conv2d_forward(x, weight, bias=None, stride=1):
-    """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last)."""
+def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None):
+    """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last);
+    negative_slope: LeakyReLU fused after the bias."""
     lib = _lib_for(x)
     x = as_cl2(x)
     n, cin, h, w = x.shape
@@ -667,6 +668,10 @@ def conv2d_forward(x, weight, bias=None, stride=1):
     ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
     ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x)
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=CL2)
+    if negative_slope is not None:
+        lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
+                 n, h, w, cin, cout, ks, stride, float(negative_slope), _stream(x), tag="fwd2d_lrelu:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+        return y
     lib.call("mvs_conv2d_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
              n, h, w, cin, cout, ks, stride, _stream(x), tag="fwd2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
     return y
@@ -715,4 +720,29 @@ class Conv2dFn(torch.autograd.Function):
         gx = conv2d_dgrad(gy, weight, tuple(x.shape), ctx.stride) if ctx.needs_input_grad[0] else None
         gw = conv2d_wgrad(x, gy, tuple(weight.shape), ctx.stride) if ctx.needs_input_grad[1] else None
         gb = gy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+class Conv2dLReLUFn(torch.autograd.Function):
+    """nn.Sequential(nn.Conv2d(k3 s1 p1, bias), nn.LeakyReLU(slope)) -- the `conv` block of the CVP feature pyramid
+    (jdacs-ms/models/modules.py:15-19) -- forward in ONE csrc/conv2d.hip pass; backward: the activation's mask (one
+    elementwise launch), then the input- and weight-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, negative_slope):
+        x = as_cl2(x)
+        y = conv2d_forward(x, weight, bias, 1, negative_slope=negative_slope)
+        ctx.save_for_backward(x, weight, y)
+        ctx.slope = float(negative_slope)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        # y > 0 <=> the pre-activation was > 0 (slope > 0), so the output is enough to mask the gradient
+        g = torch.ops.aten.leaky_relu_backward(as_cl2(gy), y, ctx.slope, True).contiguous(memory_format=CL2)
+        gx = conv2d_dgrad(g, weight, tuple(x.shape), 1) if ctx.needs_input_grad[0] else None
+        gw = conv2d_wgrad(x, g, tuple(weight.shape), 1) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb, None

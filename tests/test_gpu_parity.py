@@ -895,3 +895,65 @@ def test_geo_consistency_filter_golden(dev):
     ok = cnt == z["geo_count"]
     assert np.allclose(r["depth_avg"].cpu().numpy()[ok], z["depth_avg"][ok], rtol=1e-6)
     assert float((r["final_mask"].cpu().numpy() != z["final_mask"]).mean()) < 2e-3
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(3, 64, (61, 83)), (64, 64, (37, 65)), (64, 32, (40, 52)), (32, 16, (33, 70)), (16, 16, (45, 37)), (4, 32, (64, 96)),
+                                         (32, 1, (64, 96))])
+def test_conv2d_lrelu_block_and_wide_channels(dev, cin, cout, hw):
+    """the CVP feature pyramid's `conv` block (Conv2d 3x3 + bias + LeakyReLU 0.1, widths up to 64:
+    jdacs-ms/models/network.py:16-41) and RefineNet's channel counts (jdacs/models/mvsnet.py:77-92) vs ATen on the same GPU."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    x = torch.randn(2, cin, *hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (0.5 / cin ** 0.5)).to(dev)
+    b = (torch.randn(cout, generator=g) * 0.3).to(dev)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, padding=1), 0.1)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.Conv2dLReLUFn.apply(xa, wa, ba, 0.1)
+    assert y.shape == yr.shape and float((y - yr).abs().max()) < 3e-4
+    gy = torch.randn(yr.shape, generator=g).to(dev)
+    yr.backward(gy)
+    y.backward(gy)
+    assert float((xa.grad - xr.grad).abs().max()) < 5e-4 * max(1.0, float(xr.grad.abs().max()))
+    assert float((wa.grad - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+    assert float((ba.grad - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
+
+
+def test_feature_pyramid_and_refinenet_hip_convs_vs_stock(dev):
+    """FeaturePyramid (jdacs-ms/models/network.py:16-41) with every block through csrc/conv2d.hip, and MVSNet(refine=True)'s
+    RefineNet (jdacs/models/mvsnet.py:77-92) with its convolutions through csrc/conv2d.hip == the stock (MIOpen) path."""
+    from mvs_amd.jdacs.models.module import ConvBnReLU
+    from mvs_amd.jdacs.models.mvsnet import RefineNet
+    from mvs_amd.jdacs_ms.models.network import FeaturePyramid
+    torch.manual_seed(0)
+    fp = FeaturePyramid().to(dev)
+    img = torch.randn(1, 3, 96, 160, device=dev)
+    old = FeaturePyramid.hip_conv
+    try:
+        FeaturePyramid.hip_conv = False
+        ref = fp(img, 3)
+        sum(f.square().mean() for f in ref).backward()
+        gref = {k: p.grad.clone() for k, p in fp.named_parameters()}
+        fp.zero_grad()
+        FeaturePyramid.hip_conv = True
+        out = fp(img, 3)
+        sum(f.square().mean() for f in out).backward()
+    finally:
+        FeaturePyramid.hip_conv = old
+    for a, b in zip(out, ref):
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+    for k, p in fp.named_parameters():
+        assert rel_l1(p.grad, gref[k]) < 2e-3, k
+    rn = RefineNet().to(dev).train()
+    im = torch.randn(2, 3, 128, 192, device=dev)
+    d0 = 500 + 100 * torch.rand(2, 32, 48, device=dev)
+    oldc = ConvBnReLU.hip_conv
+    try:
+        ConvBnReLU.hip_conv = False
+        r0 = rn(im, d0)
+        ConvBnReLU.hip_conv = True
+        r1 = rn(im, d0)
+    finally:
+        ConvBnReLU.hip_conv = oldc
+    assert rel_l1(r1, r0) < 1e-5

@@ -64,6 +64,20 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "f34" ]; then
+  MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "bf16 or geo or conv2d or pyramid or featurenet or config1 or config5" -s > gpurun_out/pytest_f34.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_f34.log; grep -E "passed|failed|FAILED|Error|bf16 vs" gpurun_out/pytest_f34.log | tail -20
+  for e in 0 1; do
+    MVS_HIP_PYRAMID=$e timeout 900 python bench.py --config 4 --steps 10 --warmup 3 > "gpurun_out/bench_config_4_pyr$e.json" 2> "gpurun_out/bench_config_4_pyr$e.err"
+    echo "bench --config 4 MVS_HIP_PYRAMID=$e exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'])" "gpurun_out/bench_config_4_pyr$e.json"
+  done
+  timeout 900 python bench.py --config 5 --steps 10 --warmup 3 --time-all-kernels > "gpurun_out/bench_config_5.json" 2> "gpurun_out/bench_config_5.err"
+  echo "bench --config 5 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], {k:(round(v['ms'],3), round(v['frac'],3)) for k,v in d['kernels'].items()})" "gpurun_out/bench_config_5.json"; grep "ms/step" "gpurun_out/bench_config_5.err" | head -6
+fi
 if [ "$what" = "bf16b" ]; then
   MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "bf16 or golden_mvsnet or config1 or config5 or sweep or homo" -s > gpurun_out/pytest_bf16.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_bf16.log; grep -E "passed|failed|FAILED|Error|bf16 vs" gpurun_out/pytest_bf16.log | tail -20
