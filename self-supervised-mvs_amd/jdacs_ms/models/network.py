@@ -27,9 +27,9 @@ class FeaturePyramid(nn.Module):
             setattr(self, name, conv(cin, cout, kernel_size=3, stride=1))
 
     # conv + bias + LeakyReLU of every block as ONE csrc/conv2d.hip pass (channels-last) instead of the stock
-    # MIOpen convolution + activation.  MVS_HIP_PYRAMID=1 / FeaturePyramid.hip_conv = True; default follows the measurement
-    # recorded in profiles/ (see DESIGN.md section 7).
-    hip_conv = os.environ.get("MVS_HIP_PYRAMID", "0") == "1"
+    # MIOpen convolution + activation.  ON by default: measured at BASELINE configs[3] (N=5, 1152x864, 3 levels) the whole
+    # inference goes 47.2 -> 40.4 ms (profiles/r02_run10_*); MVS_HIP_PYRAMID=0 / FeaturePyramid.hip_conv = False restores MIOpen.
+    hip_conv = os.environ.get("MVS_HIP_PYRAMID", "1") == "1"
 
     def _trunk(self, img):
         if self.hip_conv and img.is_cuda and img.dtype == torch.float32:

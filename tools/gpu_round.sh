@@ -64,6 +64,22 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "b2" ]; then
+  timeout 900 python bench.py --steps 20 --warmup 5 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench (default) exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], {k:(round(v['ms'],3), round(v['frac'],3), v.get('traffic')) for k,v in d['kernels'].items()}); print(d['roofline']); print(d.get('cpu_baseline')); print(d.get('reference_gpu_path'))" gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+  for t in "" "sweep_fwd=2"; do
+    MVS_TUNING=$t timeout 600 python bench.py --config 3 --steps 20 --warmup 5 > "gpurun_out/bench_c3_[$t].json" 2> "gpurun_out/bench_c3_[$t].err"
+    echo "bench config 3 [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], {k:(round(v['ms'],3), round(v['frac'],3)) for k,v in d['kernels'].items()})" "gpurun_out/bench_c3_[$t].json"
+    MVS_TUNING=$t timeout 600 python bench.py --config 5 --dtype f32 --steps 10 --warmup 3 > "gpurun_out/bench_c5f32_[$t].json" 2> "gpurun_out/bench_c5f32_[$t].err"
+    echo "bench config 5 f32 [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], {k:(round(v['ms'],3), round(v['frac'],3)) for k,v in d['kernels'].items()})" "gpurun_out/bench_c5f32_[$t].json"
+  done
+fi
 if [ "$what" = "f34" ]; then
   MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "bf16 or geo or conv2d or pyramid or featurenet or config1 or config5" -s > gpurun_out/pytest_f34.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_f34.log; grep -E "passed|failed|FAILED|Error|bf16 vs" gpurun_out/pytest_f34.log | tail -20
