@@ -205,11 +205,11 @@ template <int C, int CPT> struct TileC {
 // lanes, so lane q computes only view q % NS_T and the others fetch (wx, wy, x0, y0) with quad-broadcast DPP moves
 // instead of recomputing them: ~20 (NS_T = 2) / ~70 (NS_T = 4) fewer VALU instructions per plane in a kernel whose VALU
 // is busy 73 % of the time.  Bit-identical results.  Variant 6 of the "sweep_fwd" knob; not yet measured on the GPU.
-// BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns 8
-// CONSECUTIVE channels so that its 8 values are one 16-byte store and the 4 lanes of a pixel write one 64-byte segment.
+// BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns CPT
+// CONSECUTIVE channels so that its values are one 16- (8-) byte store and the lanes of a pixel write one 64-byte segment.
 template <int C, int NS_T, int CPT, bool QS = false, bool BF = false>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
-    static_assert(!BF || CPT == 8, "bf16 store: 8 channels per thread");
+    static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
     constexpr int V = CPT / 4;                     // float4s per tap per thread
     static_assert(!QS || (C == 32 && CPT == 8 && (NS_T == 2 || NS_T == 4)), "quad sharing needs 4 lanes per pixel");
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
@@ -349,9 +349,11 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
             else *reinterpret_cast<float4*>(outp + ck * k) = o;
         }
-        if (BF && (!QS || live))
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.var) + oidx) =
-                make_uint4(packed[0], packed[1], packed[2 % (2 * V)], packed[3 % (2 * V)]);
+        if (BF && (!QS || live)) {
+            if (V == 2) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.var) + oidx) =
+                            make_uint4(packed[0], packed[1], packed[2 % (2 * V)], packed[3 % (2 * V)]);
+            else { uint2 o2; o2.x = packed[0]; o2.y = packed[1]; *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.var) + oidx) = o2; }
+        }
     }
 }
 
@@ -1268,7 +1270,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1291,7 +1293,9 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
         constexpr int CPT16 = C >= 32 ? 16 : CPT8;
         const bool c16 = variant == 4 && CPT16 == 16;
-        const bool c8 = !c16 && variant >= 3 && CPT8 == 8;
+        // 8 channels per thread up to 4 source views; 6 views' blocks at 8 channels leave one wave per SIMD (256 VGPRs) and
+        // measured 3.99 ms against 2.98 ms with 4 channels at config 5 (N = 7, 1600x1184, D = 256; profiles/r02_run11_*)
+        const bool c8 = !c16 && variant >= 3 && CPT8 == 8 && a.NS <= 4;
         const int ppb = c16 ? TileC<C, CPT16>::PPB : (c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB);
         int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? TileC<C, CPT8>::TW : TileC<C, 4>::TW));
         if (tw > ppb) tw = ppb;
@@ -1311,8 +1315,9 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         if (a.bf16_out) {
             MVS_REQUIRE(CPT8 == 8, MVS_ERR_UNSUPPORTED, "plane_sweep bf16 volume: needs >= 16 feature channels");
             constexpr int CB = CPT8 == 8 ? C : 16;       // (C = 8 never gets here; keeps the template instantiable)
-            const int ppbb = TileC<CB, 8>::PPB;
-            a.tile_w = TileC<CB, 8>::TW;
+            const bool b8 = a.NS <= 4;
+            const int ppbb = b8 ? TileC<CB, 8>::PPB : TileC<CB, 4>::PPB;
+            a.tile_w = b8 ? TileC<CB, 8>::TW : TileC<CB, 4>::TW;
             a.tiles_x = mvs_cdiv(a.W, a.tile_w);
             a.tiles_y = mvs_cdiv(a.H, ppbb / a.tile_w);
             const long tilesb = (long)a.tiles_x * a.tiles_y * a.B;
@@ -1325,7 +1330,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
                 case 2: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 2, 8, false, true>), gridb, block, 0, st, a); break;
                 case 3: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 3, 8, false, true>), gridb, block, 0, st, a); break;
                 case 4: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 4, 8, false, true>), gridb, block, 0, st, a); break;
-                case 6: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 6, 8, false, true>), gridb, block, 0, st, a); break;
+                case 6: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 6, 4, false, true>), gridb, block, 0, st, a); break;
             }
             return mvs_check_launch("plane_sweep_variance_fwd_cached (bf16 volume)");
         }
@@ -1395,7 +1400,7 @@ static int launch_bwd(SweepArgs& a, hipStream_t st) {
         // <= 2 source views: 4 channels per thread + one-plane lookahead staging of the next block (knobs "bwd_cpt" 4|8,
         // "bwd_pf" 0|1 keep the other forms for A/B); 3-4 views: 4 channels per thread, synchronous re-gather at 2 waves
         // per SIMD or staged at 1 wave per SIMD
-        const bool pf = g_sweep_bwd_pf != 0;
+        const bool pf = g_sweep_bwd_pf == 1;
         constexpr int CPT_HI = C >= 16 ? 8 : 4;
         if (a.NS <= 2) {
             const bool c8 = g_sweep_bwd_cpt == 8 && CPT_HI == 8;
@@ -1406,8 +1411,11 @@ static int launch_bwd(SweepArgs& a, hipStream_t st) {
             if (c8) return pf ? launch_bwd_pw<C, 2, CPT_HI, true, 1>(a, st) : launch_bwd_pw<C, 2, CPT_HI, false, 2>(a, st);
             return pf ? launch_bwd_pw<C, 2, 4, true, 2>(a, st) : launch_bwd_pw<C, 2, 4, false, 3>(a, st);
         }
-        if (a.NS == 3) return pf ? launch_bwd_pw<C, 3, 4, true, 1>(a, st) : launch_bwd_pw<C, 3, 4, false, 2>(a, st);
-        return pf ? launch_bwd_pw<C, 4, 4, true, 1>(a, st) : launch_bwd_pw<C, 4, 4, false, 2>(a, st);
+        // knob bwd_pf = 2: synchronous re-gather at ONE wave per SIMD (512 registers: nothing spills with 4 views' blocks)
+        if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 4, false, 1>(a, st)
+                                                   : (pf ? launch_bwd_pw<C, 3, 4, true, 1>(a, st) : launch_bwd_pw<C, 3, 4, false, 2>(a, st));
+        return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 4, 4, false, 1>(a, st)
+                                   : (pf ? launch_bwd_pw<C, 4, 4, true, 1>(a, st) : launch_bwd_pw<C, 4, 4, false, 2>(a, st));
     }
     // more than four source views (or knob "sweep_bwd" = 1): view pairs per workgroup, LDS-atomic windows
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);

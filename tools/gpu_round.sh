@@ -64,6 +64,18 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "runA" ]; then
+  MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd N=5" gpurun_out/kernels_k2.log
+  timeout 900 python bench.py --config 5 --steps 10 --warmup 3 > "gpurun_out/bench_config_5.json" 2> "gpurun_out/bench_config_5.err"
+  echo "bench --config 5 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], {k:(round(v['ms'],3), round(v['frac'],3)) for k,v in d['kernels'].items()})" "gpurun_out/bench_config_5.json"
+  MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 --time-all-kernels > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
+  echo "bench MVS_HIP_FEATURE=1 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'])" gpurun_out/bench_hipfeature.json; grep "ms/step" gpurun_out/bench_hipfeature.err | grep -E "2d|bn_group" | head -40
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 --torch-profile gpurun_out/torch_profile.txt > /dev/null 2>&1; grep -E "miopen|Miopen|igemm|ck::|naive|batched_gemm|Name" gpurun_out/torch_profile.txt | head -30 | cut -c1-200
+fi
 if [ "$what" = "b2" ]; then
   timeout 900 python bench.py --steps 20 --warmup 5 --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench (default) exit $?"; python -c "
