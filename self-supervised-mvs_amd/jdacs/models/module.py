@@ -47,11 +47,13 @@ class ConvBnReLU(nn.Module):
         after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
         y = conv2d_maybe_hip(self.conv, x) if self.hip_conv else self.conv(x)
         bn = self.bn
-        if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 64
+        # the BatchNorm kernels serve 4/8/16/32/64 channels and an exponential moving average; anything else (e.g. 12 or 48
+        # channels in a user's own ConvBnReLU, or momentum=None = cumulative average) takes the stock modules
+        if (self.hip_bn and y.is_cuda and y.dtype == torch.float32 and y.shape[1] in (4, 8, 16, 32, 64) and bn.momentum is not None
                 and y.is_contiguous(memory_format=torch.channels_last)):
             for _ in range(groups):
                 count_batch(bn, self.training)
-            momentum = bn.momentum if bn.momentum is not None else 0.1
+            momentum = bn.momentum
             return ops.BnReLUFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.eps,
                                       momentum, groups)
         if groups > 1:

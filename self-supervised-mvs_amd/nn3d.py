@@ -51,8 +51,11 @@ def _require_eval(module, what):
 
 
 def _bn_step(bn: nn.BatchNorm3d, training: bool):
+    if bn.momentum is None:
+        raise ValueError("mvs_amd: BatchNorm3d(momentum=None) (cumulative moving average) is not supported by the fused kernels; "
+                         "the reference uses the default momentum 0.1 (jdacs/models/module.py:39)")
     count_batch(bn, training)
-    return bn.momentum if bn.momentum is not None else 0.1
+    return bn.momentum
 
 
 class ConvBnReLU3D(nn.Module):
