@@ -125,12 +125,32 @@ class FlatGradBucket:
 
     def all_reduce(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            _all_reduce_sum(self.flat)
             self.flat.div_(dist.get_world_size())
+
+
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo (the CPU backend used by the tests, also for ranks that share ONE GPU) moves host memory: device tensors are
+    staged through a host copy.  nccl (== RCCL, the product path: one rank per GPU over xGMI) takes the device tensor as is."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor) -> None:
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """One-off broadcast of initial weights + buffers so every rank starts from rank `src`'s model."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+            if _host_staged(t.data):
+                h = t.data.cpu()
+                dist.broadcast(h, src)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src)

@@ -89,3 +89,75 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+# ---- SURVEY 8(e) with the REAL model: 2 ranks x 1 sample == the mean of the per-sample gradients of one process -------------
+def _mvsnet_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import mvs_amd  # noqa: F401
+    from mvs_amd import dist as mdist
+    from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
+    from mvs_amd.synthetic import synthetic_mvsnet_inputs
+    mdist.init_from_env("gloo")            # both ranks share the box's ONE GPU: the collective goes through host memory
+    dev = torch.device("cuda:0")
+    torch.manual_seed(100 + rank)          # deliberately different init per rank -> the broadcast must fix it
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    net = net.to(dev).train()
+    mdist.broadcast_parameters(net)
+    bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
+    imgs, proj, dv = synthetic_mvsnet_inputs(1, 3, 64, 96, 16, seed=1 + rank)     # one sample per rank
+    gt = torch.full((1, 16, 24), 450.0, device=dev)
+    bucket.zero()
+    out = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+    mvsnet_loss(out["depth"], gt, torch.ones_like(gt)).backward()
+    bucket.gather()
+    bucket.all_reduce()
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret["flat"] = bucket.flat.cpu()
+        ret["sd"] = {k: v.cpu() for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_real_mvsnet_equals_mean_of_per_sample_gradients():
+    """One rank per sample with per-replica BatchNorm statistics and ONE flat all-reduce (the data-parallel scheme of dist.py,
+    here 2 ranks sharing the box's single GPU over gloo) == one process running the two samples one after the other and
+    averaging the gradients -- with the real MVSNet on the HIP path."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mvsnet_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import mvs_amd  # noqa: F401
+    from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
+    from mvs_amd.synthetic import synthetic_mvsnet_inputs
+    dev = torch.device("cuda:0")
+    net = MVSNet(refine=False)
+    net.load_state_dict(dict(ret["sd"]), strict=False)
+    net = net.to(dev).train()
+    gt = torch.full((1, 16, 24), 450.0, device=dev)
+    grads = None
+    for r in range(world):
+        imgs, proj, dv = synthetic_mvsnet_inputs(1, 3, 64, 96, 16, seed=1 + r)
+        net.zero_grad(set_to_none=True)
+        for m in net.modules():                       # per-replica BatchNorm: every sample starts from fresh running stats
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        out = net(imgs.to(dev), proj.to(dev), dv.to(dev))
+        mvsnet_loss(out["depth"], gt, torch.ones_like(gt)).backward()
+        # the bucket holds every gradient in its parameter's storage order (channels-last conv weights of the feature extractor)
+        g = torch.cat([torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(p.grad).as_strided((p.numel(),), (1,))
+                       for p in net.parameters() if p.requires_grad])
+        grads = g if grads is None else grads + g
+    ref = (grads / world).cpu()
+    got = ret["flat"]
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
