@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     if (tid < 32) {
         int off = 0;
-        if (GEOM == GEOM_TR2) {
+        if (G::BASE == GEOM_TR2) {
             if (tid < 27) {
                 int cls = 0, k0 = 0;
                 for (; cls < 8; ++cls) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { st1[nb] = 0.f; st2[nb] = 0.f; }
 
-    const int nchunks = GEOM == GEOM_TR2 ? 1 : a.Cin / CC;
+    const int nchunks = G::BASE == GEOM_TR2 ? 1 : a.Cin / CC;
     const int KSF = ksteps_for(27, CC);
 
     for (int cls = 0; cls < G::NCLS; ++cls) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 __syncthreads();
             }
             int KS, kk0, tapbase;
-            if (GEOM == GEOM_TR2) {
+            if (G::BASE == GEOM_TR2) {
                 KS = tr2_ntaps(cls) * CC / 16;
                 tapbase = tr2_tap_prefix(cls);
                 kk0 = tapbase * CC / 16;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             // their time waiting on the next 256-byte weight fragment (profiles/r01_run17_bench_kernel_stats.csv).
             // (measured: 64>64 at 24x16x20 0.073 -> 0.061 ms with PD = 4; conv0's dgrad, NB = 2: 0.556 ms with PD = 2 against 0.60
             //  with 1; the transposed geometry got slower with PD > 1 and keeps 1)
-            constexpr int PD = GEOM == GEOM_TR2 ? 1 : (NB == 1 ? 4 : 2);
+            constexpr int PD = G::BASE == GEOM_TR2 ? 1 : (NB == 1 ? 4 : 2);
             float4 bq[PD][NB], af[MB];
             auto load_b = [&](int ks, float4 (&dst)[NB]) {
                 const int kc = ks < KS ? ks : KS - 1;   // past the end: re-read the last fragment (harmless)
@@ -1376,6 +1376,7 @@ static size_t packed_floats(int geom, int cin, int cout) {
 }
 
 int g_conv_split = 1;
+int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
 int g_conv_fs = 0;      // tuning knob "fs": fast halo staging of interior tiles in the generic implicit-GEMM kernels (unmeasured)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
@@ -1401,6 +1402,22 @@ static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t s
     return mvs_check_launch("conv_igemm");
 }
 
+// Which tiling the generic kernel runs with (shared by run_igemm and mvs_conv3d_stat_rows: the BatchNorm partial-sum buffer has
+// exactly one row per workgroup tile).  Small volumes (deep U-Net levels) have too few tiles to fill 256 CUs: first one 16-wide
+// Cout tile per workgroup, and if that still leaves fewer than ~1.5 workgroups per CU, quarter-size tiles (knob "conv_small":
+// 0 never, 1 auto, 2 always).
+static void igemm_tiling(int geom, int B, int QD, int QH, int QW, int cout, int& kgeom, int& NB, int& nblocks) {
+    const int nb_total = mvs_cdiv(cout, 16) == 3 ? 4 : mvs_cdiv(cout, 16);
+    nblocks = B * mvs_cdiv(QD, geom_tqd(geom)) * mvs_cdiv(QH, geom_tqh(geom)) * mvs_cdiv(QW, 16);
+    NB = nb_total;
+    if (g_conv_split && nblocks < 512 && NB > 1) NB = 1;
+    kgeom = geom;
+    if (g_conv_small == 2 || (g_conv_small == 1 && (long)nblocks * (nb_total / NB) < 384)) {
+        kgeom = geom + GEOM_S1_SMALL;
+        nblocks = B * mvs_cdiv(QD, geom_tqd(kgeom)) * mvs_cdiv(QH, geom_tqh(kgeom)) * mvs_cdiv(QW, 16);
+    }
+}
+
 struct Epilogue {
     const float* scale; const float* shift; const float* skip; int relu; float* partials;
 };
@@ -1421,8 +1438,7 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
         a.Do = (Di - 1) / 2 + 1; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1;
         a.QD = a.Do; a.QH = a.Ho; a.QW = a.Wo;
     } else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
-    const int tqd = geom == GEOM_S2 ? 2 : 4;
-    a.ntd = mvs_cdiv(a.QD, tqd); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    a.ntd = mvs_cdiv(a.QD, geom_tqd(geom)); a.nth = mvs_cdiv(a.QH, geom_tqh(geom)); a.ntw = mvs_cdiv(a.QW, 16);
     if ((g_conv_c8 & 2) && geom == GEOM_S1 && cout == 8 && (cin == 8 || cin == 16 || cin == 32)) {
         // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions
         const int ntl = B * a.ntd * a.nth * a.ntw;
@@ -1439,18 +1455,17 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
         MVS_LAUNCH((conv_c8_fwd_kernel<8, 2>), dim3(nb8), dim3(256), 0, st, a, wsrc, wlayout, flip);
         return mvs_check_launch("conv_c8_fwd");
     }
-    const int nblocks = B * a.ntd * a.nth * a.ntw;
+    int nblocks = B * a.ntd * a.nth * a.ntw;
     if (geom == GEOM_S1 && cout == 1 && wlayout == WL_OIK && !flip && !ep.partials && (cin == 8 || cin == 16)) {
         if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         return mvs_check_launch("conv_cout1");
     }
     const int cc = pick_cc(geom, cin);
-    int NB = mvs_cdiv(cout, 16);
-    if (NB == 3) NB = 4;
-    a.nb_total = NB;
-    // small volumes (deep U-Net levels): too few tiles to fill 256 CUs -> one 16-wide Cout tile per workgroup
-    if (g_conv_split && nblocks < 512 && NB > 1) NB = 1;
+    int NB, kgeom;
+    a.nb_total = mvs_cdiv(cout, 16) == 3 ? 4 : mvs_cdiv(cout, 16);
+    igemm_tiling(geom, B, a.QD, a.QH, a.QW, cout, kgeom, NB, nblocks);
+    a.ntd = mvs_cdiv(a.QD, geom_tqd(kgeom)); a.nth = mvs_cdiv(a.QH, geom_tqh(kgeom));
     // pack weights into ws
     {
         const int total = (int)((size_t)total_ksteps(geom, cin, cc) * a.nb_total * 256);
@@ -1458,18 +1473,32 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
                    a.nb_total, wlayout, flip, total);
     }
     a.wp = ws;
-    if (geom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
-                                         : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
-    if (geom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
+                                          : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_S1_SMALL) return cc == 16 ? launch_igemm_nb<GEOM_S1_SMALL, 16>(a, NB, nblocks, st)
+                                                : launch_igemm_nb<GEOM_S1_SMALL, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_S2_SMALL) return launch_igemm_nb<GEOM_S2_SMALL, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_TR2_SMALL) {
+        if (cc == 16) return launch_igemm_nb<GEOM_TR2_SMALL, 16>(a, NB, nblocks, st);
+        if (cc == 32) return launch_igemm_nb<GEOM_TR2_SMALL, 32>(a, NB, nblocks, st);
+        return launch_igemm_nb<GEOM_TR2_SMALL, 64>(a, NB, nblocks, st);
+    }
     if (cc == 16) return launch_igemm_nb<GEOM_TR2, 16>(a, NB, nblocks, st);
     if (cc == 32) return launch_igemm_nb<GEOM_TR2, 32>(a, NB, nblocks, st);
     return launch_igemm_nb<GEOM_TR2, 64>(a, NB, nblocks, st);
 }
 
-static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi) {
-    int QD = Di, QH = Hi, QW = Wi;  // upper bound over the tilings a forward call may pick (rows beyond the used ones are never read)
+// rows of the BatchNorm partial-sum buffer of a forward call: one per workgroup tile of the tiling the call will use
+static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi, int cout = 16, bool generic = false) {
+    int QD = Di, QH = Hi, QW = Wi;
     if (geom == GEOM_S2) { QD = (Di - 1) / 2 + 1; QH = (Hi - 1) / 2 + 1; QW = (Wi - 1) / 2 + 1; }
-    return B * mvs_cdiv(QD, geom == GEOM_S2 ? 2 : 4) * mvs_cdiv(QH, 4) * mvs_cdiv(QW, 16);
+    if (generic) {
+        int kgeom, NB, nblocks;
+        igemm_tiling(geom, B, QD, QH, QW, cout, kgeom, NB, nblocks);
+        return nblocks;
+    }
+    return B * mvs_cdiv(QD, geom_tqd(geom)) * mvs_cdiv(QH, geom_tqh(geom)) * mvs_cdiv(QW, 16);
 }
 
 static const int WGRAD_MAX_GROUPS = 768;
@@ -1571,8 +1600,8 @@ extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin,
         return igemm_blocks(GEOM_S1, B, D, H, W);                        // conv_c8_fwd_bc_kernel tiling
     if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && g_conv_c8 && Cout == 8 && Cin % 8 == 0)
         return B * mvs_cdiv(D, 4) * mvs_cdiv(H, 8) * mvs_cdiv(W, 16);   // conv_c8_fwd_kernel tiling
-    if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W);
-    if (op == MVS_OP_CONVT_FWD) return igemm_blocks(stride == 2 ? GEOM_TR2 : GEOM_S1, B, D, H, W);
+    if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W, Cout, true);
+    if (op == MVS_OP_CONVT_FWD) return igemm_blocks(stride == 2 ? GEOM_TR2 : GEOM_S1, B, D, H, W, Cout, true);
     return -1;
 }
 

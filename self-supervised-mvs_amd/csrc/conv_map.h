@@ -16,7 +16,10 @@
 #define MVS_HD
 #endif
 
-enum { GEOM_S1 = 0, GEOM_S2 = 1, GEOM_TR2 = 2 };
+enum { GEOM_S1 = 0, GEOM_S2 = 1, GEOM_TR2 = 2,
+       // the same index maps on quarter-size workgroup tiles (one 16-voxel row per wave): 4x the workgroups for the deep U-Net
+       // levels, whose volumes (24x16x20 at config 2) give the full-size tiles fewer workgroups than the chip has CUs
+       GEOM_S1_SMALL = 3, GEOM_S2_SMALL = 4, GEOM_TR2_SMALL = 5 };
 // source weight tensor layout: OIK = [out'][in'][3][3][3], IOK = [in'][out'][3][3][3]
 enum { WL_OIK = 0, WL_IOK = 1 };
 
@@ -24,22 +27,50 @@ template <int GEOM>
 struct ConvGeom;
 template <>
 struct ConvGeom<GEOM_S1> {
+    static constexpr int BASE = GEOM_S1;
     static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;
     static constexpr int IS = 1, OS = 1, NCLS = 1, PAD = 1;
     static constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
 };
 template <>
 struct ConvGeom<GEOM_S2> {
+    static constexpr int BASE = GEOM_S2;
     static constexpr int TQD = 2, TQH = 4, TQW = 16, MB = 2;
     static constexpr int IS = 2, OS = 1, NCLS = 1, PAD = 1;
     static constexpr int RD = 2 * TQD + 1, RH = 2 * TQH + 1, RW = 2 * TQW + 1;
 };
 template <>
 struct ConvGeom<GEOM_TR2> {
+    static constexpr int BASE = GEOM_TR2;
     static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;
     static constexpr int IS = 1, OS = 2, NCLS = 8, PAD = 0;
     static constexpr int RD = TQD + 1, RH = TQH + 1, RW = TQW + 1;
 };
+template <>
+struct ConvGeom<GEOM_S1_SMALL> {
+    static constexpr int BASE = GEOM_S1;
+    static constexpr int TQD = 2, TQH = 2, TQW = 16, MB = 1;
+    static constexpr int IS = 1, OS = 1, NCLS = 1, PAD = 1;
+    static constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
+};
+template <>
+struct ConvGeom<GEOM_S2_SMALL> {
+    static constexpr int BASE = GEOM_S2;
+    static constexpr int TQD = 1, TQH = 4, TQW = 16, MB = 1;
+    static constexpr int IS = 2, OS = 1, NCLS = 1, PAD = 1;
+    static constexpr int RD = 2 * TQD + 1, RH = 2 * TQH + 1, RW = 2 * TQW + 1;
+};
+template <>
+struct ConvGeom<GEOM_TR2_SMALL> {
+    static constexpr int BASE = GEOM_TR2;
+    static constexpr int TQD = 2, TQH = 2, TQW = 16, MB = 1;
+    static constexpr int IS = 1, OS = 2, NCLS = 8, PAD = 0;
+    static constexpr int RD = TQD + 1, RH = TQH + 1, RW = TQW + 1;
+};
+// tile extents of a geometry id as plain functions (host code)
+MVS_HD inline int geom_base(int geom) { return geom >= GEOM_S1_SMALL ? geom - GEOM_S1_SMALL : geom; }
+MVS_HD inline int geom_tqd(int geom) { return geom == GEOM_S2 ? 2 : (geom == GEOM_S2_SMALL ? 1 : (geom >= GEOM_S1_SMALL ? 2 : 4)); }
+MVS_HD inline int geom_tqh(int geom) { return (geom == GEOM_S1_SMALL || geom == GEOM_TR2_SMALL) ? 2 : 4; }
 
 // number of taps of a TR2 parity class and of the classes before it (class id = pd*4 + ph*2 + pw)
 MVS_HD inline int tr2_ntaps(int cls) { return (1 + ((cls >> 2) & 1)) * (1 + ((cls >> 1) & 1)) * (1 + (cls & 1)); }

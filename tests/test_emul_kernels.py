@@ -144,8 +144,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 2], ids=["full_tiles", "quarter_tiles"])
+def conv_tiles(request, emul_lib):
+    """The generic implicit-GEMM kernel's two workgroup tilings (knob "conv_small": the library picks by launch size)."""
+    emul_lib.call("mvs_set_tuning", b"conv_small", request.param)
+    yield request.param
+    emul_lib.call("mvs_set_tuning", b"conv_small", 1)
+
+
 @pytest.mark.parametrize("cin,cout,stride,transposed,dims", CONV_CASES)
-def test_conv3d_family(emul_lib, cin, cout, stride, transposed, dims):
+def test_conv3d_family(emul_lib, conv_tiles, cin, cout, stride, transposed, dims):
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin * 7 + cout)
     b = 2 if max(dims) <= 16 and cin < 64 else 1      # (the emulated MFMA is a 64-thread barrier: keep the 64-channel cases small)

@@ -217,8 +217,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 2], ids=["full_tiles", "quarter_tiles"])
+def conv_tiles(request, dev):
+    """The generic implicit-GEMM kernel's two workgroup tilings (knob "conv_small": the library picks by launch size)."""
+    from mvs_amd import _lib
+    _lib.get().call("mvs_set_tuning", b"conv_small", request.param)
+    yield request.param
+    _lib.get().call("mvs_set_tuning", b"conv_small", 1)
+
+
 @pytest.mark.parametrize("cin,cout,stride,transposed,dims", CONV_CASES)
-def test_conv3d_family_vs_torch(dev, cin, cout, stride, transposed, dims):
+def test_conv3d_family_vs_torch(dev, conv_tiles, cin, cout, stride, transposed, dims):
     """Every conv geometry of both regularisers vs the reference's ATen ops (CPU, fp32)."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin * 7 + cout)

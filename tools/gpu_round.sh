@@ -64,6 +64,17 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "runB" ]; then
+  MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "conv3d_family or costregnet or two_ranks or golden_mvsnet or golden_cvp or cout8" > gpurun_out/pytest_runB.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_runB.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_runB.log | tail -12
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -n 3 gpurun_out/smoke.log
+  for t in "conv_small=0" "conv_small=1"; do
+    MVS_TUNING=$t timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --time-all-kernels > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'])" "gpurun_out/bench_[$t].json"; grep "ms/step" "gpurun_out/bench_[$t].err" | grep -E "24x16x20|48x32x40" | sort -k5 | head -30
+  done
+fi
 if [ "$what" = "runA" ]; then
   MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd N=5" gpurun_out/kernels_k2.log
   timeout 900 python bench.py --config 5 --steps 10 --warmup 3 > "gpurun_out/bench_config_5.json" 2> "gpurun_out/bench_config_5.err"
