@@ -15,6 +15,8 @@
 #include "mvs_rt.h"
 #include "conv_map.h"
 
+extern int g_conv_split, g_conv_small, g_conv_small_wgs;
+
 struct ConvArgs {
     const float* x;         // [B,Di,Hi,Wi,Cin]
     const float* wp;        // packed weights
@@ -1376,6 +1378,7 @@ static size_t packed_floats(int geom, int cin, int cout) {
 }
 
 int g_conv_split = 1;
+int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
 int g_conv_fs = 0;      // tuning knob "fs": fast halo staging of interior tiles in the generic implicit-GEMM kernels (unmeasured)
@@ -1412,7 +1415,7 @@ static void igemm_tiling(int geom, int B, int QD, int QH, int QW, int cout, int&
     NB = nb_total;
     if (g_conv_split && nblocks < 512 && NB > 1) NB = 1;
     kgeom = geom;
-    if (g_conv_small == 2 || (g_conv_small == 1 && (long)nblocks * (nb_total / NB) < 384)) {
+    if (g_conv_small == 2 || (g_conv_small == 1 && (long)nblocks * (nb_total / NB) < g_conv_small_wgs)) {
         kgeom = geom + GEOM_S1_SMALL;
         nblocks = B * mvs_cdiv(QD, geom_tqd(kgeom)) * mvs_cdiv(QH, geom_tqh(kgeom)) * mvs_cdiv(QW, 16);
     }

@@ -794,9 +794,6 @@ template <int C, int CPT> struct PwCfg {
     static constexpr int PPW = 64 / LPP;            // pixels per wave, as a BW x BH block
     static constexpr int BW = PPW >= 32 ? 8 : 4, BH = PPW / BW;
     static constexpr int V = CPT / 4;               // float4s per tap per thread
-    // accumulation window per wave, shared by its views: 19.5 KiB (2 workgroups per CU) with 8 channels per thread,
-    // 12.5 KiB (3 workgroups per CU) with 4 (half the pixels per wave: smaller footprints)
-    static constexpr int WAVE_FLOATS = CPT == 8 ? 4992 : 3200;
 };
 
 // One source view's register-resident 2x2 texel block of a thread: tap values + gradient accumulators (V float4 each).
@@ -899,7 +896,11 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     using Cfg = PwCfg<C, CPT>;
     constexpr int LPP = Cfg::LPP, BW = Cfg::BW, BH = Cfg::BH, V = Cfg::V;
     constexpr int CK = 4 * LPP;                      // channel of float4 k of lane q: 4q + CK*k (as in the forward)
-    constexpr int VIEW_FLOATS = Cfg::WAVE_FLOATS / NS_T / C * C, WCAP = VIEW_FLOATS / C;
+    // LDS per wave: 12.5 KiB when 3 workgroups share a CU (4 channels per thread, <= 2 views: 3 waves/SIMD by registers),
+    // 19.5 KiB when registers allow only 2 waves/SIMD anyway (8 channels per thread, or 3-4 views: more room per view -> longer
+    // depth segments before a window overflows)
+    constexpr int WAVE_FLOATS = WPS >= 3 ? 3200 : 4992;
+    constexpr int VIEW_FLOATS = WAVE_FLOATS / NS_T / C * C, WCAP = VIEW_FLOATS / C;
     __shared__ __attribute__((aligned(16))) float lds[4 * NS_T * VIEW_FLOATS];   // [wave][view][texel][C]
     __shared__ int s_win[4][NS_T][5];                // per wave and view: x0, y0, w, h, usable
     __shared__ int s_fit[4];
@@ -1251,6 +1252,7 @@ static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
 extern int g_conv_split;
 extern int g_conv_small;
+extern int g_conv_small_wgs;
 extern int g_conv_c8;
 extern int g_conv_xcd;
 extern int g_conv_fs;
@@ -1268,7 +1270,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     struct Knob { const char* name; int* var; int lo, hi; };
     const Knob knobs[] = {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
-        {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
+        {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
         {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2},

@@ -64,6 +64,14 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "runC" ]; then
+  for t in "conv_small_wgs=384" "conv_small_wgs=1024" "conv_small_wgs=2500" "conv_small_wgs=8000"; do
+    MVS_TUNING=$t timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --time-all-kernels > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'])" "gpurun_out/bench_[$t].json"; grep "ms/step" "gpurun_out/bench_[$t].err" | grep -E "48x32x40|96x64x80" | grep -E "fwd|dgrad" | sort -k5 | head -24
+  done
+fi
 if [ "$what" = "runB" ]; then
   MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --timeout 600 -k "conv3d_family or costregnet or two_ranks or golden_mvsnet or golden_cvp or cout8" > gpurun_out/pytest_runB.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_runB.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_runB.log | tail -12
