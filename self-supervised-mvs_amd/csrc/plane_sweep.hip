@@ -1097,8 +1097,10 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                         }
                     }
                 } else {
-                    // synchronous form (3-4 source views: no registers left for staging)
-                    const float dep = dptr[(size_t)(d - ds) * dstep];
+                    // synchronous form (the default).  The plane's depth was requested one plane ahead: a load issued here is consumed
+                    // by the very next instruction, i.e. every plane would start with a full memory round trip
+                    const float dep = dep_next;
+                    if (d + 1 < de) dep_next = dptr[(size_t)(d + 1 - ds) * dstep];
 #pragma unroll
                     for (int s = 0; s < NS_T; ++s) {
                         int x0, y0;
