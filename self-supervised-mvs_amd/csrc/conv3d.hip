@@ -15,7 +15,7 @@
 #include "mvs_rt.h"
 #include "conv_map.h"
 
-extern int g_conv_split, g_conv_small, g_conv_small_wgs;
+extern int g_conv_split, g_conv_small, g_conv_small_wgs, g_conv_tr2pw;
 
 struct ConvArgs {
     const float* x;         // [B,Di,Hi,Wi,Cin]
@@ -44,6 +44,29 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     const int nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
     const int co = nb * 16 + (lane & 15);
     int ks, chunk = 0, cls = 0;
+    if (geom == GEOM_TR2_PW) {
+        // columns n = pw*8 + co (Cout == 8, NB == 1); classes (pd, ph); taps incl. the input offset dw
+        int k0 = 0;
+        for (cls = 0; cls < 4; ++cls) {
+            int n = tr2p_ntaps(cls) * CC / 16;
+            if (kk < k0 + n) break;
+            k0 += n;
+        }
+        ks = kk - k0;
+        const int kf = 16 * ks + 4 * (lane >> 4) + j;
+        const int tp = kf / CC, cip = kf % CC, n = lane & 15, pw = n >> 3, cop = n & 7;
+        int dd, dh, dw, kd, kh;
+        tr2p_tap(cls, tp, dd, dh, dw, kd, kh);
+        int kw = tr2p_kw(pw, dw);
+        float v = 0.f;
+        if (kw >= 0 && nb == 0 && cop < Cout) {
+            if (flip) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+            const int kidx = kd * 9 + kh * 3 + kw;
+            v = layout == WL_OIK ? w[((size_t)cop * Cin + cip) * 27 + kidx] : w[((size_t)cip * Cout + cop) * 27 + kidx];
+        }
+        wp[idx] = v;
+        return;
+    }
     if (geom == GEOM_TR2) {
         int k0 = 0;
         for (cls = 0; cls < 8; ++cls) {
@@ -178,7 +201,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     if (tid < 32) {
         int off = 0;
-        if (G::BASE == GEOM_TR2) {
+        if (G::PW) {
+            if (tid < 18) {
+                int cls = 0, k0 = 0;
+                for (; cls < 4; ++cls) {
+                    int n = tr2p_ntaps(cls);
+                    if (tid < k0 + n) break;
+                    k0 += n;
+                }
+                int dd, dh, dw, kd, kh;
+                tr2p_tap(cls, tid - k0, dd, dh, dw, kd, kh);
+                off = ((dd * G::RH + dh) * G::RW + dw) * CCP;
+            }
+        } else if (G::BASE == GEOM_TR2) {
             if (tid < 27) {
                 int cls = 0, k0 = 0;
                 for (; cls < 8; ++cls) {
@@ -244,7 +279,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 __syncthreads();
             }
             int KS, kk0, tapbase;
-            if (G::BASE == GEOM_TR2) {
+            if (G::PW) {
+                KS = tr2p_ntaps(cls) * CC / 16;
+                tapbase = tr2p_tap_prefix(cls);
+                kk0 = tapbase * CC / 16;
+            } else if (G::BASE == GEOM_TR2) {
                 KS = tr2_ntaps(cls) * CC / 16;
                 tapbase = tr2_tap_prefix(cls);
                 kk0 = tapbase * CC / 16;
@@ -302,7 +341,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
 
         // ---- epilogue for this class: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
-        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        // (PW: class = (pd, ph); the column index l15 = pw*8 + co carries the W parity -> 16 consecutive floats per voxel pair)
+        const int pd = G::PW ? (cls >> 1) & 1 : (cls >> 2) & 1, ph = G::PW ? cls & 1 : (cls >> 1) & 1, pw = G::PW ? (l15 >> 3) : cls & 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int f = wave * MB + mb;
@@ -317,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int co = (nb0 + nb) * 16 + l15;
+                    const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
                     if (co >= a.Cout) continue;
                     float v = acc[mb][nb][r];
                     st1[nb] += v;
@@ -339,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             float s1 = st1[nb], s2 = st2[nb];
             s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (G::PW) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }   // columns n and n ^ 8 are the same channel (pw = 0 / 1)
             if (lane < 16) {
                 red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
                 red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
@@ -1378,6 +1419,7 @@ static size_t packed_floats(int geom, int cin, int cout) {
 }
 
 int g_conv_split = 1;
+int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv with Cout == 8 as W-parity-merged GEMMs (GEOM_TR2_PW)
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
@@ -1415,7 +1457,11 @@ static void igemm_tiling(int geom, int B, int QD, int QH, int QW, int cout, int&
     NB = nb_total;
     if (g_conv_split && nblocks < 512 && NB > 1) NB = 1;
     kgeom = geom;
-    if (g_conv_small == 2 || (g_conv_small == 1 && (long)nblocks * (nb_total / NB) < g_conv_small_wgs)) {
+    // measured per geometry (profiles/r02_run14_*): stride-2 layers gain ~10 % from quarter tiles at every size of the network
+    // (5x9x33-voxel halo in LDS -> 3x9x33: one more workgroup per CU), stride-1 layers up to ~1000 workgroups, the transposed
+    // geometry only when the chip is under-filled (its 8 parity classes re-walk the tile: smaller tiles lose 10 % at L0)
+    const long thr = (long)g_conv_small_wgs * (geom == GEOM_S2 ? 24 : (geom == GEOM_S1 ? 3 : 1));
+    if (g_conv_small == 2 || (g_conv_small == 1 && (long)nblocks * (nb_total / NB) < thr)) {
         kgeom = geom + GEOM_S1_SMALL;
         nblocks = B * mvs_cdiv(QD, geom_tqd(kgeom)) * mvs_cdiv(QH, geom_tqh(kgeom)) * mvs_cdiv(QW, 16);
     }
@@ -1471,8 +1517,9 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     a.ntd = mvs_cdiv(a.QD, geom_tqd(kgeom)); a.nth = mvs_cdiv(a.QH, geom_tqh(kgeom));
     // pack weights into ws
     {
-        const int total = (int)((size_t)total_ksteps(geom, cin, cc) * a.nb_total * 256);
-        MVS_LAUNCH(conv_pack_weights_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, wsrc, ws, geom, cc, cin, cout,
+        const int pgeom = (kgeom == GEOM_TR2 && cc == 16 && cout == 8 && g_conv_tr2pw) ? GEOM_TR2_PW : geom;
+        const int total = (int)((size_t)total_ksteps(pgeom, cin, cc) * a.nb_total * 256);
+        MVS_LAUNCH(conv_pack_weights_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, wsrc, ws, pgeom, cc, cin, cout,
                    a.nb_total, wlayout, flip, total);
     }
     a.wp = ws;
@@ -1487,6 +1534,7 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
         if (cc == 32) return launch_igemm_nb<GEOM_TR2_SMALL, 32>(a, NB, nblocks, st);
         return launch_igemm_nb<GEOM_TR2_SMALL, 64>(a, NB, nblocks, st);
     }
+    if (cc == 16 && cout == 8 && g_conv_tr2pw) return launch_igemm_nb<GEOM_TR2_PW, 16>(a, NB, nblocks, st);
     if (cc == 16) return launch_igemm_nb<GEOM_TR2, 16>(a, NB, nblocks, st);
     if (cc == 32) return launch_igemm_nb<GEOM_TR2, 32>(a, NB, nblocks, st);
     return launch_igemm_nb<GEOM_TR2, 64>(a, NB, nblocks, st);

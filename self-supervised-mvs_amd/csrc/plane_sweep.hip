@@ -1255,6 +1255,7 @@ static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the fo
 extern int g_conv_split;
 extern int g_conv_small;
 extern int g_conv_small_wgs;
+extern int g_conv_tr2pw;
 extern int g_conv_c8;
 extern int g_conv_xcd;
 extern int g_conv_fs;
@@ -1272,7 +1273,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
     struct Knob { const char* name; int* var; int lo, hi; };
     const Knob knobs[] = {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
-        {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
+        {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
         {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2},

@@ -64,6 +64,19 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "runD" ]; then
+  MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -k "conv3d_family or costregnet or golden_mvsnet or sweep or homo or config2_train" > gpurun_out/pytest_runD.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_runD.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_runD.log | tail -12
+  for t in "tr2pw=0" "tr2pw=1"; do
+    MVS_TUNING=$t timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --time-all-kernels > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"; grep "ms/step" "gpurun_out/bench_[$t].err" | grep -E "16>8|8>16" | head -8
+  done
+  timeout 600 python bench.py --config 3 --steps 20 --warmup 5 > gpurun_out/bench_config_3.json 2> gpurun_out/bench_config_3.err; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print('config 3', d['ms_per_step'], d['value'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" gpurun_out/bench_config_3.json
+fi
 if [ "$what" = "runC" ]; then
   for t in "conv_small_wgs=384" "conv_small_wgs=1024" "conv_small_wgs=2500" "conv_small_wgs=8000"; do
     MVS_TUNING=$t timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --time-all-kernels > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
