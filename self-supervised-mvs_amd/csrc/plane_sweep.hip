@@ -263,8 +263,14 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // the plane's depth is requested one plane ahead (a load issued at the top of the iteration is consumed by its very next
+    // instruction: one memory round trip per plane; the same change took the backward from 0.41 to 0.34 ms)
+    const float* __restrict__ dptr = a.depth + (a.per_pixel ? ((size_t)b * a.D + d0) * HW + pix : (size_t)b * a.D + d0);
+    const size_t dstep = a.per_pixel ? (size_t)HW : 1;
+    float dep_next = dptr[0];
     for (int d = d0; d < d1; ++d) {
-        const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
+        const float dep = dep_next;
+        if (d + 1 < d1) dep_next = dptr[(size_t)(d + 1 - d0) * dstep];
         float4 S[V], Q[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
