@@ -224,10 +224,13 @@ if [ "$what" = "final" ]; then
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -n 3 gpurun_out/smoke.log
   timeout 900 python bench.py --steps 20 --warmup 5 --time-all-kernels --gpu-reference 1 --torch-profile gpurun_out/torch_profile.txt > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench exit $?"; cat gpurun_out/bench.json; grep "ms/step" gpurun_out/bench.err | head -16
-  timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels.log
+  for c in 3 4 5; do
+    timeout 400 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 > gpurun_out/bench_c$c.json 2> gpurun_out/bench_c$c.err
+    echo "bench config $c exit $?"; cut -c1-200 gpurun_out/bench_c$c.json
+  done
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
-      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
   echo "prof exit $?"
   mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
   rm -rf gpurun_out/prof
