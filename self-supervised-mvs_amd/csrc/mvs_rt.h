@@ -32,6 +32,9 @@ static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
 #define MVS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget 512 / n per wave
 #define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating
+// "these four registers are needed now": the compiler places the s_waitcnt for the loads that produce them here instead of at their
+// first arithmetic use (used to keep a conditional gather's wait inside the conditional block)
+#define MVS_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 // wave-wide votes (every lane of the wave must reach them) and a compiler-level ordering point for a wave's own LDS
 // traffic (the DS queue of a wave is in order in hardware; this only stops the compiler from moving accesses across it)
 #define MVS_BALLOT(p) ((unsigned long long)__ballot(p))

@@ -896,7 +896,9 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
 }
 
 // MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
-template <int C, int NS_T, int CPT, int MODE, bool PF, int WPS>
+// GD: 0 = the upstream gradient of the next plane in ONE rotating register set (fits 3 waves/SIMD), 2 = requested two planes ahead into
+// three sets (2 waves/SIMD).  PPD: per-plane depth hypotheses only (scalar depth loads; the generic form decides at run time)
+template <int C, int NS_T, int CPT, int MODE, int GD, int WPS, bool PPD>
 __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
     constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
     using Cfg = PwCfg<C, CPT>;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     const float cxa = (float)min(bx0, a.W - 1), cxb = (float)min(bx0 + BW - 1, a.W - 1);
     const float cya = (float)min(by0, a.H - 1), cyb = (float)min(by0 + BH - 1, a.H - 1);
     float* const wwin = lds + (size_t)wv * NS_T * VIEW_FLOATS;     // this wave's windows
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr float4 z4{0.f, 0.f, 0.f, 0.f};   // a constant, not an object: captured by the lambdas below it would live in scratch
 
     int ds = blockIdx.y * a.dslab;
     const int dend = min(a.D, ds + a.dslab);
@@ -1048,65 +1050,34 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
             };
             const float* __restrict__ gptr = a.gvar + (((size_t)b * a.D + ds) * HW + pix) * C + cq;
             const size_t gstep = (size_t)HW * C;
-            float4 g_next[V];
+            // upstream gradient.  GD = 2: requested two planes ahead into three register sets used in rotation, the plane loop
+            // unrolled by three so that no set is ever copied (a loop-carried copy `g = g_next` makes the compiler wait for the load
+            // at the END of the plane that issued it: most of an HBM round trip exposed per plane).  GD = 0: that copy form, which is
+            // what fits the 170 registers of 3 waves/SIMD
+            constexpr int AH = GD == 0 ? 1 : GD;   // planes ahead
+            float4 g0[V], g1[GD == 2 ? V : 1], g2[GD == 2 ? V : 1];
 #pragma unroll
-            for (int k = 0; k < V; ++k) g_next[k] = ld4(gptr + CK * k);
-            // PF: the block a lane will need on the NEXT plane is requested one plane ahead into staging registers, so the
-            // L2 round trip of a re-gather (every plane SOME pixel of the wave leaves its block) overlaps a plane of arithmetic
-            // instead of stalling the whole wave.  nx / ny / nwx / nwy: the sample position of the plane about to be processed.
-            int nx[NS_T], ny[NS_T];
-            float nwx[NS_T], nwy[NS_T];
-            float4 s00[PF ? NS_T : 1][V], s01[PF ? NS_T : 1][V], s10[PF ? NS_T : 1][V], s11[PF ? NS_T : 1][V];
-            const float* __restrict__ dptr = a.depth + (a.per_pixel ? ((size_t)b * a.D + ds) * HW + pix : (size_t)b * a.D + ds);
-            const size_t dstep = a.per_pixel ? (size_t)HW : 1;
-            float dep_next = dptr[0];
-            if (PF) {
-#pragma unroll
-                for (int s = 0; s < NS_T; ++s) {
-                    locate(s, dep_next, nx[s], ny[s], nwx[s], nwy[s]);
-                    gather(s, nx[s], ny[s], s00[PF ? s : 0], s01[PF ? s : 0], s10[PF ? s : 0], s11[PF ? s : 0]);
-                }
-                if (ds + 1 < de) dep_next = dptr[dstep];
+            for (int k = 0; k < V; ++k) {
+                g0[k] = ld4(gptr + CK * k);
+                if constexpr (GD == 2) g1[k] = ds + 1 < de ? ld4(gptr + gstep + CK * k) : z4;
             }
-#pragma clang loop unroll(disable)
-            for (int d = ds; d < de; ++d) {
+            // depth of plane d: per-plane hypotheses are ONE value per (sample, plane) -> a scalar load (its own counter: a vector
+            // load here would be waited for by every vmcnt(0) that follows a re-gather); per-pixel hypotheses a vector load
+            auto depth_of = [&](int d) __attribute__((always_inline)) -> float {
+                if constexpr (!PPD) {
+                    if (a.per_pixel) return a.depth[((size_t)b * a.D + d) * HW + pix];
+                }
+                return a.depth[MVS_UNIFORM_I(b * a.D + d)];
+            };
+            float dep_next = depth_of(ds);
+            // one plane: gu = the plane's upstream gradient, gl = the set that receives plane d + GD
+            auto plane = [&](const int d, float4 (&gu)[V], float4 (&gl)[V]) __attribute__((always_inline)) {
                 float fwx[NS_T], fwy[NS_T];
-                if (PF) {
-                    // (a) lanes whose sample point left their block: flush the accumulators, take over the staged block
-#pragma unroll
-                    for (int s = 0; s < NS_T; ++s) {
-                        const bool chg = nx[s] != blk[s].cx || ny[s] != blk[s].cy;
-                        if (MVS_ANY(chg)) {
-                            pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                           wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
-                            if (chg) {
-                                blk[s].cx = nx[s]; blk[s].cy = ny[s];
-#pragma unroll
-                                for (int k = 0; k < V; ++k) {
-                                    blk[s].t00[k] = s00[PF ? s : 0][k]; blk[s].t01[k] = s01[PF ? s : 0][k];
-                                    blk[s].t10[k] = s10[PF ? s : 0][k]; blk[s].t11[k] = s11[PF ? s : 0][k];
-                                    blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
-                                }
-                            }
-                        }
-                        fwx[s] = nwx[s]; fwy[s] = nwy[s];
-                    }
-                    // (b) look one plane ahead: request the blocks that will be entered there
-                    if (d + 1 < de) {
-                        const float dep1 = dep_next;
-                        if (d + 2 < de) dep_next = dptr[(size_t)(d + 2 - ds) * dstep];
-#pragma unroll
-                        for (int s = 0; s < NS_T; ++s) {
-                            locate(s, dep1, nx[s], ny[s], nwx[s], nwy[s]);
-                            if (nx[s] != blk[s].cx || ny[s] != blk[s].cy)
-                                gather(s, nx[s], ny[s], s00[PF ? s : 0], s01[PF ? s : 0], s10[PF ? s : 0], s11[PF ? s : 0]);
-                        }
-                    }
-                } else {
-                    // synchronous form (the default).  The plane's depth was requested one plane ahead: a load issued here is consumed
-                    // by the very next instruction, i.e. every plane would start with a full memory round trip
+                {
+                    // the plane's depth was requested one plane ahead: a load issued here is consumed by the very next instruction,
+                    // i.e. every plane would start with a full memory round trip
                     const float dep = dep_next;
-                    if (d + 1 < de) dep_next = dptr[(size_t)(d + 1 - ds) * dstep];
+                    if (d + 1 < de) dep_next = depth_of(d + 1);
 #pragma unroll
                     for (int s = 0; s < NS_T; ++s) {
                         int x0, y0;
@@ -1123,6 +1094,12 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
 #pragma unroll
                                 for (int k = 0; k < V; ++k) blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
                             }
+                            // the gathered taps are waited for HERE, on the planes that re-gather: left to the join below, the wait
+                            // would be a vmcnt(0) on every plane and would also drain the upstream-gradient requests in flight
+#pragma unroll
+                            for (int k = 0; k < V; ++k) {
+                                MVS_PIN4(blk[s].t00[k]); MVS_PIN4(blk[s].t01[k]); MVS_PIN4(blk[s].t10[k]); MVS_PIN4(blk[s].t11[k]);
+                            }
                         }
                     }
                 }
@@ -1137,8 +1114,8 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                     const float ex = 1.0f - wx, ey = 1.0f - wy;
                     wt[s][0] = ey * ex; wt[s][1] = ey * wx; wt[s][2] = wy * ex; wt[s][3] = wy * wx;
                 }
-                const bool more = d + 1 < de;
-                if (more) gptr += gstep;
+                const bool more = d + AH < de;
+                const float* __restrict__ gnx = gptr + (size_t)(d + AH - ds) * gstep;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     float4 S = WARP_ONLY ? z4 : (MS_ALIAS ? make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w) : r[k]);
@@ -1154,8 +1131,8 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                             S.x += v[s].x; S.y += v[s].y; S.z += v[s].z; S.w += v[s].w;
                         }
                     }
-                    const float4 g = g_next[k];
-                    if (more) g_next[k] = ld4(gptr + CK * k);
+                    const float4 g = gu[k];
+                    if (more) gl[k] = ld4(gnx + CK * k);
                     float4 gs = make_float4(g.x * two_n, g.y * two_n, g.z * two_n, g.w * two_n);   // g * 2/N (0 on dead lanes)
                     float4 Sm = make_float4(S.x * inv_n, S.y * inv_n, S.z * inv_n, S.w * inv_n);
                     if (WARP_ONLY) {
@@ -1183,6 +1160,16 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                         B.g11[k].z = fmaf(gv.z, wt[s][3], B.g11[k].z); B.g11[k].w = fmaf(gv.w, wt[s][3], B.g11[k].w);
                     }
                     MVS_SCHED_FENCE();
+                }
+            };
+#pragma clang loop unroll(disable)
+            for (int d = ds; d < de; d += GD + 1) {
+                if constexpr (GD == 2) {
+                    plane(d, g0, g2);
+                    if (d + 1 < de) plane(d + 1, g1, g0);
+                    if (d + 2 < de) plane(d + 2, g2, g1);
+                } else {
+                    plane(d, g0, g0);   // `g = g0[k]; g0[k] = <plane d + 1>`: the copy-rotation form
                 }
             }
             // the blocks still held in registers
@@ -1268,8 +1255,9 @@ extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
-static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": channels per thread of the per-wave-window backward for <= 2 source views
-static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": one-plane lookahead staging of the next 2x2 block in the per-wave-window backward
+static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
+static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 2 = ONE wave per SIMD for 3-4 source views (1, the removed block-lookahead form, is accepted and ignored)
+static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
@@ -1282,7 +1270,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1385,8 +1373,9 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     return mvs_check_launch("plane_sweep_variance_fwd");
 }
 
-template <int C, int NS_T, int CPT, bool PF, int WPS>
+template <int C, int NS_T, int GD, int WPS>
 static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
+    constexpr int CPT = 4;   // 8 channels per thread measured slower at every occupancy (0.46-0.52 vs 0.41 ms, round 2 run 7)
     using Cfg = PwCfg<C, CPT>;
     a.tiles_x = mvs_cdiv(a.W, 2 * Cfg::BW);
     a.tiles_y = mvs_cdiv(a.H, 2 * Cfg::BH);
@@ -1400,34 +1389,23 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     a.no_window = g_sweep_bwd_nowin;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     if (a.warp_only) {
-        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, PF, WPS>), grid, block, 0, st, a);
-    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1, PF, WPS>), grid, block, 0, st, a);
-    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, PF, WPS>), grid, block, 0, st, a);
+        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, GD, WPS, false>), grid, block, 0, st, a);
+    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1, GD, WPS, false>), grid, block, 0, st, a);
+    else if (a.per_pixel) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, false>), grid, block, 0, st, a);
+    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, true>), grid, block, 0, st, a);
     return mvs_check_launch("plane_sweep_variance_bwd_pw");
 }
 
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
     if (g_sweep_bwd_variant == 0 && a.NS <= 4) {
-        // <= 2 source views: 4 channels per thread + one-plane lookahead staging of the next block (knobs "bwd_cpt" 4|8,
-        // "bwd_pf" 0|1 keep the other forms for A/B); 3-4 views: 4 channels per thread, synchronous re-gather at 2 waves
-        // per SIMD or staged at 1 wave per SIMD
-        const bool pf = g_sweep_bwd_pf == 1;
-        constexpr int CPT_HI = C >= 16 ? 8 : 4;
-        if (a.NS <= 2) {
-            const bool c8 = g_sweep_bwd_cpt == 8 && CPT_HI == 8;
-            if (a.NS == 1) {
-                if (c8) return pf ? launch_bwd_pw<C, 1, CPT_HI, true, 2>(a, st) : launch_bwd_pw<C, 1, CPT_HI, false, 2>(a, st);
-                return pf ? launch_bwd_pw<C, 1, 4, true, 2>(a, st) : launch_bwd_pw<C, 1, 4, false, 3>(a, st);
-            }
-            if (c8) return pf ? launch_bwd_pw<C, 2, CPT_HI, true, 1>(a, st) : launch_bwd_pw<C, 2, CPT_HI, false, 2>(a, st);
-            return pf ? launch_bwd_pw<C, 2, 4, true, 2>(a, st) : launch_bwd_pw<C, 2, 4, false, 3>(a, st);
-        }
-        // knob bwd_pf = 2: synchronous re-gather at ONE wave per SIMD (512 registers: nothing spills with 4 views' blocks)
-        if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 4, false, 1>(a, st)
-                                                   : (pf ? launch_bwd_pw<C, 3, 4, true, 1>(a, st) : launch_bwd_pw<C, 3, 4, false, 2>(a, st));
-        return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 4, 4, false, 1>(a, st)
-                                   : (pf ? launch_bwd_pw<C, 4, 4, true, 1>(a, st) : launch_bwd_pw<C, 4, 4, false, 2>(a, st));
+        // 1-2 views: 2 waves per SIMD with the upstream gradient requested two planes ahead (knob "bwd_gd" = 0: 3 waves per SIMD, one
+        // rotating register set); 3-4 views: 2 waves per SIMD (knob "bwd_pf" = 2: ONE wave per SIMD, 512 registers, nothing spills)
+        const bool gd2 = g_sweep_bwd_gd == 2;
+        if (a.NS == 1) return gd2 ? launch_bwd_pw<C, 1, 2, 2>(a, st) : launch_bwd_pw<C, 1, 0, 3>(a, st);
+        if (a.NS == 2) return gd2 ? launch_bwd_pw<C, 2, 2, 2>(a, st) : launch_bwd_pw<C, 2, 0, 3>(a, st);
+        if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 2, 1>(a, st) : launch_bwd_pw<C, 3, 0, 2>(a, st);
+        return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 4, 2, 1>(a, st) : launch_bwd_pw<C, 4, 0, 2>(a, st);
     }
     // more than four source views (or knob "sweep_bwd" = 1): view pairs per workgroup, LDS-atomic windows
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);

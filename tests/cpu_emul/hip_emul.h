@@ -183,6 +183,7 @@ static inline void emul_wave_sync() {
 #define MVS_QUAD_BCAST_I(v, s) __shfl((int)(v), (emul::lane & ~3) | (s))
 #define MVS_QUAD_BCAST_F(v, s) __shfl((float)(v), (emul::lane & ~3) | (s))
 #define MVS_SCHED_FENCE() ((void)0)
+#define MVS_PIN4(v) ((void)0)
 #define MVS_WAVES_PER_SIMD(n)
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) emul_mfma_4x4x1_bc((a), (b), (c), (abid))
 

@@ -75,11 +75,12 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
     depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
-    # variant 3 = ... with 8 channels per thread for <= 2 source views, variant 4 = ... without the lookahead staging
+    # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
+    # wave/SIMD for 3-4 source views
     emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
-    emul_lib.call("mvs_set_tuning", b"bwd_cpt", 8 if variant == 3 else 4)
-    emul_lib.call("mvs_set_tuning", b"bwd_pf", 0 if variant == 4 else 1)
+    emul_lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
+    emul_lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else 0)
     try:
         var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
         gup = torch.randn(var.shape, generator=g)
@@ -87,8 +88,8 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     finally:
         emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_nowin", 0)
-        emul_lib.call("mvs_set_tuning", b"bwd_cpt", 4)
-        emul_lib.call("mvs_set_tuning", b"bwd_pf", 1)
+        emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
     got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
     for t in [ref] + srcs:
         t.grad = None
@@ -221,6 +222,7 @@ def test_conv_epilogue_and_bn(emul_lib):
         assert float((ye - yre).abs().max()) < 2e-4
 
 
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="2 minutes of emulation; set MVS_EMUL_FULL=1 (the same golden runs on the GPU in test_gpu_parity.py::test_golden_costregnet_mvs; the per-layer conv family runs by default)")
 def test_costregnet_golden(emul_lib):
     from mvs_amd.jdacs.models.mvsnet import CostRegNet
     g = load_golden("g4_costregnet_mvs")
@@ -387,7 +389,7 @@ def test_conv_c8_broadcast_operand_forward(emul_lib, cin, dims, xcd):
     (scale/shift/relu/skip), BN stat partials and both tile orders vs F.conv3d (mvsnet.py:40 conv0, network.py:47)."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(cin + dims[1])
-    x = torch.randn(2 if cin == 8 else 1, cin, *dims, generator=g)   # (the emulated MFMA is a 64-thread barrier: keep the tile count small)
+    x = torch.randn(2 if (cin == 8 and dims[2] == 33) else 1, cin, *dims, generator=g)   # (the emulated MFMA is a 64-thread barrier: keep the tile count small)
     w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
     yr = F.conv3d(x, w, padding=1)
     emul_lib.call("mvs_set_tuning", b"k8", 7)
@@ -554,6 +556,7 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
         assert float((gx - xr.grad).abs().max()) < 3e-4
 
 
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="45 s of emulation; set MVS_EMUL_FULL=1 (the GPU version is test_gpu_parity.py::test_featurenet_hip_convs_vs_stock; test_conv2d_family runs by default)")
 def test_featurenet_through_hip_convs(emul_lib, monkeypatch):
     """FeatureNet (mvsnet.py:17-34) with its convolutions through csrc/conv2d.hip (ConvBnReLU.hip_conv) vs the stock path:
     three views batched with per-view BatchNorm statistics, forward + parameter gradients."""

@@ -114,11 +114,12 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     refg = ref.to(dev).requires_grad_(True)
     srcg = [s.to(dev).requires_grad_(True) for s in srcs]
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
-    # variant 3 = ... with 8 channels per thread for <= 2 source views, variant 4 = ... without the lookahead staging
+    # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
+    # wave/SIMD for 3-4 source views
     lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
-    lib.call("mvs_set_tuning", b"bwd_cpt", 8 if variant == 3 else 4)
-    lib.call("mvs_set_tuning", b"bwd_pf", 0 if variant == 4 else 1)
+    lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
+    lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else 0)
     try:
         var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
         gup = torch.randn(var.shape, generator=g)
@@ -127,8 +128,8 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     finally:
         lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         lib.call("mvs_set_tuning", b"bwd_nowin", 0)
-        lib.call("mvs_set_tuning", b"bwd_cpt", 4)
-        lib.call("mvs_set_tuning", b"bwd_pf", 1)
+        lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        lib.call("mvs_set_tuning", b"bwd_pf", 0)
     refc = ref.clone().requires_grad_(True)
     srcc = [s.clone().requires_grad_(True) for s in srcs]
     exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)

@@ -93,21 +93,20 @@ def main():
         v5 = ops.plane_sweep_variance(f5[0], f5[1:], rot5, trans5, depth)
         gv5 = torch.randn_like(v5)
         nbytes = C * vox * 4 + 2 * (ns_ + 1) * C * H * W * 4
-        for variant, cpt, pf, dslab in ((1, 8, 0, 0), (0, 8, 0, 0), (0, 8, 1, 0), (0, 4, 0, 0), (0, 4, 1, 0), (0, 4, 1, 32), (0, 4, 1, 48),
-                                        (0, 4, 1, 64), (0, 4, 2, 0), (0, 4, 0, 0), (0, 4, 2, 0)):
-            if ns_ > 2 and cpt == 8:
-                continue
+        for variant, gd, pf, dslab in ((1, 2, 0, 0), (0, 0, 0, 0), (0, 2, 0, 0), (0, 2, 0, 32), (0, 2, 0, 64), (0, 2, 0, 96), (0, 2, 2, 0),
+                                       (0, 0, 0, 0), (0, 2, 0, 0)):
             lib.call("mvs_set_tuning", b"sweep_bwd", variant)
             lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
-            lib.call("mvs_set_tuning", b"bwd_cpt", cpt)
+            lib.call("mvs_set_tuning", b"bwd_gd", gd)
             lib.call("mvs_set_tuning", b"bwd_pf", pf)
-            add("sweep_bwd N=%d [%s%s]%s" % (ns_ + 1, "per-wave windows, %d ch/thread%s" % (cpt, (", lookahead" if pf == 1 else ", 1 wave/SIMD") if pf else "") if variant == 0
+            add("sweep_bwd N=%d [%s%s]%s" % (ns_ + 1, "per-wave windows, %s%s" % ("gradient 2 planes ahead" if gd == 2 else "rotating gradient set",
+                                                                                   ", 1 wave/SIMD (3-4 views)" if pf == 2 else "") if variant == 0
                                              else "view pairs + LDS atomics", ", dslab %d" % dslab if dslab else "", label),
                 lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
         lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         lib.call("mvs_set_tuning", b"bwd_dslab", 0)
-        lib.call("mvs_set_tuning", b"bwd_cpt", 4)
-        lib.call("mvs_set_tuning", b"bwd_pf", 1)
+        lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        lib.call("mvs_set_tuning", b"bwd_pf", 0)
 
     sweep_bwd_case(NS, "")
     sweep_bwd_case(4, "")
