@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     __shared__ int s_win[4][NS_T][5];                // per wave and view: x0, y0, w, h, usable
     __shared__ int s_fit[4];
     __shared__ float red[8];
+    __shared__ float s_dep[4][64];                   // per wave: the per-plane depth hypotheses of 64 planes of the segment
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int q = lane % LPP, pl = lane / LPP;
     const int bx0 = (blockIdx.x % a.tiles_x) * (2 * BW) + (wv & 1) * BW, by0 = (blockIdx.x / a.tiles_x) * (2 * BH) + (wv >> 1) * BH;
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     const float cxa = (float)min(bx0, a.W - 1), cxb = (float)min(bx0 + BW - 1, a.W - 1);
     const float cya = (float)min(by0, a.H - 1), cyb = (float)min(by0 + BH - 1, a.H - 1);
     float* const wwin = lds + (size_t)wv * NS_T * VIEW_FLOATS;     // this wave's windows
-    constexpr float4 z4{0.f, 0.f, 0.f, 0.f};   // a constant, not an object: captured by the lambdas below it would live in scratch
+#define z4 (make_float4(0.f, 0.f, 0.f, 0.f))   /* a literal: a const object captured by the lambdas below lives in scratch */
 
     int ds = blockIdx.y * a.dslab;
     const int dend = min(a.D, ds + a.dslab);
@@ -1050,28 +1051,36 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
             };
             const float* __restrict__ gptr = a.gvar + (((size_t)b * a.D + ds) * HW + pix) * C + cq;
             const size_t gstep = (size_t)HW * C;
-            // upstream gradient.  GD = 2: requested two planes ahead into three register sets used in rotation, the plane loop
-            // unrolled by three so that no set is ever copied (a loop-carried copy `g = g_next` makes the compiler wait for the load
-            // at the END of the plane that issued it: most of an HBM round trip exposed per plane).  GD = 0: that copy form, which is
-            // what fits the 170 registers of 3 waves/SIMD
-            constexpr int AH = GD == 0 ? 1 : GD;   // planes ahead
-            float4 g0[V], g1[GD == 2 ? V : 1], g2[GD == 2 ? V : 1];
+            // upstream gradient: the planes of the NEXT group (GD = 0: one plane, 3 waves/SIMD; GD = 2: two planes, 2 waves/SIMD) are
+            // requested at the TOP of the current group and taken over at its end, so their HBM round trip overlaps a whole group
+            // of arithmetic.  (Requested in the middle of a plane and copied at its end they had ~65 instructions of cover: most of
+            // a round trip exposed per plane.  Rotating three register sets through an unrolled loop does not work with hipcc: the
+            // loop-carried sets are copied anyway and every copy waits for the request just issued.)
+            constexpr int G = GD == 2 ? 2 : 1;
+            float4 gc[G][V], gn[G][V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                g0[k] = ld4(gptr + CK * k);
-                if constexpr (GD == 2) g1[k] = ds + 1 < de ? ld4(gptr + gstep + CK * k) : z4;
-            }
-            // depth of plane d: per-plane hypotheses are ONE value per (sample, plane) -> a scalar load (its own counter: a vector
-            // load here would be waited for by every vmcnt(0) that follows a re-gather); per-pixel hypotheses a vector load
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int k = 0; k < V; ++k) gc[j][k] = ld4(gptr + (size_t)min(j, de - 1 - ds) * gstep + CK * k);
+            // depth of plane d.  Per-plane hypotheses (one value per sample and plane) are staged 64 planes at a time in the wave's
+            // own LDS row and read back one plane ahead: a global load here (hipcc emits a VECTOR load, the kernel also stores) sits
+            // in the same in-order queue as the upstream-gradient requests, and waiting for it drains them.  Per-pixel hypotheses:
+            // a vector load per plane.
             auto depth_of = [&](int d) __attribute__((always_inline)) -> float {
                 if constexpr (!PPD) {
                     if (a.per_pixel) return a.depth[((size_t)b * a.D + d) * HW + pix];
                 }
-                return a.depth[MVS_UNIFORM_I(b * a.D + d)];
+                const int i = d - ds;
+                if ((i & 63) == 0) {                 // wave-uniform; a wave's DS operations execute in order
+                    MVS_WAVE_SYNC();
+                    if (d + lane < de) s_dep[wv][lane] = a.depth[b * a.D + d + lane];
+                    MVS_WAVE_SYNC();
+                }
+                return s_dep[wv][i & 63];
             };
             float dep_next = depth_of(ds);
-            // one plane: gu = the plane's upstream gradient, gl = the set that receives plane d + GD
-            auto plane = [&](const int d, float4 (&gu)[V], float4 (&gl)[V]) __attribute__((always_inline)) {
+            // one plane: gu = the plane's upstream gradient
+            auto plane = [&](const int d, const float4 (&gu)[V]) __attribute__((always_inline)) {
                 float fwx[NS_T], fwy[NS_T];
                 {
                     // the plane's depth was requested one plane ahead: a load issued here is consumed by the very next instruction,
@@ -1114,8 +1123,6 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                     const float ex = 1.0f - wx, ey = 1.0f - wy;
                     wt[s][0] = ey * ex; wt[s][1] = ey * wx; wt[s][2] = wy * ex; wt[s][3] = wy * wx;
                 }
-                const bool more = d + AH < de;
-                const float* __restrict__ gnx = gptr + (size_t)(d + AH - ds) * gstep;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     float4 S = WARP_ONLY ? z4 : (MS_ALIAS ? make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w) : r[k]);
@@ -1132,7 +1139,6 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                         }
                     }
                     const float4 g = gu[k];
-                    if (more) gl[k] = ld4(gnx + CK * k);
                     float4 gs = make_float4(g.x * two_n, g.y * two_n, g.z * two_n, g.w * two_n);   // g * 2/N (0 on dead lanes)
                     float4 Sm = make_float4(S.x * inv_n, S.y * inv_n, S.z * inv_n, S.w * inv_n);
                     if (WARP_ONLY) {
@@ -1163,14 +1169,22 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 }
             };
 #pragma clang loop unroll(disable)
-            for (int d = ds; d < de; d += GD + 1) {
-                if constexpr (GD == 2) {
-                    plane(d, g0, g2);
-                    if (d + 1 < de) plane(d + 1, g1, g0);
-                    if (d + 2 < de) plane(d + 2, g2, g1);
-                } else {
-                    plane(d, g0, g0);   // `g = g0[k]; g0[k] = <plane d + 1>`: the copy-rotation form
+            for (int d = ds; d < de; d += G) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const float* __restrict__ gnx = gptr + (size_t)(min(d + G + j, de - 1) - ds) * gstep;   // clamped: always a valid plane
+#pragma unroll
+                    for (int k = 0; k < V; ++k) gn[j][k] = ld4(gnx + CK * k);
                 }
+                MVS_SCHED_FENCE();
+                plane(d, gc[0]);
+                if constexpr (G == 2) {
+                    if (d + 1 < de) plane(d + 1, gc[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) gc[j][k] = gn[j][k];
             }
             // the blocks still held in registers
 #pragma unroll
@@ -1372,6 +1386,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     }
     return mvs_check_launch("plane_sweep_variance_fwd");
 }
+
+#undef z4
 
 template <int C, int NS_T, int GD, int WPS>
 static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {

@@ -61,6 +61,35 @@ def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
     for a, t in zip(got, [ref] + srcs):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
+@pytest.mark.parametrize("c,ns,d,gd", [(8, 2, 67, 2), (16, 1, 66, 2), (8, 2, 65, 0)])
+def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
+    """One depth segment longer than 64 planes with a narrow depth range (the backward stages the per-plane hypotheses 64 planes
+    at a time and takes the upstream gradient over in groups of 1 or 2 planes: odd / even tails, refill of the staging row)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 1, 6, 9
+    rot, trans = _cams(b, ns, h, w, g)
+    ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+    srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
+    depth = (430 + 1.5 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    emul_lib.call("mvs_set_tuning", b"bwd_gd", gd)
+    emul_lib.call("mvs_set_tuning", b"bwd_dslab", d)
+    try:
+        var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+        gup = torch.randn(var.shape, generator=g)
+        var.backward(gup)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        emul_lib.call("mvs_set_tuning", b"bwd_dslab", 0)
+    got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
+    for t in [ref] + srcs:
+        t.grad = None
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
+    for a, t in zip(got, [ref] + srcs):
+        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("c,ns,step,hw", [(32, 2, 400.0, (13, 21)), (16, 3, 150.0, (10, 18))])

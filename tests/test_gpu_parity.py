@@ -137,6 +137,38 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     for a, t in zip([refg] + srcg, [refc] + srcc):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
+@pytest.mark.parametrize("c,ns,d,gd", [(32, 2, 131, 2), (16, 1, 130, 2), (32, 2, 129, 0), (8, 4, 70, 2)])
+def test_plane_sweep_backward_long_segment(dev, c, ns, d, gd):
+    """One depth segment longer than 64 planes with a narrow depth range: the backward stages the per-plane hypotheses 64 planes
+    at a time and takes the upstream gradient over in groups of 1 or 2 planes (odd / even tails, refills of the staging row)."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 1, 20, 28
+    rot, trans = _cams(b, ns, h, w)
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 1.5 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    refg = ref.to(dev).requires_grad_(True)
+    srcg = [s.to(dev).requires_grad_(True) for s in srcs]
+    lib.call("mvs_set_tuning", b"bwd_gd", gd)
+    lib.call("mvs_set_tuning", b"bwd_dslab", d)
+    try:
+        var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
+        gup = torch.randn(var.shape, generator=g)
+        var.backward(gup.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        lib.call("mvs_set_tuning", b"bwd_dslab", 0)
+    refc = ref.clone().requires_grad_(True)
+    srcc = [s.clone().requires_grad_(True) for s in srcs]
+    exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
+    for a, t in zip([refg] + srcg, [refc] + srcc):
+        assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
+
+
 
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops
