@@ -898,7 +898,8 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
 // MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
 // GD: 0 = the upstream gradient of the next plane in ONE rotating register set (fits 3 waves/SIMD), 2 = requested two planes ahead into
 // three sets (2 waves/SIMD).  PPD: per-plane depth hypotheses only (scalar depth loads; the generic form decides at run time)
-template <int C, int NS_T, int CPT, int MODE, int GD, int WPS, bool PPD>
+// PFL: block lookahead -- the 2x2 block a lane enters on the NEXT plane is requested one plane ahead into staging registers
+template <int C, int NS_T, int CPT, int MODE, int GD, int WPS, bool PPD, bool PFL = false>
 __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_variance_bwd_pw_kernel(SweepArgs a) {
     constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
     using Cfg = PwCfg<C, CPT>;
@@ -1079,27 +1080,89 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 return s_dep[wv][i & 63];
             };
             float dep_next = depth_of(ds);
+            // PFL: sample position of the plane about to be processed + the staged block of the lanes that enter a new one there
+            int nx[PFL ? NS_T : 1], ny[PFL ? NS_T : 1];
+            float nwx[PFL ? NS_T : 1], nwy[PFL ? NS_T : 1];
+            float4 s00[PFL ? NS_T : 1][V], s01[PFL ? NS_T : 1][V], s10[PFL ? NS_T : 1][V], s11[PFL ? NS_T : 1][V];
+            if constexpr (PFL) {
+#pragma unroll
+                for (int s = 0; s < NS_T; ++s) {
+                    locate(s, dep_next, nx[s], ny[s], nwx[s], nwy[s]);
+                    gather(s, nx[s], ny[s], s00[s], s01[s], s10[s], s11[s]);
+                }
+                if (ds + 1 < de) dep_next = depth_of(ds + 1);
+            }
             // one plane: gu = the plane's upstream gradient
             auto plane = [&](const int d, const float4 (&gu)[V]) __attribute__((always_inline)) {
                 float fwx[NS_T], fwy[NS_T];
-                {
+                if constexpr (PFL) {
+                    // (a) lanes whose sample point left their block: flush the accumulators, take over the staged block (requested
+                    // a whole plane ago: the wait is short)
+                    bool chg[NS_T], any = false;
+#pragma unroll
+                    for (int s = 0; s < NS_T; ++s) {
+                        chg[s] = nx[s] != blk[s].cx || ny[s] != blk[s].cy;
+                        any = any || chg[s];
+                        fwx[s] = nwx[s]; fwy[s] = nwy[s];
+                    }
+                    if (MVS_ANY(any)) {
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s)
+                            if (MVS_ANY(chg[s]))
+                                pw_flush_groups<C, V, CK, LPP>(chg[s] && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
+                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s) {
+#pragma unroll
+                            for (int k = 0; k < V; ++k) { MVS_PIN4(s00[s][k]); MVS_PIN4(s01[s][k]); MVS_PIN4(s10[s][k]); MVS_PIN4(s11[s][k]); }
+                            if (chg[s]) {
+                                blk[s].cx = nx[s]; blk[s].cy = ny[s];
+#pragma unroll
+                                for (int k = 0; k < V; ++k) {
+                                    blk[s].t00[k] = s00[s][k]; blk[s].t01[k] = s01[s][k]; blk[s].t10[k] = s10[s][k]; blk[s].t11[k] = s11[s][k];
+                                    blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
+                                }
+                            }
+                        }
+                    }
+                    // (b) one plane ahead: request the blocks that will be entered there
+                    if (d + 1 < de) {
+                        const float dep1 = dep_next;
+                        if (d + 2 < de) dep_next = depth_of(d + 2);
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s) {
+                            locate(s, dep1, nx[s], ny[s], nwx[s], nwy[s]);
+                            if (nx[s] != blk[s].cx || ny[s] != blk[s].cy) gather(s, nx[s], ny[s], s00[s], s01[s], s10[s], s11[s]);
+                        }
+                    }
+                } else {
                     // the plane's depth was requested one plane ahead: a load issued here is consumed by the very next instruction,
                     // i.e. every plane would start with a full memory round trip
                     const float dep = dep_next;
                     if (d + 1 < de) dep_next = depth_of(d + 1);
+                    int x0[NS_T], y0[NS_T];
+                    bool chg[NS_T], any = false;
 #pragma unroll
                     for (int s = 0; s < NS_T; ++s) {
-                        int x0, y0;
-                        locate(s, dep, x0, y0, fwx[s], fwy[s]);
-                        const bool chg = x0 != blk[s].cx || y0 != blk[s].cy;
-                        if (MVS_ANY(chg)) {
-                            // request the new block first (the flush below needs the accumulators and the OLD base texel, not
-                            // the tap values): the L2 round trip of the gather overlaps the LDS round trips of the flush
-                            if (chg) gather(s, x0, y0, blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
-                            pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                           wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
-                            if (chg) {
-                                blk[s].cx = x0; blk[s].cy = y0;
+                        locate(s, dep, x0[s], y0[s], fwx[s], fwy[s]);
+                        chg[s] = x0[s] != blk[s].cx || y0[s] != blk[s].cy;
+                        any = any || chg[s];
+                    }
+                    if (MVS_ANY(any)) {
+                        // ALL views' new blocks are requested first, then the flushes (they need the accumulators and the OLD base
+                        // texel, not the tap values), then ONE wait: a round per view serialises one L2 round trip per view and plane
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s)
+                            if (chg[s]) gather(s, x0[s], y0[s], blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s)
+                            if (MVS_ANY(chg[s]))
+                                pw_flush_groups<C, V, CK, LPP>(chg[s] && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
+                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+#pragma unroll
+                        for (int s = 0; s < NS_T; ++s) {
+                            if (chg[s]) {
+                                blk[s].cx = x0[s]; blk[s].cy = y0[s];
 #pragma unroll
                                 for (int k = 0; k < V; ++k) blk[s].g00[k] = blk[s].g01[k] = blk[s].g10[k] = blk[s].g11[k] = z4;
                             }
@@ -1270,7 +1333,7 @@ extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
-static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 2 = ONE wave per SIMD for 3-4 source views (1, the removed block-lookahead form, is accepted and ignored)
+static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
@@ -1389,7 +1452,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 
 #undef z4
 
-template <int C, int NS_T, int GD, int WPS>
+template <int C, int NS_T, int GD, int WPS, bool PFL = false>
 static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     constexpr int CPT = 4;   // 8 channels per thread measured slower at every occupancy (0.46-0.52 vs 0.41 ms, round 2 run 7)
     using Cfg = PwCfg<C, CPT>;
@@ -1405,10 +1468,10 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     a.no_window = g_sweep_bwd_nowin;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     if (a.warp_only) {
-        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, GD, WPS, false>), grid, block, 0, st, a);
-    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1, GD, WPS, false>), grid, block, 0, st, a);
-    else if (a.per_pixel) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, false>), grid, block, 0, st, a);
-    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, true>), grid, block, 0, st, a);
+        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, GD, WPS, false, PFL>), grid, block, 0, st, a);
+    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 1, GD, WPS, false, PFL>), grid, block, 0, st, a);
+    else if (a.per_pixel) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, false, PFL>), grid, block, 0, st, a);
+    else MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, NS_T, CPT, 0, GD, WPS, true, PFL>), grid, block, 0, st, a);
     return mvs_check_launch("plane_sweep_variance_bwd_pw");
 }
 
@@ -1418,6 +1481,10 @@ static int launch_bwd(SweepArgs& a, hipStream_t st) {
         // 1-2 views: 2 waves per SIMD with the upstream gradient requested two planes ahead (knob "bwd_gd" = 0: 3 waves per SIMD, one
         // rotating register set); 3-4 views: 2 waves per SIMD (knob "bwd_pf" = 2: ONE wave per SIMD, 512 registers, nothing spills)
         const bool gd2 = g_sweep_bwd_gd == 2;
+        if (g_sweep_bwd_pf == 1 && a.NS <= 2) {   // knob "bwd_pf" = 1: block lookahead (2 waves/SIMD, one-plane groups)
+            if (a.NS == 1) return launch_bwd_pw<C, 1, 0, 2, true>(a, st);
+            return launch_bwd_pw<C, 2, 0, 2, true>(a, st);
+        }
         if (a.NS == 1) return gd2 ? launch_bwd_pw<C, 1, 2, 2>(a, st) : launch_bwd_pw<C, 1, 0, 3>(a, st);
         if (a.NS == 2) return gd2 ? launch_bwd_pw<C, 2, 2, 2>(a, st) : launch_bwd_pw<C, 2, 0, 3>(a, st);
         if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 2, 1>(a, st) : launch_bwd_pw<C, 3, 0, 2>(a, st);

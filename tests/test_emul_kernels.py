@@ -61,7 +61,7 @@ def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
     for a, t in zip(got, [ref] + srcs):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
-@pytest.mark.parametrize("c,ns,d,gd", [(8, 2, 67, 2), (16, 1, 66, 2), (8, 2, 65, 0)])
+@pytest.mark.parametrize("c,ns,d,gd", [(8, 2, 67, 2), (16, 1, 66, 2), (8, 2, 65, 0), (8, 2, 66, -1)])
 def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
     """One depth segment longer than 64 planes with a narrow depth range (the backward stages the per-plane hypotheses 64 planes
     at a time and takes the upstream gradient over in groups of 1 or 2 planes: odd / even tails, refill of the staging row)."""
@@ -72,7 +72,8 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
     ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
     srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
     depth = (430 + 1.5 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
-    emul_lib.call("mvs_set_tuning", b"bwd_gd", gd)
+    emul_lib.call("mvs_set_tuning", b"bwd_gd", max(gd, 0))
+    emul_lib.call("mvs_set_tuning", b"bwd_pf", 1 if gd < 0 else 0)   # gd = -1: the block-lookahead form
     emul_lib.call("mvs_set_tuning", b"bwd_dslab", d)
     try:
         var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
@@ -80,6 +81,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
         var.backward(gup)
     finally:
         emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_dslab", 0)
     got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
     for t in [ref] + srcs:
@@ -91,7 +93,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
 
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("c,ns,step,hw", [(32, 2, 400.0, (13, 21)), (16, 3, 150.0, (10, 18))])
 def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, variant):
     """Footprints larger than an accumulation window: depth segmentation + global-atomic path (both backward kernels)."""
@@ -105,11 +107,11 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
-    # wave/SIMD for 3-4 source views
+    # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
     emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
-    emul_lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else 0)
+    emul_lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else (1 if variant == 5 else 0))
     try:
         var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
         gup = torch.randn(var.shape, generator=g)

@@ -98,7 +98,7 @@ def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("c,ns,step", [(32, 2, 60.0), (32, 2, 400.0), (16, 3, 150.0), (32, 4, 90.0)])
 def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     """Backward with footprints that do not fit one accumulation window: depth segmentation and, for the widest range,
@@ -115,11 +115,11 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     srcg = [s.to(dev).requires_grad_(True) for s in srcs]
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
-    # wave/SIMD for 3-4 source views
+    # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
     lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
     lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
     lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
-    lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else 0)
+    lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else (1 if variant == 5 else 0))
     try:
         var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
         gup = torch.randn(var.shape, generator=g)
@@ -137,7 +137,7 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     for a, t in zip([refg] + srcg, [refc] + srcc):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
-@pytest.mark.parametrize("c,ns,d,gd", [(32, 2, 131, 2), (16, 1, 130, 2), (32, 2, 129, 0), (8, 4, 70, 2)])
+@pytest.mark.parametrize("c,ns,d,gd", [(32, 2, 131, 2), (16, 1, 130, 2), (32, 2, 129, 0), (8, 4, 70, 2), (32, 2, 130, -1)])
 def test_plane_sweep_backward_long_segment(dev, c, ns, d, gd):
     """One depth segment longer than 64 planes with a narrow depth range: the backward stages the per-plane hypotheses 64 planes
     at a time and takes the upstream gradient over in groups of 1 or 2 planes (odd / even tails, refills of the staging row)."""
@@ -151,7 +151,8 @@ def test_plane_sweep_backward_long_segment(dev, c, ns, d, gd):
     depth = (430 + 1.5 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     refg = ref.to(dev).requires_grad_(True)
     srcg = [s.to(dev).requires_grad_(True) for s in srcs]
-    lib.call("mvs_set_tuning", b"bwd_gd", gd)
+    lib.call("mvs_set_tuning", b"bwd_gd", max(gd, 0))
+    lib.call("mvs_set_tuning", b"bwd_pf", 1 if gd < 0 else 0)   # gd = -1: the block-lookahead form
     lib.call("mvs_set_tuning", b"bwd_dslab", d)
     try:
         var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
@@ -160,6 +161,7 @@ def test_plane_sweep_backward_long_segment(dev, c, ns, d, gd):
         torch.cuda.synchronize()
     finally:
         lib.call("mvs_set_tuning", b"bwd_gd", 2)
+        lib.call("mvs_set_tuning", b"bwd_pf", 0)
         lib.call("mvs_set_tuning", b"bwd_dslab", 0)
     refc = ref.clone().requires_grad_(True)
     srcc = [s.clone().requires_grad_(True) for s in srcs]

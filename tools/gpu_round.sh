@@ -68,13 +68,13 @@ if [ "$what" = "runE" ]; then
   # K2 with group-ahead gradient requests + LDS-staged depths: parity subset, then A/B of the two forms in the training step
   MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -k "sweep or homo or golden_mvsnet or config2_train or config3_self" > gpurun_out/pytest_runE.log 2>&1
   echo "pytest exit $?" >> gpurun_out/pytest_runE.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_runE.log | tail -12
-  for t in "bwd_gd=0" "bwd_gd=2"; do
+  for t in ${RUNE_SET:-"bwd_gd=0" "bwd_gd=2"}; do
     MVS_TUNING=$t timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
     echo "bench [$t] exit $?"; python -c "
 import json,sys
 d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"
   done
-  for t in "bwd_gd=2" "bwd_pf=2"; do
+  for t in ${RUNE_SET3:-"bwd_gd=2" "bwd_pf=2"}; do
     MVS_TUNING=$t timeout 300 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 > "gpurun_out/bench_c3_[$t].json" 2> "gpurun_out/bench_c3_[$t].err"; python -c "
 import json,sys
 d=json.load(open(sys.argv[1])); print('config 3', sys.argv[1], d['ms_per_step'], d['value'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" "gpurun_out/bench_c3_[$t].json"
