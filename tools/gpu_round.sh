@@ -64,6 +64,21 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "sqk2" ]; then
+  # what the waves of the sweep kernels wait for: average LDS / vector-memory / scalar-memory latency (INST_LEVEL / INSTS) and issue counts
+  export MVS_PMC_SWEEP_ONLY=1
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU" \
+             "SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_FLAT SQ_INST_LEVEL_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM"; do
+    i=$((i+1)); rm -rf gpurun_out/pmc_S$i
+    (cd /tmp && timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_S$i" -o pmc -- \
+        python "$OLDPWD/tools/pmc_driver.py" > "$OLDPWD/gpurun_out/pmc_S$i.log" 2>&1); echo "pmc S$i exit $?"; tail -n 2 gpurun_out/pmc_S$i.log
+  done
+  python tools/pmc_summary.py gpurun_out/pmc_S1 gpurun_out/pmc_S2 > gpurun_out/pmc_sq_k2.json; python -c "
+import json; d=json.load(open('gpurun_out/pmc_sq_k2.json'))
+for k,v in d.items(): print(k, {c:round(x['mean']) for c,x in v.items()})"
+  rm -rf gpurun_out/pmc_S1 gpurun_out/pmc_S2
+fi
 if [ "$what" = "runE" ]; then
   # K2 with group-ahead gradient requests + LDS-staged depths: parity subset, then A/B of the two forms in the training step
   MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -k "sweep or homo or golden_mvsnet or config2_train or config3_self" > gpurun_out/pytest_runE.log 2>&1
