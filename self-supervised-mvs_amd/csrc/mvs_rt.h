@@ -30,6 +30,7 @@ static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
 #define MVS_QUAD_BCAST_I(v, s) mvs_quad_bcast_i((v), (s))
 #define MVS_QUAD_BCAST_F(v, s) __int_as_float(mvs_quad_bcast_i(__float_as_int(v), (s)))
 #define MVS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // register budget 512 / n per wave
+#define MVS_MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))   // at least n waves per SIMD: caps the register allocation
 #define MVS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)   // the instruction scheduler moves nothing across this point
 #define MVS_F2I(x) __float2int_rz(x)   // v_cvt_i32_f32: saturating
 // "these four registers are needed now": the compiler places the s_waitcnt for the loads that produce them here instead of at their

@@ -207,7 +207,11 @@ template <int C, int CPT> struct TileC {
 // is busy 73 % of the time.  Bit-identical results.  Variant 6 of the "sweep_fwd" knob; not yet measured on the GPU.
 // BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns CPT
 // CONSECUTIVE channels so that its values are one 16- (8-) byte store and the lanes of a pixel write one 64-byte segment.
-template <int C, int NS_T, int CPT, bool QS = false, bool BF = false>
+// DL (per-plane hypotheses only): the slab's depths are staged in LDS once and read back one plane ahead, and the taps of a
+// re-gather are waited for INSIDE the re-gather block.  Without it the plane loop starts with a vmcnt(0) (the depth is a vector
+// load) that also waits for the previous plane's stores -- on gfx9 stores and loads share the counter -- and every plane pays a
+// second vmcnt(0) at the join after the re-gather blocks whether or not a lane re-gathered.
+template <int C, int NS_T, int CPT, bool QS = false, bool BF = false, int DL = 0>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
     constexpr int V = CPT / 4;                     // float4s per tap per thread
@@ -218,6 +222,13 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const int q = tid % LPP, pl = tid / LPP;
     const int xr = (blockIdx.x % a.tiles_x) * TW + pl % TW, yr = (blockIdx.x / a.tiles_x) * TH + pl / TW;
     const int b = blockIdx.z;
+    const int d0 = blockIdx.y * a.dslab;
+    const int d1 = min(a.D, d0 + a.dslab);
+    __shared__ float s_dep[DL ? 512 : 1];            // DL: the launcher keeps a slab <= 512 planes
+    if constexpr (DL != 0) {
+        for (int i = tid; i < d1 - d0; i += 256) s_dep[i] = a.depth[b * a.D + d0 + i];
+        __syncthreads();
+    }
     if (!QS) {
         if (xr >= a.W || yr >= a.H) return;  // no barriers / cross-lane ops below
     }
@@ -225,8 +236,6 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const bool live = !QS || (xr < a.W && yr < a.H);
     const int x = live ? xr : 0, y = live ? yr : 0;
     const int HW = a.H * a.W, pix = y * a.W + x;
-    const int d0 = blockIdx.y * a.dslab;
-    const int d1 = min(a.D, d0 + a.dslab);
     const float xf = (float)x, yf = (float)y;
     // channel of float4 k of lane q: 4q + 4*LPP*k, so that ONE store instruction writes whole 64-byte segments
     // (with CPT*q + 4k every store instruction wrote 16 of each 32 bytes: 5 % slower, profiles/r01_run19_kernels.log)
@@ -267,10 +276,15 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     // instruction: one memory round trip per plane; the same change took the backward from 0.41 to 0.34 ms)
     const float* __restrict__ dptr = a.depth + (a.per_pixel ? ((size_t)b * a.D + d0) * HW + pix : (size_t)b * a.D + d0);
     const size_t dstep = a.per_pixel ? (size_t)HW : 1;
-    float dep_next = dptr[0];
+    float dep_next;
+    if constexpr (DL != 0) dep_next = s_dep[0];
+    else dep_next = dptr[0];
     for (int d = d0; d < d1; ++d) {
         const float dep = dep_next;
-        if (d + 1 < d1) dep_next = dptr[(size_t)(d + 1 - d0) * dstep];
+        if (d + 1 < d1) {
+            if constexpr (DL != 0) dep_next = s_dep[d + 1 - d0];
+            else dep_next = dptr[(size_t)(d + 1 - d0) * dstep];
+        }
         float4 S[V], Q[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
@@ -314,12 +328,24 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
                 const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (DL == 2 && xin0 && xin1 && yin0 && yin1) {   // common case: the four loads back to back, no selects
 #pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
-                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
-                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
-                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
+                    for (int k = 0; k < V; ++k) {
+                        t00[s][k] = ld4(f + ck * k); t01[s][k] = ld4(f + C + ck * k);
+                        t10[s][k] = ld4(f + a.W * C + ck * k); t11[s][k] = ld4(f + a.W * C + C + ck * k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                        t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                        t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                        t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
+                    }
+                }
+                if constexpr (DL == 2) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) { MVS_PIN4(t00[s][k]); MVS_PIN4(t01[s][k]); MVS_PIN4(t10[s][k]); MVS_PIN4(t11[s][k]); }
                 }
             }
             const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
@@ -1360,6 +1386,7 @@ extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views), 1 = view-pair kernel with LDS atomics
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
+static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 static int g_sweep_bwd_nowin = 0;     // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 static int g_sweep_bwd_dslab = 0;     // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
@@ -1373,7 +1400,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1414,6 +1441,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             while (slab > 8 && tiles * mvs_cdiv(a.D, slab) < 5000) slab = (slab + 1) / 2;
             a.dslab = slab;
         }
+        const int dl = a.per_pixel ? 0 : g_sweep_fwd_dl;   // knob "fwd_dl": 1 = LDS-staged depths, 2 = + in-block gather waits (per-plane hypotheses)
+        if (dl && a.dslab > 512) a.dslab = 512;
         dim3 gridc(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
         if (a.bf16_out) {
             MVS_REQUIRE(CPT8 == 8, MVS_ERR_UNSUPPORTED, "plane_sweep bf16 volume: needs >= 16 feature channels");
@@ -1427,14 +1456,15 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             int slab = a.D;
             while (slab > 8 && tilesb * mvs_cdiv(a.D, slab) < 5000) slab = (slab + 1) / 2;
             a.dslab = g_sweep_dslab > 0 ? g_sweep_dslab : slab;
+            if (dl && a.dslab > 512) a.dslab = 512;
             dim3 gridb(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
-            switch (a.NS) {
-                case 1: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 1, 8, false, true>), gridb, block, 0, st, a); break;
-                case 2: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 2, 8, false, true>), gridb, block, 0, st, a); break;
-                case 3: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 3, 8, false, true>), gridb, block, 0, st, a); break;
-                case 4: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 4, 8, false, true>), gridb, block, 0, st, a); break;
-                case 6: MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, 6, 4, false, true>), gridb, block, 0, st, a); break;
-            }
+#define MVS_BF_CASE(N, CPTN)                                                                                                   \
+    case N:                                                                                                                    \
+        if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 1>), gridb, block, 0, st, a);      \
+        else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 0>), gridb, block, 0, st, a);         \
+        break;
+            switch (a.NS) { MVS_BF_CASE(1, 8) MVS_BF_CASE(2, 8) MVS_BF_CASE(3, 8) MVS_BF_CASE(4, 8) MVS_BF_CASE(6, 4) }
+#undef MVS_BF_CASE
             return mvs_check_launch("plane_sweep_variance_fwd_cached (bf16 volume)");
         }
 #define MVS_CACHED_CASE(N)                                                                                      \
@@ -1442,7 +1472,10 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
         else if (c8 && variant == 6 && C == 32 && (N == 2 || N == 4))                                            \
             MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, (N == 2 || N == 4) ? N : 2, CPT8, (C == 32 && (N == 2 || N == 4))>), gridc, block, 0, st, a); \
+        else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 2>), gridc, block, 0, st, a); \
+        else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 1>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
+        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, false, 1>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;
         switch (a.NS) {

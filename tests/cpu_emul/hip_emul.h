@@ -185,6 +185,7 @@ static inline void emul_wave_sync() {
 #define MVS_SCHED_FENCE() ((void)0)
 #define MVS_PIN4(v) ((void)0)
 #define MVS_WAVES_PER_SIMD(n)
+#define MVS_MIN_WAVES_PER_SIMD(n)
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) emul_mfma_4x4x1_bc((a), (b), (c), (abid))
 
 static inline float atomicAdd(float* addr, float v) {

@@ -300,6 +300,30 @@ def test_plane_sweep_bwd_segmented_windows(emul_lib):
         assert float(t.grad.abs().max()) > 0
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
+@pytest.mark.parametrize("c,ns", [(32, 2), (16, 3)])
+def test_plane_sweep_fwd_depth_staging_forms_agree(emul_lib, c, ns):
+    """Knob fwd_dl: 0 = depth loaded per plane, 1 = the slab's per-plane depths staged in LDS (default), 2 = + gathers waited
+    for inside the re-gather block.  Same arithmetic: the three volumes are bit-identical."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(9)
+    b, d, h, w = 1, 11, 9, 14
+    rot, trans = _cams(b, ns, h, w, g)
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 35.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    vols = []
+    try:
+        for dl in (0, 1, 2):
+            emul_lib.call("mvs_set_tuning", b"fwd_dl", dl)
+            with torch.no_grad():
+                vols.append(ops.plane_sweep_variance(ref, srcs, rot, trans, depth).clone())
+    finally:
+        emul_lib.call("mvs_set_tuning", b"fwd_dl", 1)
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    assert float((vols[1] - exp).abs().max()) < 2e-4
+    assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2])
+
+
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):

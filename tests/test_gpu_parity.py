@@ -171,6 +171,31 @@ def test_plane_sweep_backward_long_segment(dev, c, ns, d, gd):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
+@pytest.mark.parametrize("c,ns,d", [(32, 2, 48), (16, 3, 21), (32, 6, 9)])
+def test_plane_sweep_fwd_depth_staging_forms_agree(dev, c, ns, d):
+    """Knob fwd_dl: 0 = depth loaded per plane, 1 = the slab's per-plane depths staged in LDS (default), 2 = + gathers waited
+    for inside the re-gather block.  Same arithmetic: the three volumes are bit-identical (and match the oracle)."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(9)
+    b, h, w = 2, 37, 45
+    rot, trans = _cams(b, ns, h, w)
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 9.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    vols = []
+    try:
+        for dl in (0, 1, 2):
+            lib.call("mvs_set_tuning", b"fwd_dl", dl)
+            with torch.no_grad():
+                vols.append(ops.plane_sweep_variance(ref.to(dev), [s.to(dev) for s in srcs], rot.to(dev), trans.to(dev), depth.to(dev)).cpu())
+    finally:
+        lib.call("mvs_set_tuning", b"fwd_dl", 1)
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    assert float((vols[1] - exp).abs().max()) < 2e-4
+    assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2])
+
+
 
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops

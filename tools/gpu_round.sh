@@ -64,6 +64,22 @@ if [ "$what" = "r2" ]; then
   MVS_HIP_FEATURE=1 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_hipfeature.json 2> gpurun_out/bench_hipfeature.err
   echo "bench [MVS_HIP_FEATURE=1] exit $?"; cut -c1-200 gpurun_out/bench_hipfeature.json
 fi
+if [ "$what" = "runF" ]; then
+  # K1 with LDS-staged depths (fwd_dl 0 / 1 / 2): parity subset, A/B in the training step and at config 5 (bf16, N = 7)
+  MVS_SKIP_HEAVY=1 timeout 420 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -k "sweep or homo or golden_mvsnet or config2_train or bf16" > gpurun_out/pytest_runF.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_runF.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_runF.log | tail -12
+  for t in "fwd_dl=0" "fwd_dl=1" "fwd_dl=2"; do
+    MVS_TUNING=$t timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'], {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"
+  done
+  for t in "fwd_dl=0" "fwd_dl=1"; do
+    MVS_TUNING=$t timeout 200 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 > "gpurun_out/bench_c5_[$t].json" 2> "gpurun_out/bench_c5_[$t].err"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print('config 5', sys.argv[1], d['ms_per_step'], d['value'], {k:round(v['ms'],3) for k,v in d['kernels'].items()})" "gpurun_out/bench_c5_[$t].json"
+  done
+fi
 if [ "$what" = "sqk2" ]; then
   # what the waves of the sweep kernels wait for: average LDS / vector-memory / scalar-memory latency (INST_LEVEL / INSTS) and issue counts
   export MVS_PMC_SWEEP_ONLY=1
