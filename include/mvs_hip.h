@@ -37,8 +37,11 @@ const char* mvs_last_error(void);   /* thread-local, valid until the next failin
 int mvs_is_emulation(void);         /* 0 in the product library */
 /* A/B knobs for measurements/tests (full-string keys; an unknown key is MVS_ERR_UNSUPPORTED): "sweep_fwd" 0 taps through
  * L1 | 1 LDS windows | 2,3 register-cached taps (default 3) | 6 quad-shared projection; "sweep_bwd" 0 per-wave windows |
- * 1 view pairs + LDS atomics; "bwd_cpt" 4|8, "bwd_pf" 0|1, "bwd_dslab", "bwd_nowin"; "nt", "tile_w", "dslab";
- * "conv_split", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups".  Process-wide, not part of the data path's contract. */
+ * 1 view pairs + LDS atomics; "fwd_dl" 0 | 1 per-plane depths staged in LDS (default) | 2 + in-block gather waits;
+ * "bwd_gd" 2 (default: 2-plane gradient groups, 2 waves/SIMD) | 0 (1-plane groups, 3 waves/SIMD), "bwd_pf" 0 | 1 block
+ * lookahead (1-2 views) | 2 one wave/SIMD (3-4 views), "bwd_dslab", "bwd_nowin", "bwd_cpt" (ignored); "nt", "tile_w", "dslab";
+ * "conv_split", "conv_small", "conv_small_wgs", "tr2pw", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups".
+ * Process-wide, not part of the data path's contract. */
 int mvs_set_tuning(const char* key, int value);
 
 /* ---- K1/K2: homography warp + variance cost volume -------------------------------------------
