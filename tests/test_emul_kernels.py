@@ -324,6 +324,54 @@ def test_plane_sweep_fwd_depth_staging_forms_agree(emul_lib, c, ns):
     assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2])
 
 
+@pytest.mark.parametrize("c,ns,d,hw,per_pixel", [(8, 1, 1, (2, 3), False), (8, 1, 1, (2, 2), True), (16, 2, 2, (3, 2), False),
+                                                  (32, 1, 3, (2, 5), False)])
+def test_plane_sweep_smallest_shapes(emul_lib, c, ns, d, hw, per_pixel):
+    """The smallest shapes the C ABI accepts (one depth plane, one source view, images of 2 x 2 ... pixels: tiles, slabs and
+    depth segments are all partial), forward and backward."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(21)
+    b = 1
+    h, w = hw
+    rot, trans = _cams(b, ns, 8, 12, g)     # cameras of a larger image: sample points fall in and out of the tiny maps
+    ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+    srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
+    if per_pixel:
+        depth = 450 + 30 * torch.rand(b, d, h, w, generator=g)
+    else:
+        depth = (430 + 35.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    var = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+    gup = torch.randn(var.shape, generator=g)
+    var.backward(gup)
+    got = [ref.grad.clone()] + [s.grad.clone() for s in srcs]
+    for t in [ref] + srcs:
+        t.grad = None
+    exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
+    assert float((var - exp).abs().max()) < 2e-4
+    for a, t in zip(got, [ref] + srcs):
+        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+def test_c_abi_rejects_bad_arguments_with_a_message(emul_lib):
+    """Error behaviour of the boundary (include/mvs_hip.h): unsupported channel counts, too few views, degenerate images and null
+    pointers come back as error codes with a message in mvs_last_error(), and the Python mirror raises ValueError like the
+    reference's shape errors do -- nothing is launched."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(1)
+    rot, trans = _cams(1, 1, 8, 12, g)
+    depth = torch.full((1, 2), 500.0)
+    with pytest.raises(ValueError, match="C must be 8, 16 or 32"):
+        ops.plane_sweep_variance(torch.randn(1, 12, 8, 12), [torch.randn(1, 12, 8, 12)], rot, trans, depth)
+    with pytest.raises(ValueError):
+        ops.plane_sweep_variance(torch.randn(1, 8, 1, 12), [torch.randn(1, 8, 1, 12)], rot, trans, depth)   # H must be > 1
+    with pytest.raises(ValueError):
+        ops.plane_sweep_variance(torch.randn(1, 8, 8, 12), [], rot[:, :0], trans[:, :0], depth)              # no source view
+    with pytest.raises(ValueError, match="unknown|not a tuning key|mvs_set_tuning"):
+        emul_lib.call("mvs_set_tuning", b"no_such_knob", 1)
+    assert emul_lib.raw("mvs_set_tuning", b"bwd", 1) != 0        # full-string keys: a prefix of a real key is rejected
+
+
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):

@@ -196,6 +196,36 @@ def test_plane_sweep_fwd_depth_staging_forms_agree(dev, c, ns, d):
     assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2])
 
 
+@pytest.mark.parametrize("c,ns,d,hw,per_pixel", [(8, 1, 1, (2, 3), False), (8, 1, 1, (2, 2), True), (16, 2, 2, (3, 2), False),
+                                                  (32, 1, 3, (2, 5), False), (32, 4, 1, (5, 3), False)])
+def test_plane_sweep_smallest_shapes(dev, c, ns, d, hw, per_pixel):
+    """The smallest shapes the C ABI accepts (one depth plane, one source view, images of 2 x 2 ... pixels: tiles, slabs and
+    depth segments are all partial), forward and backward."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(21)
+    b = 1
+    h, w = hw
+    rot, trans = _cams(b, ns, 8, 12)        # cameras of a larger image: sample points fall in and out of the tiny maps
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    if per_pixel:
+        depth = 450 + 30 * torch.rand(b, d, h, w, generator=g)
+    else:
+        depth = (430 + 35.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    refg = ref.to(dev).requires_grad_(True)
+    srcg = [s.to(dev).requires_grad_(True) for s in srcs]
+    var = ops.plane_sweep_variance(refg, srcg, rot.to(dev), trans.to(dev), depth.to(dev))
+    gup = torch.randn(var.shape, generator=g)
+    var.backward(gup.to(dev))
+    refc = ref.clone().requires_grad_(True)
+    srcc = [s.clone().requires_grad_(True) for s in srcs]
+    exp = R.plane_sweep_variance(refc, srcc, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
+    exp.backward(gup)
+    assert float((var.detach().cpu() - exp.detach()).abs().max()) < 2e-4
+    for a, t in zip([refg] + srcg, [refc] + srcc):
+        assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
+
+
 
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops
