@@ -226,6 +226,55 @@ def test_plane_sweep_smallest_shapes(dev, c, ns, d, hw, per_pixel):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
+@pytest.mark.parametrize("d,hw,per_pixel", [(1, (1, 1), False), (2, (3, 5), False), (3, (1, 17), True), (5, (2, 9), False), (9, (7, 3), True)])
+def test_softargmin_smallest_shapes(dev, d, hw, per_pixel):
+    """Soft-argmin + confidence at shapes smaller than one wave's 16 pixels x 4 depth slices (D = 1: the confidence window
+    [idx - 1, idx + 2] is clipped on both sides), forward and backward vs the oracle (jdacs/models/module.py:145-151)."""
+    from mvs_amd import ops
+    gen = torch.Generator().manual_seed(d * 10 + hw[1])
+    b = 2
+    h, w = hw
+    lg = torch.randn(b, d, h, w, generator=gen) * 3
+    hyp = 500 + torch.rand(b, d, h, w, generator=gen) * 50 if per_pixel else (425 + 7.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    lgg = lg.to(dev).requires_grad_(True)
+    dep, conf = ops.softargmin_conf(lgg, hyp.to(dev))
+    gd = torch.randn(dep.shape, generator=gen)
+    dep.backward(gd.to(dev))
+    lgc = lg.clone().requires_grad_(True)
+    e, ec, _ = R.softargmin_conf(lgc, hyp)
+    e.backward(gd)
+    assert float((dep.detach().cpu() - e.detach()).abs().max()) < 1e-3 and float((conf.cpu() - ec).abs().max()) < 1e-5
+    assert float((lgg.grad.cpu() - lgc.grad).abs().max()) < 1e-4 * max(1.0, float(lgc.grad.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 8, 1, False, (1, 1, 1)), (32, 8, 1, False, (1, 2, 3)),
+                                                             (8, 16, 2, False, (2, 2, 2)), (16, 8, 2, True, (1, 1, 1)),
+                                                             (16, 16, 1, False, (1, 1, 17)), (8, 1, 1, False, (1, 1, 2)),
+                                                             (64, 64, 1, False, (1, 1, 1)), (64, 32, 2, True, (1, 2, 1))])
+def test_conv3d_smallest_volumes(dev, cin, cout, stride, transposed, dims):
+    """Volumes smaller than one workgroup tile in every dimension (every tile is partial, every tap of some voxels is padding):
+    forward, input gradient and weight gradient vs ATen on the CPU (mvsnet.py:40-74 layer shapes)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + dims[2])
+    x = torch.randn(1, cin, *dims, generator=g, requires_grad=True)
+    if transposed:
+        w = (torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+        yr = F.conv_transpose3d(x, w, stride=stride, padding=1, output_padding=stride - 1)
+    else:
+        w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+        yr = F.conv3d(x, w, stride=stride, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    with torch.no_grad():
+        xg, wg, gyg = x.detach().to(dev), w.detach().to(dev), gy.to(dev)
+        y, _ = ops.conv3d_forward(xg, wg, stride, transposed)
+        gx = ops.conv3d_dgrad(gyg, wg, tuple(x.shape), stride, transposed)
+        gw = ops.conv3d_wgrad(xg, gyg, tuple(w.shape), stride, transposed)
+    assert float((y.cpu() - yr).abs().max()) < 2e-4
+    assert float((gx.cpu() - x.grad).abs().max()) < 3e-4
+    assert float((gw.cpu() - w.grad).abs().max()) < 3e-4 * max(1.0, float(w.grad.abs().max()))
+
+
 
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops
