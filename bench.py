@@ -330,7 +330,8 @@ def main():
             # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
             bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
             # capturable: the step counter lives on the GPU, so a captured optimizer step stays correct when replayed
-            opt = torch.optim.Adam([bucket.flat_param], lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
+            # (as 32 slices of the flat store: a fused multi-tensor optimiser runs one workgroup per tensor chunk)
+            opt = torch.optim.Adam(bucket.optimizer_params(32), lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
 
             def fwd_bwd():
                 bucket.zero()

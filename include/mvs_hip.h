@@ -63,6 +63,11 @@ int mvs_plane_sweep_variance_fwd(const float* ref, const float* const* srcs, con
 int mvs_plane_sweep_variance_fwd_bf16(const float* ref, const float* const* srcs, const float* rot, const float* trans,
                                       const float* depth, int depth_is_per_pixel, int B, int N, int C, int D, int H,
                                       int W, int align_corners, int ms_alias, void* var_out_bf16, hipStream_t stream);
+/* rot [B,NS,9] / trans [B,NS,3] of src_proj[b,s] @ inverse(ref_proj[b]) for all NS source views in ONE launch (the caller-side
+ * lines jdacs/models/module.py:116-118, jdacs-ms/models/modules.py:71-80 run once per view).  src_proj [B,NS,4,4], ref_proj
+ * [B,4,4], row-major fp32; fp64 inside.  A singular ref_proj yields inf / nan (like torch.linalg.inv_ex), not an error. */
+int mvs_relative_projection(const float* src_proj, const float* ref_proj, int B, int NS, float* rot, float* trans,
+                            hipStream_t stream);
 /* Backward of the above w.r.t. the feature maps (the reference builds the sampling grid under
  * no_grad, module.py:115).  grad_ref and grad_srcs[i] ([B,H,W,C]) must be ZERO-FILLED by the caller
  * (accumulated with atomics). */

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mvs_cast_f32_bf16": (_i, [_f, _f, _ll, _s]),
     "mvs_plane_sweep_variance_bwd": (_i, [_f, _f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                           _f, C.POINTER(C.c_void_p), _s]),
+    "mvs_relative_projection": (_i, [_f, _f, _i, _i, _f, _f, _s]),
     "mvs_homo_warp_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_homo_warp_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_conv3d_workspace_bytes": (_ll, [_i] * 8),

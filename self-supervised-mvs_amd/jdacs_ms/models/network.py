@@ -8,7 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from .modules import (ALIGN_CORNERS, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, _ms_rot_trans, calDepthHypo,
+from .modules import (ALIGN_CORNERS, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, _ms_proj, calDepthHypo,
                       calSweepingDepthHypo, conditionIntrinsics, conv, proj_cost)
 
 
@@ -96,9 +96,9 @@ class CVPMVSNet(nn.Module):
 
         # coarse level: 48 fronto-parallel planes, fused warp + variance (alias quirk on, network.py:114-137)
         depth_hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max)
-        rts = [_ms_rot_trans(ref_in_ms[:, -1], src_in_ms[:, i, -1], ref_ex, src_ex[:, i]) for i in range(a.nsrc)]
-        rot = torch.stack([r for r, _ in rts], 1)
-        trans = torch.stack([t for _, t in rts], 1)
+        with torch.no_grad():   # modules.py:71-80 for all source views: one launch
+            rot, trans = ops.relative_projections([_ms_proj(src_in_ms[:, i, -1], src_ex[:, i]) for i in range(a.nsrc)],
+                                                  _ms_proj(ref_in_ms[:, -1], ref_ex))
         cost_volume = ops.plane_sweep_variance(ref_fp[-1], [fp[-1] for fp in src_fps], rot, trans, depth_hypos,
                                                align_corners=self.align_corners, ms_alias=True)
         cost_reg = self.cost_reg_refine(cost_volume)

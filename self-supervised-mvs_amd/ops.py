@@ -80,6 +80,23 @@ def relative_projection(src_proj: torch.Tensor, ref_proj: torch.Tensor):
     return proj[:, :3, :3], proj[:, :3, 3]
 
 
+def relative_projections(src_projs, ref_proj: torch.Tensor):
+    """rot [B,NS,3,3] / trans [B,NS,3] of src_projs[s] @ inverse(ref_proj) for ALL source views in one launch
+    (``mvs_relative_projection``: fp64 Gauss-Jordan + product per (sample, view)) instead of one LU inverse + matmul + slices
+    per view (jdacs/models/module.py:116-118 runs once per source view: ~10 tiny launches, 91 us of the training step)."""
+    lib = _lib_for(ref_proj)
+    ns = len(src_projs)
+    b = ref_proj.shape[0]
+    src = torch.stack([p.to(torch.float32) for p in src_projs], 1).contiguous()
+    ref = ref_proj.to(torch.float32).contiguous()
+    if src.shape != (b, ns, 4, 4) or ref.shape != (b, 4, 4):
+        raise ValueError("relative_projections: need NS x [B,4,4] and [B,4,4], got %s and %s" % (tuple(src.shape), tuple(ref.shape)))
+    rot = torch.empty((b, ns, 3, 3), dtype=torch.float32, device=ref.device)
+    trans = torch.empty((b, ns, 3), dtype=torch.float32, device=ref.device)
+    lib.call("mvs_relative_projection", _p(src), _p(ref), b, ns, _p(rot), _p(trans), _stream(ref))
+    return rot, trans
+
+
 def _depth_arg(depth: torch.Tensor, b: int, h: int, w: int):
     if depth.dim() == 2:
         return depth.contiguous(), 0

@@ -78,6 +78,7 @@ def test_error_convention_of_every_entry_point():
         ("mvs_unsup_loss_fwd", (None, None, None, None, None, 1, 4, 8, 8, 1.0, None, None, None)),
         ("mvs_unsup_loss_bwd", (None, None, None, None, None, 1, 4, 8, 8, 1.0, None, None, None, None)),
         ("mvs_depth_hypo", (None, None, 1, 8, 8, None, None, None)),
+        ("mvs_relative_projection", (None, None, 1, 2, None, None, None)),
     ]
     for name, args in null_calls:
         with pytest.raises(ValueError):

@@ -419,6 +419,35 @@ def test_conv3d_smallest_volumes(emul_lib, cin, cout, stride, transposed, dims):
     assert float((gw - w.grad).abs().max()) < 3e-4 * max(1.0, float(w.grad.abs().max()))
 
 
+def test_relative_projections_one_launch(emul_lib):
+    """mvs_relative_projection (all source views, fp64 Gauss-Jordan + product) vs the reference's lines
+    torch.matmul(src_proj, torch.inverse(ref_proj)) per view (jdacs/models/module.py:116-118), on DTU-like cameras
+    (fp64 truth: the kernel must be at least as accurate as the fp32 torch path) and on a matrix that needs pivoting."""
+    from mvs_amd import ops
+    K, E = R.synthetic_cameras(5, 128, 160, 640)
+    P = E.clone()
+    P[:, :3, :4] = K @ E[:, :3, :4]
+    ref = torch.stack([P[0], P[2]], 0)                      # B = 2
+    srcs = [torch.stack([P[1], P[3]], 0), torch.stack([P[4], P[1]], 0), torch.stack([P[3], P[0]], 0)]
+    rot, trans = ops.relative_projections(srcs, ref)
+    assert rot.shape == (2, 3, 3, 3) and trans.shape == (2, 3, 3)
+    for s, sp in enumerate(srcs):
+        t64 = sp.double() @ torch.linalg.inv(ref.double())
+        e32 = torch.matmul(sp, torch.inverse(ref))
+        for got, exp, tru in ((rot[:, s], e32[:, :3, :3], t64[:, :3, :3]), (trans[:, s], e32[:, :3, 3], t64[:, :3, 3])):
+            scale = float(tru.abs().max())
+            assert float((got.double() - tru).abs().max()) <= max(float((exp.double() - tru).abs().max()), 2e-7 * scale)
+            assert float((got - exp).abs().max()) < 1e-5 * scale
+    # zero on the diagonal: needs the row exchange
+    refp = torch.tensor([[[0.0, 2.0, 0.0, 1.0], [1.0, 0.0, 0.0, 2.0], [0.0, 0.0, 0.0, 3.0], [0.0, 0.0, 4.0, 1.0]]])
+    srcp = [torch.eye(4).unsqueeze(0)]
+    rot, trans = ops.relative_projections(srcp, refp)
+    inv = torch.linalg.inv(refp.double())[0]
+    assert float((rot[0, 0].double() - inv[:3, :3]).abs().max()) < 1e-6 and float((trans[0, 0].double() - inv[:3, 3]).abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        ops.relative_projections([torch.eye(3).unsqueeze(0)], torch.eye(4).unsqueeze(0))
+
+
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_plane_sweep_fwd_variants_agree(emul_lib, variant):

@@ -275,6 +275,26 @@ def test_conv3d_smallest_volumes(dev, cin, cout, stride, transposed, dims):
     assert float((gw.cpu() - w.grad).abs().max()) < 3e-4 * max(1.0, float(w.grad.abs().max()))
 
 
+def test_relative_projections_one_launch(dev):
+    """mvs_relative_projection (all source views in one launch) vs torch.matmul(src_proj, torch.inverse(ref_proj)) per view
+    (jdacs/models/module.py:116-118): at least as close to the fp64 result as the fp32 torch path."""
+    from mvs_amd import ops
+    K, E = R.synthetic_cameras(5, 128, 160, 640)
+    P = E.clone()
+    P[:, :3, :4] = K @ E[:, :3, :4]
+    ref = torch.stack([P[0], P[2]], 0)
+    srcs = [torch.stack([P[1], P[3]], 0), torch.stack([P[4], P[1]], 0), torch.stack([P[3], P[0]], 0)]
+    rot, trans = ops.relative_projections([s.to(dev) for s in srcs], ref.to(dev))
+    rot, trans = rot.cpu(), trans.cpu()
+    for s, sp in enumerate(srcs):
+        t64 = sp.double() @ torch.linalg.inv(ref.double())
+        e32 = torch.matmul(sp, torch.inverse(ref))
+        for got, exp, tru in ((rot[:, s], e32[:, :3, :3], t64[:, :3, :3]), (trans[:, s], e32[:, :3, 3], t64[:, :3, 3])):
+            scale = float(tru.abs().max())
+            assert float((got.double() - tru).abs().max()) <= max(float((exp.double() - tru).abs().max()), 2e-7 * scale)
+            assert float((got - exp).abs().max()) < 1e-5 * scale
+
+
 
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops

@@ -153,6 +153,37 @@ def test_flat_bucket_keeps_channels_last_params_trainable():
     with pytest.raises(RuntimeError, match="no longer aliases"):
         bucket.gather()
 
+def test_sliced_optimizer_params_equal_the_single_flat_tensor():
+    """FlatGradBucket.optimizer_params(): Adam over the flat store as N slices gives bit-identical parameters to Adam over the one
+    flat tensor (element-wise update), for several steps, and the slices alias the store / the bucket."""
+    import mvs_amd  # noqa: F401
+    from mvs_amd import dist as mdist
+
+    def run(sliced):
+        torch.manual_seed(3)
+        model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                                    torch.nn.Conv2d(8, 5, 3, padding=1))
+        bucket = mdist.FlatGradBucket(model.parameters(), flatten_params=True)
+        params = bucket.optimizer_params(7) if sliced else [bucket.flat_param]
+        if sliced:
+            assert sum(p.numel() for p in params) == bucket.flat_param.numel() and len(params) >= 6
+            assert params[1].data_ptr() == bucket.flat_param.data_ptr() + 4 * params[0].numel()
+            assert params[1].grad.data_ptr() == bucket.flat.data_ptr() + 4 * params[0].numel()
+        opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.999))
+        g = torch.Generator().manual_seed(4)
+        for _ in range(3):
+            x = torch.randn(2, 3, 6, 6, generator=g)
+            bucket.zero()
+            model(x).square().mean().backward()
+            bucket.gather()
+            opt.step()
+        return bucket.flat_param.detach().clone()
+
+    assert torch.equal(run(False), run(True))
+    with pytest.raises(ValueError):
+        mdist.FlatGradBucket(torch.nn.Linear(2, 2).parameters()).optimizer_params()
+
+
 
 def test_mvsnet_construction_fixes_feature_layout_once():
     """The feature extractor is converted to channels-last at construction; forward() must not touch parameter storage."""
