@@ -109,6 +109,7 @@ class MVSNet(nn.Module):
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):
+        imgs_in = imgs
         imgs = torch.unbind(imgs, 1)
         proj_matrices = torch.unbind(proj_matrices, 1)
         assert len(imgs) == len(proj_matrices), "Different number of images and projection matrices"
@@ -117,7 +118,8 @@ class MVSNet(nn.Module):
         if self.channels_last_features:
             # all views through the shared-weight extractor as ONE batch (3x fewer launches, no per-view
             # gradient accumulation); BatchNorm keeps the reference's per-view statistics (grouped BN kernels)
-            stacked = torch.cat(imgs, 0).contiguous(memory_format=torch.channels_last)
+            # (view-major [N*B,3,H,W]: for one sample per GPU a plain view of the input, so the only copy is the layout change)
+            stacked = imgs_in.transpose(0, 1).reshape(-1, *imgs_in.shape[2:]).contiguous(memory_format=torch.channels_last)
             features = list(self.feature(stacked, groups=len(imgs)).chunk(len(imgs), 0))
         else:
             features = [self.feature(img) for img in imgs]

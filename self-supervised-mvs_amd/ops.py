@@ -140,8 +140,10 @@ class PlaneSweepVariance(torch.autograd.Function):
         n = len(srcs_c) + 1
         nd = depth_c.shape[1]
         g = as_cl3(gvar)
-        gref = torch.zeros_like(ref_c, memory_format=CL2)
-        gsrcs = [torch.zeros_like(s, memory_format=CL2) for s in srcs_c]
+        # ONE zero-filled [N,B,H,W,C] buffer (one fill launch instead of N), handed out as channels-last [B,C,H,W] views
+        gall = torch.zeros((n, b, h, w, c), dtype=torch.float32, device=ref_c.device)
+        gref = gall[0].permute(0, 3, 1, 2)
+        gsrcs = [gall[i + 1].permute(0, 3, 1, 2) for i in range(n - 1)]
         lib.call("mvs_plane_sweep_variance_bwd", _p(g), _p(ref_c), _ptr_array(srcs_c), _p(rot_c), _p(trans_c),
                  _p(depth_c), per_pixel, b, n, c, nd, h, w, align_corners, ms_alias, _p(gref), _ptr_array(gsrcs),
                  _stream(ref_c), tag="sweep_bwd:N%d:C%d:%dx%dx%dx%d" % (n, c, b, nd, h, w))
@@ -537,7 +539,11 @@ class ConvBias3dFn(torch.autograd.Function):
         gy = as_cl3(gy)
         gx = conv3d_dgrad(gy, weight, tuple(x.shape), 1, False) if ctx.needs_input_grad[0] else None
         gw = _wgrad_maybe_async(x, gy, weight, 1, False) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        gb = None
+        if ctx.needs_input_grad[2]:
+            # Cout = 1 (the prob layer): a full reduction; ATen's reduce over dims (0, 2, 3, 4) of a [B,1,D,H,W] tensor takes 53 us
+            # for 15.7 MB at config 2 (torch profile, run 16)
+            gb = gy.sum().reshape(1) if gy.shape[1] == 1 else gy.sum(dim=(0, 2, 3, 4))
         return gx, gw, gb
 
 
