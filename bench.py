@@ -76,8 +76,8 @@ def algorithmic_work(cfg):
 
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
     "sweep_fwd": "plane_sweep_variance_fwd_cached_kernel", "sweep_bwd": "plane_sweep_variance_bwd_pw_kernel",
-    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2>",
-    "sweep_fwd_bf16": "plane_sweep_variance_fwd_cached_kernel<32, 6, 4, false, true>", "conv0_fwd_bf16": "conv_bf16_kernel<0, 32, 8>",
+    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2,",
+    "sweep_fwd_bf16": "plane_sweep_variance_fwd_cached_kernel<32, 6, 4, false, true", "conv0_fwd_bf16": "conv_bf16_kernel<0, 32, 8>",
 }
 
 
