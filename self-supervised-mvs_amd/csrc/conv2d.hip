@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
     constexpr int NR = G::RH * G::RW, NPOS = G::TH * G::TW, ROWS = G::NT * CXP, CGP = NB * 16;
     constexpr int XP = CXP + 1;                       // odd pixel stride: the A gather walks (tap, cx) rows
     __shared__ float xt[NR * XP];
-    __shared__ float gt[NPOS * CGP];
+    __shared__ __attribute__((aligned(16))) float gt[NPOS * CGP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l15 = lane & 15;
     // m-tile m of this wave covers rows 16 (wave + 4 m) .. +15; row -> (tap = row / CXP, cx = row % CXP)
     int rowoff[MT];
@@ -284,9 +284,20 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(Wgrad2dArgs a) {
                 }
             }
         }
-        for (int i = tid; i < NPOS * CGP; i += 256) {
-            const int p = i / CGP, co = i % CGP, oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
-            gt[i] = (co < a.CG && oy < a.Ho && ox < a.Wo) ? a.g[(((size_t)n * a.Ho + oy) * a.Wo + ox) * a.gs + a.g0 + co] : 0.f;
+        if ((a.CG & 3) == 0 && (a.gs & 3) == 0 && (a.g0 & 3) == 0) {
+            // 16-byte loads of the output-gradient tile (channel quads beyond CG and positions outside the image are zero)
+            for (int i = tid; i < NPOS * (CGP / 4); i += 256) {
+                const int p = i / (CGP / 4), co = 4 * (i % (CGP / 4)), oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co < a.CG && oy < a.Ho && ox < a.Wo)
+                    v = *reinterpret_cast<const float4*>(a.g + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.gs + a.g0 + co);
+                *reinterpret_cast<float4*>(&gt[p * CGP + co]) = v;
+            }
+        } else {
+            for (int i = tid; i < NPOS * CGP; i += 256) {
+                const int p = i / CGP, co = i % CGP, oy = oy0 + p / G::TW, ox = ox0 + p % G::TW;
+                gt[i] = (co < a.CG && oy < a.Ho && ox < a.Wo) ? a.g[(((size_t)n * a.Ho + oy) * a.Wo + ox) * a.gs + a.g0 + co] : 0.f;
+            }
         }
         __syncthreads();
         for (int ks = 0; ks < NPOS / 4; ++ks) {
@@ -337,8 +348,9 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static const int C2_WGRAD_GROUPS = 256;   // partial images the workspace holds
-int g_conv2d_wgrad_groups = 256;          // tuning knob "wgrad2d_groups" (<= 256): persistent workgroups of the weight gradient
+static const int C2_WGRAD_GROUPS = 1024;  // partial images the workspace holds
+int g_conv2d_wgrad_groups = 256;          // tuning knob "wgrad2d_groups" (<= 1024): persistent workgroups of the weight gradient (256 = one per CU;
+                                          // more let a CU overlap one workgroup's tile staging with another's MFMA loop -- not yet measured)
 int g_conv2d_s2_mfma = 1;   // tuning knob "conv2d_s2_mfma": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
