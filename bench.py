@@ -47,7 +47,18 @@ def algorithmic_work(cfg):
     """Per-launch algorithmic bytes / flops of the tagged kernels (stated in DESIGN.md) and their call tags."""
     c = CONFIGS[cfg]
     if c["kind"] == "cvp_infer":
-        return {}, {}
+        # CVP-MVSNet finest level (D = 8 per-pixel hypotheses at the full 864x1152, 16 feature channels): the refine sweep (HBM:
+        # features in, per-pixel hypotheses in, variance out) and the two layers that dominate the step (MFMA)
+        n, (ih, iw) = c["views"], c["image"]
+        d = c["planes"][-1]
+        vox = d * ih * iw
+        work = {"sweep_fwd": ("hbm", n * 16 * ih * iw * 4 + 16 * vox * 4 + vox * 4),
+                "conv_64_64": ("mfma", 2 * 27 * 64 * 64 * (d // 2) * (ih // 2) * (iw // 2)),
+                "conv_16_16": ("mfma", 2 * 27 * 16 * 16 * vox)}
+        tags = {"sweep_fwd": ("mvs_plane_sweep_variance_fwd", "sweep_fwd:N%d:C16:1x%dx%dx%d" % (n, d, ih, iw)),
+                "conv_64_64": ("mvs_conv3d_fwd", "fwd:64>64:s1:1x%dx%dx%d" % (d // 2, ih // 2, iw // 2)),
+                "conv_16_16": ("mvs_conv3d_fwd", "fwd:16>16:s1:1x%dx%dx%d" % (d, ih, iw))}
+        return work, tags
     n, (ih, iw), nd = c["views"], c["image"], c["planes"]
     hf, wf = ih // 4, iw // 4
     vox = nd * hf * wf
@@ -75,15 +86,22 @@ def algorithmic_work(cfg):
 
 
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
-    "sweep_fwd": "plane_sweep_variance_fwd_cached_kernel", "sweep_bwd": "plane_sweep_variance_bwd_pw_kernel",
+    "sweep_fwd": "plane_sweep_variance_fwd", "sweep_bwd": "plane_sweep_variance_bwd",
     "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2,",
-    "sweep_fwd_bf16": "plane_sweep_variance_fwd_cached_kernel<32, 6, 4, false, true", "conv0_fwd_bf16": "conv_bf16_kernel<0, 32, 8>",
+    "sweep_fwd_bf16": "plane_sweep_variance_fwd", "conv0_fwd_bf16": "conv_bf16_kernel<0, 32, 8>",
+    "conv_64_64": "conv_igemm_kernel<0, 16, 4", "conv_16_16": "conv_igemm_kernel<0, 16, 1",
 }
+# the tags tools/pmc_driver.py replays per --config (one kernel name per tag within a config: the substrings above are matched
+# against that config's driver run only)
+PMC_TAGS = {2: ("sweep_fwd", "sweep_bwd", "conv0_fwd", "conv0_wgrad", "conv0_dgrad"),
+            3: ("sweep_fwd", "sweep_bwd", "conv0_fwd", "conv0_wgrad", "conv0_dgrad"),
+            4: ("sweep_fwd", "conv_64_64", "conv_16_16"),
+            5: ("sweep_fwd_bf16", "conv0_fwd_bf16", "sweep_fwd", "conv0_fwd")}
 
 
-def pmc_traffic():
+def pmc_traffic(cfg, dtype="f32"):
     """HBM traffic per launch of the roofline kernels: rocprofv3 PMC counters of tools/pmc_driver.py (the same kernels at
-    the same config-2 shapes), FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes.  On gfx950
+    the same shapes as --config), FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes.  On gfx950
     FETCH_SIZE tallies every 128-byte line at 64 bytes (calibrated: tools/fetch_calib.hip, profiles/r01_run20_fetch_calib.log)
     -> doubled; WRITE_SIZE matched known byte counts as reported.  Both are in KiB."""
     import shutil
@@ -95,13 +113,13 @@ def pmc_traffic():
     sys.path.insert(0, os.path.join(root, "tools"))
     from pmc_summary import summarise
     tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MVS_PMC_CONFIG=str(cfg), MVS_PMC_DTYPE=dtype)
     dirs = []
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(tmp, counter)
         r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                             sys.executable, os.path.join(root, "tools", "pmc_driver.py")],
-                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             shutil.rmtree(tmp, ignore_errors=True)
             return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
@@ -109,11 +127,16 @@ def pmc_traffic():
     summ = summarise(dirs)
     shutil.rmtree(tmp, ignore_errors=True)
     out = {}
-    for tag, sub in HIP_KERNEL_OF.items():
+    for tag in PMC_TAGS.get(cfg, ()):
+        if (dtype == "f32") == tag.endswith("_bf16") and cfg == 5:   # config 5 replays one storage dtype per run
+            continue
+        sub = HIP_KERNEL_OF[tag]
         for name, c in summ.items():
             if sub in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                out[tag] = {"fetch_bytes": 2.0 * 1024.0 * c["FETCH_SIZE"]["mean"], "write_bytes": 1024.0 * c["WRITE_SIZE"]["mean"]}
-    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py; FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)"
+                out[tag] = {"fetch_bytes": 2.0 * 1024.0 * c["FETCH_SIZE"]["mean"], "write_bytes": 1024.0 * c["WRITE_SIZE"]["mean"],
+                            "hip_kernel": name}
+    return out, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py at the --config %d shapes; "
+                 "FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)" % cfg)
 
 
 def host_cpu():
@@ -150,6 +173,9 @@ def cpu_baseline(net_state, seed):
     model, phys, logical = host_cpu()
     old_threads = torch.get_num_threads()
     torch.set_num_threads(phys)
+    # the warp is timed as the reference's own F.grid_sample call (jdacs/models/module.py:136), not the oracle's hand-written
+    # gather (1.96x slower on the CPU: VERDICT r2 #11); tests/test_oracle_golden.py asserts the two forms agree
+    old_sampler = R.set_sampler("aten")
     try:
         oracle = R.OracleMVSNet(refine=False)
         oracle.load_state_dict(net_state)
@@ -180,10 +206,12 @@ def cpu_baseline(net_state, seed):
         c1 = sorted(t1)[2]
     finally:
         torch.set_num_threads(old_threads)
+        R.set_sampler(old_sampler)
     return {"value": 1.0 / dt, "unit": "depth-samples/s", "cores": phys, "kind": "port", "cpu_model": model, "logical_cpus": logical,
             "seconds_per_sample": dt, "timed_runs_s": [round(t, 3) for t in ts],
             "sample": "1 warm-up + 3 timed samples (median) of the same workload (MVSNet N=3 640x512 D=192 fp32 fwd+loss+bwd), "
-                      "oracle/ref_torch.py on %d CPU threads = physical cores" % phys,
+                      "oracle/ref_torch.py with sampler='aten' (F.grid_sample called as the reference calls it, ATen/oneDNN conv3d, batch_norm, "
+                      "softmax) on %d CPU threads = physical cores" % phys,
             "config1": {"value": 1.0 / c1, "unit": "depth-samples/s", "seconds_per_sample": c1,
                         "what": "BASELINE configs[0]: MVSNet eval forward N=3 160x128 D=48 on the same CPU, median of 5 after 1 warm-up"}}
 
@@ -215,7 +243,7 @@ def main():
                     help="storage dtype of the cost volume / regulariser activations for --config 5 (default bf16 there; f32 elsewhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-reference", type=int, default=-1,
-                    help="time the same step with the oracle's stock torch ops on this GPU (ATen grid_sample, MIOpen conv3d) = "
+                    help="time the same step with the oracle's stock torch ops on this GPU (sampler='aten': F.grid_sample, MIOpen conv3d) = "
                          "'the reference GPU path' -> reference_gpu_path.  Default: on for the default N=1 config-2 run, off otherwise")
     ap.add_argument("--feature-channels-last", type=int, default=1,
                     help="1: run the stock-PyTorch FeatureNet in channels-last (MIOpen NHWC kernels)")
@@ -369,7 +397,8 @@ def main():
     # weight gradients on a side HIP stream: safe here -- gradients are read (bucket.gather) only after backward() has
     # returned, no DDP / DataParallel hooks; the library default is off (ops.py)
     from mvs_amd import ops as _ops
-    _ops.set_async_wgrad(os.environ.get("MVS_ASYNC_WGRAD", "1") != "0")
+    async_wgrad = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
+    _ops.set_async_wgrad(async_wgrad)
     eager_step = step
     graph_mode = False
     if args.graph != 0:
@@ -447,6 +476,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     lossv = float(loss)
+    # the same K steps with the OTHER weight-gradient mode (the library default is synchronous: what the drop-in runs under the
+    # reference's own train.py with DataParallel hooks), reported beside the headline -- never the headline itself
+    ms_other_mode = None
+    if train and not graph_mode:
+        _ops.set_async_wgrad(not async_wgrad)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_other_mode = float(tm.item()) / args.steps * 1e3
+        _ops.set_async_wgrad(async_wgrad)
 
     if rank == 0:
         summ = timer.summary()
@@ -462,17 +508,24 @@ def main():
                 kernels[key] = {"bound": bound, "ms": ms, "achieved": ach, "peak": peak, "unit": unit,
                                 "frac": ach / peak, "calls": calls}
         traffic, traffic_note = None, "not collected"
-        if args.pmc and world == 1 and args.config == 2:    # tools/pmc_driver.py replays the config-2 kernels
+        if args.pmc and world == 1:    # tools/pmc_driver.py replays this config's tagged kernels at this config's shapes
             try:
-                traffic, traffic_note = pmc_traffic()
+                traffic, traffic_note = pmc_traffic(args.config, dtype)
             except Exception as e:  # the bench line must still come out
                 traffic, traffic_note = None, "PMC pass failed: %r" % (e,)
         for k, t in (traffic or {}).items():
             if k in kernels:
                 kernels[k]["traffic"] = t["fetch_bytes"] + t["write_bytes"]
-                hf, wf = IMG_H // 4, IMG_W // 4
-                # bytes each launch has to move at least once (conv0: the 32-channel volume + the 8-channel one)
-                kernels[k]["algorithmic_bytes"] = work[k][1] if work[k][0] == "hbm" else (FEAT_C + 8) * NDEPTH * hf * wf * 4
+                kernels[k]["traffic_fetch"], kernels[k]["traffic_write"] = t["fetch_bytes"], t["write_bytes"]
+                kernels[k]["hip_kernel"] = t.get("hip_kernel")
+                # bytes each launch has to move at least once (conv: input volume + output volume, fp32)
+                if work[k][0] == "hbm":
+                    kernels[k]["algorithmic_bytes"] = work[k][1]
+                elif k.startswith("conv0"):
+                    kernels[k]["algorithmic_bytes"] = (FEAT_C + 8) * ndepth * (img_h // 4) * (img_w // 4) * 4
+                elif k in ("conv_64_64", "conv_16_16"):
+                    cch = 64 if k == "conv_64_64" else 16
+                    kernels[k]["algorithmic_bytes"] = int(work[k][1] // (27 * cch)) * 4   # = 2 * cch * voxels * 4
         # the roofline object describes the dominant (longest-running) kernel of the step; the other tagged kernels are in "kernels"
         dom = max(kernels, key=lambda k: kernels[k]["ms"], default=None)
         roof = None
@@ -496,6 +549,8 @@ def main():
             "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if (world > 1 and train) else "none",
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
+            "async_wgrad": bool(async_wgrad) if train else None,
+            ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }
         if not args.no_cpu_baseline and world == 1 and args.config == 2:   # rank 0 at N=1 only (bench contract)
@@ -507,6 +562,7 @@ def main():
         if want_ref and args.config == 2:
             try:
                 from oracle import ref_torch as R
+                old_sampler = R.set_sampler("aten")   # F.grid_sample as the reference calls it (module.py:136)
                 oracle = R.OracleMVSNet(refine=False)
                 oracle.load_state_dict(state0)
                 oracle = oracle.to(dev).train()
@@ -526,12 +582,15 @@ def main():
                 torch.cuda.synchronize()
                 odt = (time.perf_counter() - t1) / 5
                 res["reference_gpu_path"] = {"value": 1.0 / odt, "unit": "depth-samples/s", "ms_per_step": odt * 1e3,
-                                             "what": "oracle/ref_torch.py (stock PyTorch-ROCm ops) on the same MI355X, "
-                                                     "same step", "speedup": (world * args.steps / dt) * odt}
+                                             "what": "oracle/ref_torch.py with sampler='aten' (stock PyTorch-ROCm ops: ATen grid_sample, "
+                                                     "MIOpen conv3d / batch_norm, cudnn.benchmark on) on the same MI355X, same step",
+                                             "speedup": (world * args.steps / dt) * odt}
                 del oracle, oopt
                 torch.cuda.empty_cache()
             except Exception as e:
                 res["reference_gpu_path"] = {"value": None, "error": repr(e)}
+            finally:
+                R.set_sampler("gather")
         if args.torch_profile:
             from torch.profiler import ProfilerActivity, profile
             with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

@@ -95,13 +95,43 @@ def bilinear_gather_zeros(fea: torch.Tensor, ix: torch.Tensor, iy: torch.Tensor)
     return out
 
 
-def warp_features(src_fea, rot, trans, depth, align_corners: bool = False) -> torch.Tensor:
+# Which bilinear sampler warp_features() uses.  "gather": the hand-written 4-tap gather above (the sampling convention spelled
+# out; what the parity tests compare against).  "aten": F.grid_sample called exactly as the reference does
+# (jdacs/models/module.py:131-136) -- the form bench.py TIMES as the CPU baseline / reference GPU path, so the baseline is the
+# reference's own op and not a slower restatement (tests/test_oracle_golden.py asserts the two agree to 1e-6).
+SAMPLER = "gather"
+
+
+def set_sampler(name: str) -> str:
+    """Select the sampler ("gather" | "aten"); returns the previous one."""
+    global SAMPLER
+    if name not in ("gather", "aten"):
+        raise ValueError("sampler must be 'gather' or 'aten', got %r" % (name,))
+    old, SAMPLER = SAMPLER, name
+    return old
+
+
+def grid_sample_aten(fea: torch.Tensor, px: torch.Tensor, py: torch.Tensor, nd: int, align_corners: bool) -> torch.Tensor:
+    """The reference's own sampler call (module.py:131-136): normalise with the (size-1)/2 formula, stack to
+    [B, D, H*W, 2], F.grid_sample(bilinear, zeros) on the [B, D*H, W, 2] view.  px, py [B,D,H*W] -> [B,C,D*H*W]."""
+    b, c, h, w = fea.shape
+    gx = px / ((w - 1) / 2) - 1
+    gy = py / ((h - 1) / 2) - 1
+    grid = torch.stack((gx, gy), dim=3)
+    out = F.grid_sample(fea, grid.view(b, nd * h, w, 2), mode="bilinear", padding_mode="zeros", align_corners=align_corners)
+    return out.view(b, c, nd * h * w)
+
+
+def warp_features(src_fea, rot, trans, depth, align_corners: bool = False, sampler: Optional[str] = None) -> torch.Tensor:
     """[B,C,H,W] -> [B,C,D,H,W]; gradient flows to src_fea only (grid is built under no_grad,
-    module.py:115)."""
+    module.py:115).  sampler: None = the module-level SAMPLER."""
     b, c, h, w = src_fea.shape
     nd = depth.shape[1]
     with torch.no_grad():
         px, py = warp_pixel_coords(rot, trans, depth, h, w)
+    if (sampler or SAMPLER) == "aten":
+        return grid_sample_aten(src_fea, px, py, nd, align_corners).view(b, c, nd, h, w)
+    with torch.no_grad():
         ix = to_sample_index(px, w, align_corners).reshape(b, -1)
         iy = to_sample_index(py, h, align_corners).reshape(b, -1)
     return bilinear_gather_zeros(src_fea, ix, iy).view(b, c, nd, h, w)

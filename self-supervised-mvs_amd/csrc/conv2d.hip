@@ -361,7 +361,10 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
     const int nt = ks * ks;
     if (op == 2) {   // one <= 32 x <= 32 channel slice at a time
         const int cxs = Cin > 32 ? 32 : (Cin + 3) / 4 * 4, cgs = Cout > 32 ? 32 : (Cout + 15) / 16 * 16;
-        return (long long)C2_WGRAD_GROUPS * nt * cxs * cgs;
+        // one partial image per persistent workgroup the launch will actually use (knob "wgrad2d_groups", evaluated now: the
+        // caller queries the size right before the call), not the 1024-image ceiling (37.7 MB instead of 9.4 MB per 32x32 layer)
+        const int gq = g_conv2d_wgrad_groups < 1 ? 1 : (g_conv2d_wgrad_groups > C2_WGRAD_GROUPS ? C2_WGRAD_GROUPS : g_conv2d_wgrad_groups);
+        return (long long)gq * nt * cxs * cgs;
     }
     const int ci = op == 1 ? Cout : Cin, co = op == 1 ? Cin : Cout;   // an input gradient is a forward-style pass on gy
     if (op == 1 && stride == 2) {                                      // four parity-class 3x3 weight images

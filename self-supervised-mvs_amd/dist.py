@@ -79,10 +79,12 @@ class FlatGradBucket:
         step = max(4, -(-n // max(1, slices)))
         step += (-step) % 4
         out = []
+        self._opt_slices = []
         for i in range(0, n, step):
             p = torch.nn.Parameter(self.flat_param.data[i:i + step])
             p.grad = self.flat[i:i + step]
             out.append(p)
+            self._opt_slices.append((p, i, i + step))
         return out
 
     @staticmethod
@@ -139,6 +141,11 @@ class FlatGradBucket:
                 g = self._storage_order(g) if self.flat_param is not None else g.reshape(-1)
             grads.append(g)
         torch.cat(grads, out=self.flat)
+        # an optimizer.zero_grad() (set_to_none=True is torch's default) drops the slices' .grad views of the bucket and the
+        # next opt.step() would then skip every slice without an error: re-attach them (no launch, views only)
+        for p, lo, hi in getattr(self, "_opt_slices", ()):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * lo:
+                p.grad = self.flat[lo:hi]
 
     def all_reduce(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -84,11 +84,17 @@ def relative_projections(src_projs, ref_proj: torch.Tensor):
     """rot [B,NS,3,3] / trans [B,NS,3] of src_projs[s] @ inverse(ref_proj) for ALL source views in one launch
     (``mvs_relative_projection``: fp64 Gauss-Jordan + product per (sample, view)) instead of one LU inverse + matmul + slices
     per view (jdacs/models/module.py:116-118 runs once per source view: ~10 tiny launches, 91 us of the training step)."""
-    lib = _lib_for(ref_proj)
     ns = len(src_projs)
     b = ref_proj.shape[0]
+    # the kernel computes in fp64 from fp32 inputs; float64 / half matrices are cast first (the reference's lines are dtype
+    # agnostic), and matrices that do not live on the library's device (CPU-resident cameras next to GPU features) take the
+    # reference's own host lines instead of raising
+    if ref_proj.device.type != _lib.get().device_type:
+        rts = [relative_projection(p, ref_proj) for p in src_projs]
+        return torch.stack([r for r, _ in rts], 1).float(), torch.stack([t for _, t in rts], 1).float()
     src = torch.stack([p.to(torch.float32) for p in src_projs], 1).contiguous()
     ref = ref_proj.to(torch.float32).contiguous()
+    lib = _lib_for(ref)
     if src.shape != (b, ns, 4, 4) or ref.shape != (b, 4, 4):
         raise ValueError("relative_projections: need NS x [B,4,4] and [B,4,4], got %s and %s" % (tuple(src.shape), tuple(ref.shape)))
     rot = torch.empty((b, ns, 3, 3), dtype=torch.float32, device=ref.device)
@@ -346,7 +352,8 @@ _ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "0") == "1"
 # final callback on the thread that called backward(), so thread-local state would not connect them; one-thread-per-GPU
 # callers (nn.DataParallel style) touch disjoint entries.
 _SIDE_STREAMS = {}      # device index -> side stream (created once)
-_WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses since the last completed backward pass}
+_WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses whose backward node has not run yet}
+_WEIGHT_MULTI = {}      # device index -> {weight data_ptr} that had > 1 outstanding use at some point (until all of them have run)
 _BWD_OPEN = {}          # device index -> [main stream, side stream used?] while a backward pass with our nodes is running
 
 
@@ -363,14 +370,29 @@ def _note_weight_use(weight: torch.Tensor) -> None:
             # (an exception in a later node).  Close it here so that state never leaks into the next step.
             _end_of_backward(idx)
         uses = _WEIGHT_USES.setdefault(idx, {})
-        uses[weight.data_ptr()] = uses.get(weight.data_ptr(), 0) + 1
+        n = uses[weight.data_ptr()] = uses.get(weight.data_ptr(), 0) + 1
+        if n > 1:
+            _WEIGHT_MULTI.setdefault(idx, set()).add(weight.data_ptr())
+
+
+def _weight_use_done(idx: int, ptr: int) -> None:
+    """One backward node of this weight has taken its decision.  The counts are kept per OUTSTANDING use, not reset per backward
+    pass: with two graphs built before either backward (forward A, forward B, A.backward(), B.backward()) a reset at the end of A's
+    pass made graph B's shared weights (CVP's regulariser) look single-use.  A weight stays in the multi-use set until
+    every outstanding use has run; a forward that never gets a backward only ever makes the weight take the synchronous path."""
+    uses = _WEIGHT_USES.get(idx)
+    if uses is None or ptr not in uses:
+        return
+    uses[ptr] -= 1
+    if uses[ptr] <= 0:
+        del uses[ptr]
+        _WEIGHT_MULTI.get(idx, set()).discard(ptr)
 
 
 def _end_of_backward(idx: int) -> None:
     ent = _BWD_OPEN.pop(idx, None)
     if ent is not None and ent[1]:
         ent[0].wait_stream(_SIDE_STREAMS[idx])
-    _WEIGHT_USES.pop(idx, None)      # counts are per graph: every backward pass (async or not) resets them
 
 
 def _async_safe(weight: torch.Tensor) -> bool:
@@ -391,7 +413,8 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
         # resets the per-graph use counts) whichever path the individual layers take
         ent = _BWD_OPEN[idx] = [main, False]
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
-    ok = _async_safe(weight) and _WEIGHT_USES.get(idx, {}).get(weight.data_ptr(), 0) <= 1
+    ok = _async_safe(weight) and weight.data_ptr() not in _WEIGHT_MULTI.get(idx, ())
+    _weight_use_done(idx, weight.data_ptr())
     if ok and lib.profiler is not None:
         # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
         # not the kernel's plus whatever shares the chip with it on the other stream
@@ -438,7 +461,8 @@ class ConvBnReLU3dFn(torch.autograd.Function):
             y, _ = conv3d_forward(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
             ctx.eval_mode = True
             return y
-        _note_weight_use(weight)
+        if ctx.needs_input_grad[1]:
+            _note_weight_use(weight)
         raw, parts = conv3d_forward(x, weight, stride, transposed, want_stats=True)
         b, _, od, oh, ow = raw.shape
         count = b * od * oh * ow
@@ -528,7 +552,8 @@ class ConvBias3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = as_cl3(x)
-        _note_weight_use(weight)
+        if ctx.needs_input_grad[1]:
+            _note_weight_use(weight)
         y, _ = conv3d_forward(x, weight, 1, False, shift=bias.contiguous())
         ctx.save_for_backward(x, weight)
         return y

@@ -127,6 +127,7 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs cuda:0 (the workers run the real MVSNet on the HIP path)")
 def test_two_ranks_real_mvsnet_equals_mean_of_per_sample_gradients():
     """One rank per sample with per-replica BatchNorm statistics and ONE flat all-reduce (the data-parallel scheme of dist.py,
     here 2 ranks sharing the box's single GPU over gloo) == one process running the two samples one after the other and

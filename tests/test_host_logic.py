@@ -245,3 +245,59 @@ def test_convbnrelu_gate_for_unsupported_bn_shapes():
     blk.bn.momentum = None
     with pytest.raises(ValueError, match="momentum=None"):
         blk(torch.randn(1, 8, 4, 4, 4))
+
+
+def test_async_wgrad_use_counts_are_per_outstanding_use():
+    """Two graphs built before either backward (forward A, forward B, A.backward(), B.backward()): a weight used twice in B (CVP's
+    shared regulariser) must stay on the synchronous path in B's backward although A's backward ran in between."""
+    from types import SimpleNamespace
+    from mvs_amd import ops
+
+    class W:   # the bookkeeping only looks at these
+        is_cuda = True
+        device = SimpleNamespace(index=0)
+
+        def __init__(self, ptr):
+            self._ptr = ptr
+
+        def data_ptr(self):
+            return self._ptr
+
+    old = ops._ASYNC_WGRAD
+    ops.set_async_wgrad(True)
+    ops._WEIGHT_USES.pop(0, None)
+    ops._WEIGHT_MULTI.pop(0, None)
+    try:
+        single, shared = W(1000), W(2000)
+        ops._note_weight_use(single)                                   # graph A
+        ops._note_weight_use(shared); ops._note_weight_use(shared)     # graph B: two uses of the same weight
+        ops._weight_use_done(0, 1000)                                  # A.backward()
+        ops._end_of_backward(0)
+        assert 2000 in ops._WEIGHT_MULTI[0] and 1000 not in ops._WEIGHT_MULTI[0]
+        ops._weight_use_done(0, 2000)                                  # B.backward(): first node -- still multi-use
+        assert 2000 in ops._WEIGHT_MULTI[0]
+        ops._weight_use_done(0, 2000)
+        assert 2000 not in ops._WEIGHT_MULTI[0] and not ops._WEIGHT_USES[0]
+    finally:
+        ops.set_async_wgrad(old)
+        ops._WEIGHT_USES.pop(0, None)
+        ops._WEIGHT_MULTI.pop(0, None)
+
+
+def test_flat_bucket_reattaches_optimizer_slices_after_zero_grad():
+    """optimizer.zero_grad() (set_to_none=True by default) drops the slices' .grad views of the bucket; gather() re-attaches them,
+    otherwise the next opt.step() silently skips every slice."""
+    from mvs_amd import dist as mdist
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
+    opt = torch.optim.SGD(bucket.optimizer_params(4), lr=0.1)
+    before = bucket.flat_param.detach().clone()
+    for _ in range(2):
+        opt.zero_grad()                      # the hazard: slices lose their .grad
+        bucket.zero()
+        net(torch.randn(4, 5)).sum().backward()
+        bucket.gather()
+        opt.step()
+    assert all(p.grad is not None for p, _, _ in bucket._opt_slices)
+    assert float((bucket.flat_param.detach() - before).abs().max()) > 0

@@ -28,6 +28,39 @@ def test_g1_homo_warping():
         assert float((g["out"] == 0).float().mean()) > 0.02  # fixture exercises out-of-image samples
 
 
+def test_aten_sampler_mode_equals_gather_form():
+    """bench.py times the oracle with sampler="aten" (the reference's own F.grid_sample call, module.py:131-136) as the CPU
+    baseline / reference GPU path; that form must be the same function as the hand-written gather the parity tests use --
+    forward and gradient, on the reference-generated fixture (out-of-image samples included) and per-pixel hypotheses."""
+    for tag in "ab":
+        g = load_golden("g1_homo_warping_" + tag)
+        outs, grads = [], []
+        for sampler in ("gather", "aten"):
+            old = R.set_sampler(sampler)
+            try:
+                src = g["src_fea"].clone().requires_grad_(True)
+                out = R.homo_warping(src, g["src_proj"], g["ref_proj"], g["depth_values"])
+                out.backward(g["grad_out"])
+            finally:
+                R.set_sampler(old)
+            outs.append(out.detach())
+            grads.append(src.grad.clone())
+        # measured 1.04e-6 / 1.3e-6 of the largest value (fp32 rounding of ix = ((g+1)*W-1)/2 inside ATen vs the same expression here)
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(1.0, float(outs[0].abs().max()))
+        assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * max(1.0, float(grads[0].abs().max()))
+        assert bool((outs[1] == g["out"]).all())     # and the aten form reproduces the reference fixture bit for bit
+    assert R.SAMPLER == "gather"
+    gen = torch.Generator().manual_seed(2)
+    fea = torch.randn(2, 8, 12, 20, generator=gen)
+    rot, trans = R.relative_projection(g["src_proj"][:1].repeat(2, 1, 1), g["ref_proj"][:1].repeat(2, 1, 1))
+    depth = 450 + 30 * torch.rand(2, 1, 12, 20, generator=gen) + 20.0 * torch.arange(5).view(1, 5, 1, 1)
+    a = R.warp_features(fea, rot, trans, depth, sampler="gather")
+    b = R.warp_features(fea, rot, trans, depth, sampler="aten")
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    with pytest.raises(ValueError):
+        R.set_sampler("nearest")
+
+
 def test_g3_proj_cost_and_ms_warp():
     g = load_golden("g3_proj_cost")
     ref = g["ref_fea"].clone().requires_grad_(True)
