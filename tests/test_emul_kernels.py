@@ -72,6 +72,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
     ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
     srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
     depth = (430 + 1.5 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)                   # the round-2 per-wave-window kernel (kept behind the knob)
     emul_lib.call("mvs_set_tuning", b"bwd_gd", max(gd, 0))
     emul_lib.call("mvs_set_tuning", b"bwd_pf", 1 if gd < 0 else 0)   # gd = -1: the block-lookahead form
     emul_lib.call("mvs_set_tuning", b"bwd_dslab", d)
@@ -80,6 +81,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
         gup = torch.randn(var.shape, generator=g)
         var.backward(gup)
     finally:
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_dslab", 0)
@@ -93,7 +95,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
 
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("c,ns,step,hw", [(32, 2, 400.0, (13, 21)), (16, 3, 150.0, (10, 18))])
 def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, variant):
     """Footprints larger than an accumulation window: depth segmentation + global-atomic path (both backward kernels)."""
@@ -107,9 +109,10 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     depth = (300 + step * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
-    # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
-    emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
-    emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
+    # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views); variant 6 = the projection-table
+    # form (round 3, the default), 7 = ... with its windows switched off; variants 0-5 are the round-1/2 kernels kept behind the knob
+    emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else (2 if variant >= 6 else 0))
+    emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant in (2, 7) else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
     emul_lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else (1 if variant == 5 else 0))
     try:
@@ -117,7 +120,7 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
         gup = torch.randn(var.shape, generator=g)
         var.backward(gup)
     finally:
-        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_nowin", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
@@ -127,6 +130,57 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     exp.backward(gup)
     for a, t in zip(got, [ref] + srcs):
+        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("c,ns,cpl,wf,mode", [
+    (32, 2, 1, 2048, "plane"), (32, 2, 2, 1536, "pixel"), (32, 2, 4, 3200, "alias"), (32, 1, 1, 2048, "warp"), (32, 1, 2, 2048, "plane"),
+    (32, 4, 1, 3200, "plane"), (32, 3, 2, 3200, "pixel"), (32, 4, 4, 3200, "alias"),
+    (16, 2, 1, 3200, "alias"), (16, 3, 2, 3200, "plane"), (16, 4, 1, 3200, "pixel"), (16, 1, 2, 3200, "warp"),
+    (8, 2, 1, 3200, "plane"), (8, 1, 1, 3200, "warp"), (8, 3, 1, 3200, "alias")])
+def test_plane_sweep_backward_table_form(emul_lib, c, ns, cpl, wf, mode):
+    """The projection-table backward (plane_sweep_bwd.hip, the default): every channels-per-lane layout (2, 4 or 8 pixels of a wave
+    side by side, 4 / 2 / 1 groups one after the other), window sizes, per-plane / per-pixel hypotheses, the jdacs-ms alias quirk
+    and plain homo_warping, on a ragged image (dead lanes), a depth range long enough for several table batches (> 32 planes) and
+    block changes in every batch, against the oracle's autograd."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(100 + c + ns + cpl)
+    b, d, h, w = 2, 37, 7, 11
+    rot, trans = _cams(b, ns, h, w, g)
+    ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
+    srcs = [torch.randn(b, c, h, w, generator=g, requires_grad=True) for _ in range(ns)]
+    if mode == "pixel":
+        depth = 440 + 25 * torch.rand(b, 1, h, w, generator=g) + 9.0 * torch.arange(d).view(1, d, 1, 1)
+    else:
+        depth = (430 + 9.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
+    emul_lib.call("mvs_set_tuning", b"bwd_cpl", cpl)
+    emul_lib.call("mvs_set_tuning", b"bwd_wf", wf)
+    try:
+        if mode == "warp":
+            from mvs_amd.ops import HomoWarp
+            out = HomoWarp.apply(srcs[0], rot[:, 0], trans[:, 0], depth, False)
+            gup = torch.randn(out.shape, generator=g)
+            out.backward(gup)
+        else:
+            out = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, ms_alias=(mode == "alias"))
+            gup = torch.randn(out.shape, generator=g)
+            out.backward(gup)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"bwd_cpl", 1)
+        emul_lib.call("mvs_set_tuning", b"bwd_wf", 2048)
+    tens = [srcs[0]] if mode == "warp" else [ref] + srcs
+    got = [t.grad.clone() for t in tens]
+    for t in tens:
+        t.grad = None
+    if mode == "warp":
+        exp = R.warp_features(srcs[0], rot[:, 0], trans[:, 0], depth)
+    else:
+        exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth,
+                                     ms_alias=(mode == "alias"))
+    assert float((out - exp).abs().max()) < 2e-4
+    exp.backward(gup)
+    for a, t in zip(got, tens):
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 

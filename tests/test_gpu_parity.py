@@ -98,7 +98,7 @@ def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("c,ns,step", [(32, 2, 60.0), (32, 2, 400.0), (16, 3, 150.0), (32, 4, 90.0)])
 def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     """Backward with footprints that do not fit one accumulation window: depth segmentation and, for the widest range,
@@ -116,8 +116,9 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
     # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
-    lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
-    lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
+    # variant 6 = the projection-table form (round 3, the default), 7 = ... with its windows switched off
+    lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else (2 if variant >= 6 else 0))
+    lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant in (2, 7) else 0)
     lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
     lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else (1 if variant == 5 else 0))
     try:
@@ -126,7 +127,7 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
         var.backward(gup.to(dev))
         torch.cuda.synchronize()
     finally:
-        lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        lib.call("mvs_set_tuning", b"sweep_bwd", 2)
         lib.call("mvs_set_tuning", b"bwd_nowin", 0)
         lib.call("mvs_set_tuning", b"bwd_gd", 2)
         lib.call("mvs_set_tuning", b"bwd_pf", 0)

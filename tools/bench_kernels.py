@@ -93,17 +93,28 @@ def main():
         v5 = ops.plane_sweep_variance(f5[0], f5[1:], rot5, trans5, depth)
         gv5 = torch.randn_like(v5)
         nbytes = C * vox * 4 + 2 * (ns_ + 1) * C * H * W * 4
-        for variant, gd, pf, dslab in ((1, 2, 0, 0), (0, 0, 0, 0), (0, 2, 0, 0), (0, 2, 0, 32), (0, 2, 0, 64), (0, 2, 0, 96), (0, 2, 2, 0),
-                                       (0, 0, 0, 0), (0, 2, 0, 0)):
+        # round 3: the projection-table form (plane_sweep_bwd.hip) over its knobs, then the round-2 / round-1 kernels for reference
+        for cpl, wf, dslab in ((1, 2048, 0), (1, 1536, 0), (1, 3200, 0), (2, 2048, 0), (2, 1536, 0), (2, 3200, 0), (4, 2048, 0), (4, 3200, 0),
+                               (1, 2048, 96), (1, 2048, 192), (2, 2048, 96), (2, 2048, 192), (1, 2048, 24), (1, 2048, 0)):
+            lib.call("mvs_set_tuning", b"sweep_bwd", 2)
+            lib.call("mvs_set_tuning", b"bwd_cpl", cpl)
+            lib.call("mvs_set_tuning", b"bwd_wf", wf)
+            lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
+            add("sweep_bwd N=%d [table form, %d ch/lane, %d window floats/wave%s]%s" % (ns_ + 1, cpl, wf, ", dslab %d" % dslab if dslab else "", label),
+                lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
+        lib.call("mvs_set_tuning", b"bwd_cpl", _lib.DEFAULT_TUNING.get("bwd_cpl", 1))
+        lib.call("mvs_set_tuning", b"bwd_wf", _lib.DEFAULT_TUNING.get("bwd_wf", 2048))
+        lib.call("mvs_set_tuning", b"bwd_dslab", 0)
+        for variant, gd, pf, dslab in ((1, 2, 0, 0), (0, 0, 0, 0), (0, 2, 0, 0)):
             lib.call("mvs_set_tuning", b"sweep_bwd", variant)
             lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
             lib.call("mvs_set_tuning", b"bwd_gd", gd)
             lib.call("mvs_set_tuning", b"bwd_pf", pf)
-            add("sweep_bwd N=%d [%s%s]%s" % (ns_ + 1, "per-wave windows, %s%s" % ("gradient 2 planes ahead" if gd == 2 else "rotating gradient set",
+            add("sweep_bwd N=%d [%s%s]%s" % (ns_ + 1, "round-2 per-wave windows, %s%s" % ("gradient 2 planes ahead" if gd == 2 else "rotating gradient set",
                                                                                    ", 1 wave/SIMD (3-4 views)" if pf == 2 else "") if variant == 0
-                                             else "view pairs + LDS atomics", ", dslab %d" % dslab if dslab else "", label),
+                                             else "round-1 view pairs + LDS atomics", ", dslab %d" % dslab if dslab else "", label),
                 lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
-        lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        lib.call("mvs_set_tuning", b"sweep_bwd", _lib.DEFAULT_TUNING.get("sweep_bwd", 2))
         lib.call("mvs_set_tuning", b"bwd_dslab", 0)
         lib.call("mvs_set_tuning", b"bwd_gd", 2)
         lib.call("mvs_set_tuning", b"bwd_pf", 0)

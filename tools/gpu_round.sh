@@ -312,3 +312,15 @@ if [ "$what" = "prof" ] || [ "$what" = "all" ]; then
   mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
   rm -rf gpurun_out/prof
 fi
+if [ "$what" = "r3a" ]; then
+  # round 3, first session: the projection-table backward (K2) -- parity subset, A/B over its knobs at config-2 / N=5 shapes, step
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "sweep or homo_warp or golden_mvsnet or golden_unsup" > gpurun_out/pytest_r3a.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_r3a.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3a.log | tail -12
+  MVS_BENCH_BWD_ONLY=1 timeout 600 python tools/bench_kernels.py --reps 10 > gpurun_out/kernels_k2.log 2>&1; echo "kernels exit $?"; grep -E "sweep_bwd|sweep_fwd\[cached8\]" gpurun_out/kernels_k2.log
+  for t in "sweep_bwd=2" "sweep_bwd=0"; do
+    MVS_TUNING=$t timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_[$t].json" 2> "gpurun_out/bench_[$t].err"
+    echo "bench [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'], d.get('ms_per_step_async_wgrad_off'), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"
+  done
+fi
