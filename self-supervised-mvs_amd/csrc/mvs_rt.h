@@ -61,6 +61,24 @@ static __device__ __forceinline__ unsigned mvs_cvt_pk_bf16(float lo, float hi) {
 // for LDS, which is an order of magnitude slower than ds_add_f32.
 typedef __attribute__((address_space(3))) float mvs_lds_float;
 typedef __attribute__((address_space(1))) float mvs_global_float;
+// LDS-DMA (gfx950 global_load_lds): every lane's 4 bytes at gbase + voff_bytes land in LDS at lds_dst + 4 * lane -- no register
+// destination; completion is counted by vmcnt like any vector load, in order.  Issued as inline assembly ON PURPOSE: for the
+// builtin, hipcc puts an s_waitcnt vmcnt(0) in front of every later LDS read (it cannot tell which reads alias the DMA target),
+// which would drain a prefetch ring on every plane.  The kernels that use it place the waits themselves (MVS_WAIT_VMCNT) and
+// state the invariant that makes the count sufficient.  lds_dst must be wave-uniform (it travels in M0).
+static __device__ __forceinline__ void mvs_dma4(float* lds_dst, const float* gbase, unsigned voff_bytes) {
+    // wave-uniform by contract; the compiler cannot always prove it (an address derived from the wave index): readfirstlane
+    // moves the values into scalar registers (it folds away when they already are)
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(mvs_lds_float*)lds_dst);
+    const unsigned long long ga = (unsigned long long)(size_t)gbase;
+    const unsigned ga_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));   // the builtin returns int:
+    const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);           // widen as UNSIGNED halves
+    gbase = (const float*)(size_t)(((unsigned long long)ga_hi << 32) | (unsigned long long)ga_lo);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff_bytes), "s"(gbase) : "memory", "m0");
+}
+#define MVS_DMA4(lds_dst, gbase, voff_bytes) mvs_dma4((lds_dst), (gbase), (voff_bytes))
+// wait until at most n vector-memory operations of this wave are outstanding (n: compile-time constant <= 63)
+#define MVS_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MVS_LDS_ATOMIC_ADD(ptr, v) \
     ((void)__hip_atomic_fetch_add((mvs_lds_float*)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) \

@@ -1266,7 +1266,8 @@ static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
 extern int g_sweep_bwd_cpl;   // plane_sweep_bwd.hip: knob "bwd_cpl"
 extern int g_sweep_bwd_wf;    // plane_sweep_bwd.hip: knob "bwd_wf"
-bool sweep_bwd_tb_supports(const SweepArgs& a);
+extern int g_sweep_bwd_pd;    // plane_sweep_bwd.hip: knob "bwd_pd"
+bool sweep_bwd_tb_supports(const SweepArgs& a, int C);
 int launch_sweep_bwd_tb(SweepArgs& a, int C, hipStream_t st);
 extern int g_conv_split;
 extern int g_conv_small;
@@ -1277,7 +1278,7 @@ extern int g_conv_xcd;
 extern int g_conv_fs;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_wgrad_groups;
-static int g_sweep_bwd_variant = 2;   // knob "sweep_bwd": 2 = projection-table form (plane_sweep_bwd.hip; <= 4 source views), 0 = round-2 per-wave windows, 1 = view-pair kernel with LDS atomics
+static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views; the default), 1 = view-pair kernel with LDS atomics, 2 = projection-table form with an LDS-DMA ring (plane_sweep_bwd.hip; round 3, measured slower: DESIGN.md section 4)
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
@@ -1293,7 +1294,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
-        {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 2}, {"bwd_cpl", &g_sweep_bwd_cpl, 1, 4}, {"bwd_wf", &g_sweep_bwd_wf, 1024, 8192},
+        {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 2}, {"bwd_cpl", &g_sweep_bwd_cpl, 1, 4}, {"bwd_wf", &g_sweep_bwd_wf, 1024, 8192}, {"bwd_pd", &g_sweep_bwd_pd, 0, 16},
         {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2},
     };
     for (const Knob& k : knobs)
@@ -1430,7 +1431,7 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
 
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
-    if (g_sweep_bwd_variant == 2 && sweep_bwd_tb_supports(a)) return launch_sweep_bwd_tb(a, C, st);
+    if (g_sweep_bwd_variant == 2 && sweep_bwd_tb_supports(a, C)) return launch_sweep_bwd_tb(a, C, st);
     if (g_sweep_bwd_variant != 1 && a.NS <= 4) {
         // 1-2 views: 2 waves per SIMD with the upstream gradient requested two planes ahead (knob "bwd_gd" = 0: 3 waves per SIMD, one
         // rotating register set); 3-4 views: 2 waves per SIMD (knob "bwd_pf" = 2: ONE wave per SIMD, 512 registers, nothing spills)

@@ -1,24 +1,35 @@
-// K2, projection-table form (round 3; default for 1..4 source views): backward of the fused homography warp + variance.
+// K2, projection-table form with an LDS-DMA ring (round 3).  EXPERIMENTAL: behind mvs_set_tuning("sweep_bwd", 2); the default
+// stays the round-2 per-wave-window kernel (plane_sweep.hip), which measured faster (0.32 ms vs 0.70 ms at BASELINE config 2:
+// profiles/r03_run4_k2_table_form_v3_lds_dma_ab.log, counters profiles/r03_run5_pmc_sq_k2_table_form_v3.json).  Parity-green on
+// the GPU and in the emulation; kept as the test bed of two ideas and of what they cost.
 //
-// What bounded the per-wave-window kernel of round 2 (plane_sweep.hip: 195 vector + 93 scalar instructions per (wave, plane),
-// profiles/r02_run19_pmc_sq_sweep_kernels.json): of its ~1560 lane-operations per (pixel, plane) only ~830 are channel
-// arithmetic.  The rest is per-PIXEL work replicated over the 8 channel lanes of a pixel on every plane (homography, reciprocal,
-// floor, bilinear weights: ~60 instructions for two views), change detection, and a flush that serialises the wave over its 8
-// pixel groups with ~100 instructions per iteration; and 130-200 registers left 2 waves per SIMD to hide any of it.
+// Idea 1 -- take the per-PIXEL work out of the plane loop.  The round-2 kernel spends ~195 vector instructions per (wave of 8
+// pixels, plane), of which ~104 are channel arithmetic; the rest is the projection replicated over the 8 channel lanes of a pixel
+// (homography, reciprocal, floor, bilinear weights), change detection and the flush.  Here a wave = PW = 64 / C pixels side by side x
+// C channel lanes (ONE channel per lane; the 8 (4) pixels of its block as groups one after the other, all into the same per-wave LDS
+// windows), and before every batch of 16 planes the wave computes a TABLE in LDS -- for every (pixel of the group, view, plane) the
+// four bilinear weights and the packed base texel, the 64 lanes spread over (row, plane) -- plus a uniform bit mask of the planes on
+// which SOME lane enters a new 2x2 block.  Planes without a change take a fast step: three LDS reads (gradient, two weight quads),
+// ~24 vector instructions for two views.
+// Idea 2 -- nothing in the plane loop waits on a register load.  The upstream gradient arrives by LDS-DMA (global_load_lds_dword,
+// inline assembly: mvs_rt.h says why) into a ring of R planes, exactly one request per step, so `s_waitcnt vmcnt(R-1)` at the top
+// of step i means plane i has landed; a lane that will enter a new block on plane i + R requests it on plane i, 4 taps by LDS-DMA
+// into its staging slots, BEFORE that step's ring request -- whose arrival step i + R waits for anyway (loads complete in order).
 //
-// Here the per-pixel work is taken OUT of the plane loop:
-//  * a wave walks PW = 64 / (C / CPL) pixels side by side (CPL = channels per lane: 1, 2 or 4 -> 2, 4 or 8 pixels at C = 32) and the
-//    8 pixels of its 4x2 block as 8 / PW groups one after the other, all into the same per-wave LDS windows;
-//  * before every batch of TB planes the wave computes a TABLE in LDS -- for every (pixel of the group, view, plane) the four
-//    bilinear weights and the packed base texel -- with the 64 lanes spread over (row, plane): the projection arithmetic runs
-//    ONCE per (pixel, view, plane) instead of once per channel lane (~2 instructions per (wave, plane) instead of ~60);
-//  * in the plane loop a lane reads its pixel's table entry with two broadcast LDS reads per view (ds_read_b128 + ds_read_b32),
-//    compares the packed texel with the one its register-resident 2x2 block belongs to (ONE v_cmp per view), and runs the channel
-//    arithmetic: ~26 instructions per channel for two views, nothing else;
-//  * a block change (every ~20 planes at DTU-like geometry) takes the slow path: re-gather (CPL floats per tap: a pixel's lanes
-//    read one contiguous 128-byte texel) + flush of the accumulators into the wave's window, pixel groups one after the other
-//    (plain read-add-write, no LDS atomics: plane_sweep.hip explains why);
-//  * 1 channel per lane needs ~50 registers: the waves per SIMD are limited by the LDS windows, not by registers.
+// What the measurement says (counters of the C = 32, 2-view launch: 184 M vector + 142 M scalar instructions, i.e. 93 + 72 per
+// (wave of TWO pixels, plane) -- twice the round-2 kernel's count per pixel; waves parked at s_waitcnt 56 % of their cycles):
+//  * at DTU-like geometry the sample point moves 0.03-0.055 texel per plane in x and 0.012-0.02 in y: a (pixel, view) enters a new
+//    block every 13-22 planes, a wave of 2 pixels x 2 views has such an event every ~4 planes, and every event makes TWO planes slow
+//    (the request R planes ahead and the take-over + flush): half of all planes run the ~100-instruction slow step, not the fast one;
+//  * every walk (group x depth segment, 22-48 planes with 24 texels of window per view) starts with two exposed memory round trips:
+//    the ring's first requests, and a register gather of the first block (nothing could be staged for plane 0);
+//  * hipcc keeps ~90 loop-invariant addresses in registers across the plane loop (161-205 VGPRs for what needs ~60): 3 waves per SIMD
+//    at best, with the LDS (52 KB per workgroup) as the second limit.
+// Channel arithmetic alone is 13 wave-instructions per (pixel, plane) in either layout; the round-2 kernel spends 24, and a version
+// of this one with the slow step slimmed to ~40 instructions and the start-up bubbles removed would land at ~20-26: not the factor
+// the 40 % target needs (DESIGN.md section 4 has the arithmetic).  The flush of register accumulators into LDS windows on every
+// block change is what both designs pay for; it is the thing to replace, not the bookkeeping around it.
+//
 // Windows, depth segments, the summed write-out with coalesced global atomics and the fallbacks (tap outside the window ->
 // global atomic; footprint larger than a window -> shorter segment) are those of the round-2 kernel.
 //
@@ -42,28 +53,21 @@ template <int N> __device__ __forceinline__ void stn(float* p, const VecN<N>& x)
     else if constexpr (N == 2) { float2 t; t.x = x.v[0]; t.y = x.v[1]; *reinterpret_cast<float2*>(p) = t; }
     else *p = x.v[0];
 }
-template <int N> __device__ __forceinline__ VecN<N> zeron() {
-    VecN<N> r;
-#pragma unroll
-    for (int k = 0; k < N; ++k) r.v[k] = 0.f;
-    return r;
-}
 #if defined(MVS_CPU_EMUL)
-#define MVS_PINN(x) ((void)0)
+#define MVS_PIN1(x) ((void)0)
 #else
-template <int N> __device__ __forceinline__ void pinn(VecN<N>& x) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(x.v[k]));
-}
-#define MVS_PINN(x) pinn(x)
+#define MVS_PIN1(x) asm volatile("" : "+v"(x))
 #endif
 
-template <int C, int CPL> struct TbCfg {
-    static constexpr int LPP = C / CPL;              // lanes per pixel
-    static constexpr int PW = 64 / LPP;              // pixels a wave walks side by side
-    static constexpr int BW = 4, BH = 2, PB = 8;     // the wave's pixel block ...
-    static constexpr int NG = PB / PW;               // ... walked as NG groups one after the other
-    static_assert(C % CPL == 0 && LPP >= 8 && LPP <= 32 && PB % PW == 0, "unsupported channels-per-lane for this channel count");
+// A wave = PW pixels side by side x C channel lanes (ONE channel per lane); the PB pixels of its block (BW x 2) as NG groups.
+// 3-4 source views take a 2x2 block: the windows of four views must share the same LDS budget.
+template <int C, int NS_T> struct TbCfg {
+    static constexpr int PW = 64 / C;                                   // pixels a wave walks side by side
+    static constexpr int PB0 = NS_T <= 2 ? 8 : 4;
+    static constexpr int PB = PB0 < PW ? PW : PB0;                      // pixels of the wave's block ...
+    static constexpr int BH = 2, BW = PB / BH;
+    static constexpr int NG = PB / PW;                                  // ... walked as NG groups one after the other
+    static_assert(C == 8 || C == 16 || C == 32, "one channel per lane: 8, 16 or 32 channels");
 };
 
 #define TB_NOBLOCK 0x7fff7fff                        // "no block held": not a packed base texel (the launcher keeps W, H < 32000)
@@ -128,49 +132,75 @@ __device__ __forceinline__ void tb_flush_groups(bool want, int lane, int cxy, co
 }
 
 // MODE: 0 variance (MVSNet), 1 variance with the jdacs-ms alias quirk (S starts from r^2), 2 plain homo_warping
-// WF: floats of LDS window space per wave (all views together); WPS: waves per SIMD the register allocation is held to
-template <int C, int NS_T, int CPL, int MODE, int WF>
-__global__ __launch_bounds__(256) void plane_sweep_variance_bwd_tb_kernel(SweepArgs a) {
+// WF: floats of LDS window space per wave (all views together)
+// R:  depth of the LDS-DMA ring = look-ahead distance in planes.
+//
+// Memory pipeline of a wave (everything below is per wave; no workgroup barrier inside a depth segment):
+//  * the upstream gradient arrives by LDS-DMA (global_load_lds_dword: 64 lanes x 4 bytes = the wave's PW pixels x C channels of one
+//    plane, no register destination) into a ring of R planes; step i issues the request of plane i + R, ALWAYS exactly one per step
+//    (past the end of the segment a valid plane is re-requested), so that at the top of step i "at most R - 1 vector-memory
+//    operations outstanding" (s_waitcnt vmcnt(R-1)) means plane i has landed: loads complete in order;
+//  * the table (computed once per batch) also says on which planes SOME lane of the wave enters a new 2x2 block (a uniform bit
+//    mask): on plane i, R planes before such a plane, the lanes concerned request the new block -- 4 taps, LDS-DMA into the lane's
+//    staging slots -- BEFORE the ring request of step i; that ring request is the one whose arrival step i + R waits for, so the
+//    staged block has arrived too: taking it over costs no wait of its own, and nothing in the loop waits on a register load.
+//    (A gather issued on the plane that needs it must be waited for together with everything requested before it: the first cut
+//    of this kernel drained its prefetch ring on every block change -- profiles/r03_run1_k2_table_form_v1_ab.log.)
+//  * planes without a block change and without a look-ahead request take the FAST step: three LDS reads (gradient, two weight
+//    quads), ~24 vector instructions for two views, one DMA request.
+template <int C, int NS_T, int MODE, int WF, int R>
+__global__ __launch_bounds__(256) MVS_MIN_WAVES_PER_SIMD((NS_T <= 2 ? 3 : 2)) void plane_sweep_variance_bwd_tb_kernel(SweepArgs a) {
     constexpr bool WARP_ONLY = MODE == 2, MS_ALIAS = MODE == 1;
-    using Cfg = TbCfg<C, CPL>;
-    constexpr int LPP = Cfg::LPP, PW = Cfg::PW, NG = Cfg::NG, BW = Cfg::BW, BH = Cfg::BH, PB = Cfg::PB;
+    using Cfg = TbCfg<C, NS_T>;
+    constexpr int PW = Cfg::PW, NG = Cfg::NG, BW = Cfg::BW, BH = Cfg::BH, PB = Cfg::PB;
     constexpr int ROWS = PW * NS_T;                                  // table rows: (pixel of the group, view)
-    constexpr int TB = ROWS <= 4 ? 32 : (ROWS <= 8 ? 16 : 8);        // planes per table batch (64 lanes fill 64 / TB rows per pass)
-    constexpr int RSTRIDE = TB * 4 + 4;                              // floats per weight row (+4: the rows of two pixels on different banks)
+    constexpr int TB = 16;                                           // planes per table batch
+    constexpr int TS = TB + R;                                       // entries per row: the batch + the look-ahead into the next one
+    constexpr int TSX = TS + 1;                                      // packed texels: one more in front (the plane before the batch)
+    constexpr int RSTRIDE = TS * 4 + 4;                              // floats per weight row (+4: the rows of two pixels on different banks)
     constexpr int VIEW_FLOATS = WF / NS_T / C * C, WCAP = VIEW_FLOATS / C;
+    constexpr int DEPMAX = 256;                                      // planes per workgroup (the launcher keeps the slab below)
+    static_assert(TS < 64 && R >= 2 && R <= 32, "the per-batch change mask is one 64-bit word");
     __shared__ __attribute__((aligned(16))) float lds[4 * NS_T * VIEW_FLOATS];      // [wave][view][texel][C]
     __shared__ __attribute__((aligned(16))) float s_tw[4][ROWS * RSTRIDE];          // [wave][row][plane][w00 w01 w10 w11]
-    __shared__ int s_txy[4][ROWS * TB];                                             // [wave][row][plane] packed base texel
+    __shared__ int s_txy[4][ROWS * TSX];                                            // [wave][row][1 + plane] packed base texel
     __shared__ __attribute__((aligned(16))) float s_proj[4][PB * NS_T][8];          // [wave][pixel of the block, view][rx ry rz tx ty tz - -]
+    __shared__ float s_ring[4][R][64];                                              // [wave][slot][lane] upstream gradient (LDS-DMA)
+    __shared__ float s_stage[4][NS_T][4][64];                                       // [wave][view][tap][lane] staged blocks (LDS-DMA)
+    __shared__ float s_dep[DEPMAX];                                                 // the slab's per-plane depth hypotheses
     __shared__ int s_win[4][NS_T][5];                                               // per wave and view: x0, y0, w, h, usable
     __shared__ int s_fit[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int q = lane % LPP, pl = lane / LPP;
+    const int cq = lane % C, pl = lane / C;                          // channel, pixel of the group
     const int bx0 = (blockIdx.x % a.tiles_x) * (2 * BW) + (wv & 1) * BW, by0 = (blockIdx.x / a.tiles_x) * (2 * BH) + (wv >> 1) * BH;
     const int b = blockIdx.z;
     const int HW = a.H * a.W;
-    const int cq = CPL * q;
     const float inv_n = 1.0f / (float)(NS_T + 1);
     const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
     const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
+    const int ds0 = blockIdx.y * a.dslab;
+    const int dend = min(a.D, ds0 + a.dslab);
     // per (pixel of the block, view): the homography rows applied to (x, y, 1) and the translation -- once per kernel
     if (lane < PB * NS_T) {
         const int p = lane / NS_T, s = lane % NS_T;
         const float xf = (float)min(bx0 + (p % BW), a.W - 1), yf = (float)min(by0 + (p / BW), a.H - 1);
-        const float* R = rotb + s * 9;
+        const float* Rm = rotb + s * 9;
         float* o = s_proj[wv][lane];
-        o[0] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
-        o[1] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
-        o[2] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
+        o[0] = fmaf(Rm[0], xf, fmaf(Rm[1], yf, Rm[2]));
+        o[1] = fmaf(Rm[3], xf, fmaf(Rm[4], yf, Rm[5]));
+        o[2] = fmaf(Rm[6], xf, fmaf(Rm[7], yf, Rm[8]));
         o[3] = trb[s * 3]; o[4] = trb[s * 3 + 1]; o[5] = trb[s * 3 + 2];
     }
+    if (!a.per_pixel) {
+        for (int i = tid; i < dend - ds0; i += 256) s_dep[i] = a.depth[b * a.D + ds0 + i];
+    }
+    __syncthreads();
     // corners of the wave's pixel block (clipped to the image) for its footprint bound
     const float cxa = (float)min(bx0, a.W - 1), cxb = (float)min(bx0 + BW - 1, a.W - 1);
     const float cya = (float)min(by0, a.H - 1), cyb = (float)min(by0 + BH - 1, a.H - 1);
     float* const wwin = lds + (size_t)wv * NS_T * VIEW_FLOATS;     // this wave's windows
 
-    int ds = blockIdx.y * a.dslab;
-    const int dend = min(a.D, ds + a.dslab);
+    int ds = ds0;
     while (ds < dend) {
         // ---- segment [ds, de): the longest one for which every wave's windows fit (workgroup-uniform) ----
         int de = dend;
@@ -191,8 +221,8 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_tb_kernel(SweepA
                 for (int m = 1; m < 64; m <<= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
                 da = lo; db = hi;                      // depth range of THIS wave's pixels: its windows only have to hold them
             } else {
-                da = a.depth[b * a.D + ds];
-                db = a.depth[b * a.D + de - 1];
+                da = s_dep[ds - ds0];
+                db = s_dep[de - 1 - ds0];
             }
             bool fits = true;
 #pragma unroll
@@ -227,6 +257,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_tb_kernel(SweepA
             }
         }
         MVS_WAVE_SYNC();
+        const int L = de - ds;                       // planes of the segment
         // ---- the wave's pixel groups, one after the other, over the planes of the segment (no workgroup barrier in here) ----
 #pragma clang loop unroll(disable)
         for (int grp = 0; grp < NG; ++grp) {
@@ -234,159 +265,199 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_tb_kernel(SweepA
             const int xr = bx0 + (p % BW), yr = by0 + (p / BW);
             const bool live = xr < a.W && yr < a.H;  // lanes outside the image follow along (wave-wide votes) on a clamped pixel
             const int pix = min(yr, a.H - 1) * a.W + min(xr, a.W - 1);
-            const unsigned voff = (unsigned)pix * C + cq;                    // this lane's channels inside one [H,W,C] plane
+            const unsigned voff = (unsigned)pix * C + cq;                    // this lane's channel inside one [H,W,C] plane
             const size_t fbase = (size_t)b * HW * C + cq;
-            const VecN<CPL> r = ldn<CPL>(a.ref + (size_t)b * HW * C + voff);
+            const float r = a.ref[(size_t)b * HW * C + voff];
             const float two_n = live ? 2.0f * inv_n : 0.0f;                  // dead lanes contribute exact zeros
-            VecN<CPL> gr = zeron<CPL>();
-            VecN<CPL> tap[NS_T][4], acc[NS_T][4];
-            int cur[NS_T];
+            float gr = 0.f;
+            VecN<1> tap[NS_T][4], acc[NS_T][4];
+            int cur[NS_T], stage_xy[NS_T];
 #pragma unroll
             for (int s = 0; s < NS_T; ++s) {
-                cur[s] = TB_NOBLOCK;
+                cur[s] = TB_NOBLOCK; stage_xy[s] = TB_NOBLOCK;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { tap[s][t] = zeron<CPL>(); acc[s][t] = zeron<CPL>(); }
+                for (int t = 0; t < 4; ++t) { tap[s][t].v[0] = 0.f; acc[s][t].v[0] = 0.f; }
             }
             const float* __restrict__ twp = &s_tw[wv][(pl * NS_T) * RSTRIDE];   // this lane's pixel, view 0 (view s: + s * RSTRIDE)
-            const int* __restrict__ txp = &s_txy[wv][(pl * NS_T) * TB];
-
-            for (int b0 = ds; b0 < de; b0 += TB) {
-                const int n = min(TB, de - b0);
-                // ---- the table of this batch: lanes spread over (row, plane) ----
-                MVS_WAVE_SYNC();                     // the previous batch's reads are done (a wave's DS queue is in order)
+            const int* __restrict__ txp = &s_txy[wv][(pl * NS_T) * TSX + 1];     // [-1] = the plane before the batch
+            const float* __restrict__ gseg = a.gvar + ((size_t)b * a.D + ds) * HW * C;    // wave-uniform; plane i of the segment: + i * HW*C
+            const size_t gstep = (size_t)HW * C;
+            float* const ring = &s_ring[wv][0][0];
+            // the ring's first R planes (re-requesting the last plane when the segment is shorter keeps the count invariant)
 #pragma unroll
-                for (int e0 = 0; e0 < ROWS * TB; e0 += 64) {
-                    const int e = e0 + lane;
-                    const int row = e / TB, i = e % TB;
-                    if (e < ROWS * TB && i < n) {
-                        const int pp = row / NS_T, s = row % NS_T;
-                        const int pb = grp * PW + pp;
-                        const float* pr = s_proj[wv][pb * NS_T + s];
-                        float dep;
-                        if (a.per_pixel) {
-                            const int px = min(bx0 + (pb % BW), a.W - 1), py = min(by0 + (pb / BW), a.H - 1);
-                            dep = a.depth[((size_t)b * a.D + b0 + i) * HW + (size_t)py * a.W + px];
-                        } else {
-                            dep = a.depth[b * a.D + b0 + i];
-                        }
-                        // the forward kernel's arithmetic (v_rcp_f32 + one Newton step)
-                        const float zz = fmaf(pr[2], dep, pr[5]);
-                        float iz = MVS_RCP(zz);
-                        iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
-                        const float ix = fmaf(fmaf(pr[0], dep, pr[3]) * iz, a.sx, a.ox);
-                        const float iy = fmaf(fmaf(pr[1], dep, pr[4]) * iz, a.sy, a.oy);
-                        const float fx = floorf(ix), fy = floorf(iy);
-                        const float wx = ix - fx, wy = iy - fy;
-                        const float ex = 1.0f - wx, ey = 1.0f - wy;
-                        float4 wt;
-                        wt.x = ey * ex; wt.y = ey * wx; wt.z = wy * ex; wt.w = wy * wx;
-                        *reinterpret_cast<float4*>(&s_tw[wv][row * RSTRIDE + 4 * i]) = wt;
-                        s_txy[wv][row * TB + i] = tb_pack(MVS_F2I(fx), MVS_F2I(fy), a.H, a.W);
-                    }
-                }
-                MVS_WAVE_SYNC();
-                // ---- the planes of the batch ----
-                const float* __restrict__ gbase = a.gvar + ((size_t)b * a.D + b0) * HW * C;   // wave-uniform; + plane * HW*C + voff
-                const size_t gstep = (size_t)HW * C;
-                constexpr int PD = 4;                // upstream gradient requested PD planes ahead (PD registers per channel)
-                VecN<CPL> gq[PD];
-#pragma unroll
-                for (int j = 0; j < PD; ++j) gq[j] = ldn<CPL>(gbase + (size_t)min(j, n - 1) * gstep + voff);
+            for (int j = 0; j < R; ++j) MVS_DMA4(ring + j * 64, gseg + (size_t)min(j, L - 1) * gstep, voff * 4u);
 
-                // one plane: i = plane of the batch, g = its upstream gradient
-                auto plane = [&](const int i, const VecN<CPL>& g) __attribute__((always_inline)) {
-                    float4 wt[NS_T];
-                    int xy[NS_T];
-                    bool any = false;
+            int i = 0;                               // plane of the segment being processed
+            int tb0 = 0, next_fill = 0;              // first plane of the table batch in LDS, first plane of the next one
+            unsigned long long chgmask = 0ull;       // bit ii: some lane of the wave enters a new block on plane tb0 + ii
+
+            // channel arithmetic of one plane: bilinear samples of all views, their mean, the gradients of the samples
+            auto arith = [&](const float g, const float4 (&wt)[NS_T]) __attribute__((always_inline)) {
+                float S = WARP_ONLY ? 0.f : (MS_ALIAS ? r * r : r);
+                float v[NS_T];
+                if (!WARP_ONLY) {
 #pragma unroll
                     for (int s = 0; s < NS_T; ++s) {
-                        wt[s] = *reinterpret_cast<const float4*>(twp + s * RSTRIDE + 4 * i);
-                        xy[s] = txp[s * TB + i];
-                        any = any || xy[s] != cur[s];
+                        v[s] = fmaf(tap[s][3].v[0], wt[s].w, fmaf(tap[s][2].v[0], wt[s].z, fmaf(tap[s][1].v[0], wt[s].y, tap[s][0].v[0] * wt[s].x)));
+                        S += v[s];
                     }
-                    if (MVS_ANY(any)) {
-                        // ---- slow path: some pixel of the wave leaves its 2x2 block on this plane ----
+                }
+                float gs = g * two_n;                            // g * 2/N (0 on dead lanes)
+                const float Sm = S * inv_n;
+                if (WARP_ONLY) gs = live ? g : 0.f;              // plain homo_warping: the warped sample itself gets the gradient
+                else if (MS_ALIAS) gr += gs * r * (1.0f - 2.0f * Sm);
+                else gr += gs * (r - Sm);
 #pragma unroll
-                        for (int s = 0; s < NS_T; ++s) {
-                            const bool chg = xy[s] != cur[s];
-                            if (MVS_ANY(chg)) {
-                                // request the new block first (the flush needs the accumulators and the OLD base texel, not the tap
-                                // values): the L2 round trip of the gather overlaps the LDS round trips of the flush
-                                if (chg) {
-                                    const int x0 = tb_x(xy[s]), y0 = tb_y(xy[s]);
-                                    const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
-                                    if (x0 >= 0 && x0 + 1 < a.W && y0 >= 0 && y0 + 1 < a.H) {   // common case: all four taps inside
-                                        tap[s][0] = ldn<CPL>(f); tap[s][1] = ldn<CPL>(f + C);
-                                        tap[s][2] = ldn<CPL>(f + a.W * C); tap[s][3] = ldn<CPL>(f + a.W * C + C);
-                                    } else {
-                                        const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
-                                        const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
-                                        tap[s][0] = (xin0 && yin0) ? ldn<CPL>(f) : zeron<CPL>();
-                                        tap[s][1] = (xin1 && yin0) ? ldn<CPL>(f + C) : zeron<CPL>();
-                                        tap[s][2] = (xin0 && yin1) ? ldn<CPL>(f + a.W * C) : zeron<CPL>();
-                                        tap[s][3] = (xin1 && yin1) ? ldn<CPL>(f + a.W * C + C) : zeron<CPL>();
-                                    }
-                                }
-                                tb_flush_groups<C, CPL, LPP>(chg && live && cur[s] != TB_NOBLOCK, lane, cur[s], acc[s], a.H, a.W,
-                                                             wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
-                                if (chg) {
-                                    cur[s] = xy[s];
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) acc[s][t] = zeron<CPL>();
-                                }
-                                // the gathered taps are waited for HERE, on the planes that re-gather
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) MVS_PINN(tap[s][t]);
-                            }
-                        }
-                    }
-                    // ---- channel arithmetic: bilinear samples of all views, their mean, the gradients of the samples ----
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        float S = WARP_ONLY ? 0.f : (MS_ALIAS ? r.v[k] * r.v[k] : r.v[k]);
-                        float v[NS_T];
-                        if (!WARP_ONLY) {
-#pragma unroll
-                            for (int s = 0; s < NS_T; ++s) {
-                                v[s] = fmaf(tap[s][3].v[k], wt[s].w, fmaf(tap[s][2].v[k], wt[s].z, fmaf(tap[s][1].v[k], wt[s].y, tap[s][0].v[k] * wt[s].x)));
-                                S += v[s];
-                            }
-                        }
-                        float gs = g.v[k] * two_n;                       // g * 2/N (0 on dead lanes)
-                        const float Sm = S * inv_n;
-                        if (WARP_ONLY) gs = live ? g.v[k] : 0.f;         // plain homo_warping: the warped sample itself gets the gradient
-                        else if (MS_ALIAS) gr.v[k] += gs * r.v[k] * (1.0f - 2.0f * Sm);
-                        else gr.v[k] += gs * (r.v[k] - Sm);
-#pragma unroll
-                        for (int s = 0; s < NS_T; ++s) {
-                            const float gv = WARP_ONLY ? gs : gs * (v[s] - Sm);
-                            acc[s][0].v[k] = fmaf(gv, wt[s].x, acc[s][0].v[k]);
-                            acc[s][1].v[k] = fmaf(gv, wt[s].y, acc[s][1].v[k]);
-                            acc[s][2].v[k] = fmaf(gv, wt[s].z, acc[s][2].v[k]);
-                            acc[s][3].v[k] = fmaf(gv, wt[s].w, acc[s][3].v[k]);
-                        }
-                    }
-                };
+                for (int s = 0; s < NS_T; ++s) {
+                    const float gv = WARP_ONLY ? gs : gs * (v[s] - Sm);
+                    acc[s][0].v[0] = fmaf(gv, wt[s].x, acc[s][0].v[0]);
+                    acc[s][1].v[0] = fmaf(gv, wt[s].y, acc[s][1].v[0]);
+                    acc[s][2].v[0] = fmaf(gv, wt[s].z, acc[s][2].v[0]);
+                    acc[s][3].v[0] = fmaf(gv, wt[s].w, acc[s][3].v[0]);
+                }
+            };
+
 #pragma clang loop unroll(disable)
-                for (int i = 0; i < n; i += PD) {
+            while (i < L) {
+                // ---- table refill at a batch boundary (+ R planes of look-ahead): lanes spread over (row, plane) ----
+                if (i == next_fill) {
+                    int keep = TB_NOBLOCK;               // the packed texel of plane i - 1 (lane = row), before the rows are overwritten
+                    if (i > 0 && lane < ROWS) keep = s_txy[wv][lane * TSX + 1 + (i - 1 - tb0)];
+                    MVS_WAVE_SYNC();                     // the previous batch's reads are done (a wave's DS queue is in order)
+                    const int nfill = min(TS, L - i);
+#pragma unroll 1
+                    for (int e0 = 0; e0 < ROWS * TS; e0 += 64) {
+                        const int e = e0 + lane;
+                        const int row = e / TS, ii = e % TS;
+                        if (e < ROWS * TS && ii < nfill) {
+                            const int pp = row / NS_T, s = row % NS_T;
+                            const int pb = grp * PW + pp;
+                            const float* pr = s_proj[wv][pb * NS_T + s];
+                            float dep;
+                            if (a.per_pixel) {
+                                const int px = min(bx0 + (pb % BW), a.W - 1), py = min(by0 + (pb / BW), a.H - 1);
+                                dep = a.depth[((size_t)b * a.D + ds + i + ii) * HW + (size_t)py * a.W + px];
+                            } else {
+                                dep = s_dep[ds - ds0 + i + ii];
+                            }
+                            // the forward kernel's arithmetic (v_rcp_f32 + one Newton step)
+                            const float zz = fmaf(pr[2], dep, pr[5]);
+                            float iz = MVS_RCP(zz);
+                            iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
+                            const float ix = fmaf(fmaf(pr[0], dep, pr[3]) * iz, a.sx, a.ox);
+                            const float iy = fmaf(fmaf(pr[1], dep, pr[4]) * iz, a.sy, a.oy);
+                            const float fx = floorf(ix), fy = floorf(iy);
+                            const float wx = ix - fx, wy = iy - fy;
+                            const float ex = 1.0f - wx, ey = 1.0f - wy;
+                            float4 wt4;
+                            wt4.x = ey * ex; wt4.y = ey * wx; wt4.z = wy * ex; wt4.w = wy * wx;
+                            *reinterpret_cast<float4*>(&s_tw[wv][row * RSTRIDE + 4 * ii]) = wt4;
+                            s_txy[wv][row * TSX + 1 + ii] = tb_pack(MVS_F2I(fx), MVS_F2I(fy), a.H, a.W);
+                        }
+                    }
+                    if (lane < ROWS) s_txy[wv][lane * TSX] = keep;
+                    MVS_WAVE_SYNC();
+                    // which planes of the batch see a block change in SOME lane of the wave: entry != the entry of the plane before
+                    chgmask = 0ull;
 #pragma unroll
-                    for (int j = 0; j < PD; ++j) {
-                        if (i + j < n) {             // wave-uniform
-                            plane(i + j, gq[j]);
-                            if (i + j + PD < n) gq[j] = ldn<CPL>(gbase + (size_t)(i + j + PD) * gstep + voff);
+                    for (int e0 = 0; e0 < ROWS * TS; e0 += 64) {
+                        const int e = e0 + lane;
+                        const int row = e / TS, ii = e % TS;
+                        bool c = false;
+                        if (e < ROWS * TS && ii < nfill) c = s_txy[wv][row * TSX + 1 + ii] != s_txy[wv][row * TSX + ii];
+                        const unsigned long long m = MVS_BALLOT(c);
+#pragma unroll
+                        for (int rr = e0 / TS; rr <= (e0 + 63) / TS && rr < ROWS; ++rr) {
+                            const int sh = rr * TS - e0;             // lane of entry (rr, 0)
+                            const unsigned long long part = sh >= 0 ? (m >> (sh & 63)) : (m << ((-sh) & 63));
+                            chgmask |= part & ((1ull << TS) - 1ull);
+                        }
+                    }
+                    tb0 = i;
+                    next_fill = i + TB;
+                }
+                const int ti = i - tb0;
+                const bool c_plane = ((chgmask >> ti) & 1ull) != 0ull;                        // scalar: a block change on this plane
+                const bool l_plane = i + R < L && ((chgmask >> (ti + R)) & 1ull) != 0ull;     // scalar: a block change R planes ahead
+                // plane i has landed in the ring, and so has every block staged for it (see the template comment)
+                MVS_WAIT_VMCNT(R - 1);
+                const float g = ring[(i % R) * 64 + lane];
+                float4 wt[NS_T];
+#pragma unroll
+                for (int s = 0; s < NS_T; ++s) wt[s] = *reinterpret_cast<const float4*>(twp + s * RSTRIDE + 4 * ti);
+                if (c_plane) {
+                    // ---- lanes whose sample point leaves its 2x2 block on this plane ----
+#pragma unroll
+                    for (int s = 0; s < NS_T; ++s) {
+                        const int xy = txp[s * TSX + ti];
+                        const bool chg = xy != cur[s];
+                        if (MVS_ANY(chg)) {
+                            if (chg) {
+                                const int x0 = tb_x(xy), y0 = tb_y(xy);
+                                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                                if (stage_xy[s] == xy) {         // requested R planes ago: in the lane's staging slots by now
+                                    const float* st = &s_stage[wv][s][0][lane];
+                                    const float t0 = st[0], t1 = st[64], t2 = st[128], t3 = st[192];
+                                    tap[s][0].v[0] = (xin0 && yin0) ? t0 : 0.f; tap[s][1].v[0] = (xin1 && yin0) ? t1 : 0.f;
+                                    tap[s][2].v[0] = (xin0 && yin1) ? t2 : 0.f; tap[s][3].v[0] = (xin1 && yin1) ? t3 : 0.f;
+                                    stage_xy[s] = TB_NOBLOCK;
+                                } else {
+                                    // first plane of a walk, or a second change inside the look-ahead distance: a register gather
+                                    // (the compiler's wait for it drains the ring: rare)
+                                    const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                                    tap[s][0].v[0] = (xin0 && yin0) ? f[0] : 0.f;
+                                    tap[s][1].v[0] = (xin1 && yin0) ? f[C] : 0.f;
+                                    tap[s][2].v[0] = (xin0 && yin1) ? f[(size_t)a.W * C] : 0.f;
+                                    tap[s][3].v[0] = (xin1 && yin1) ? f[(size_t)a.W * C + C] : 0.f;
+                                }
+                            }
+                            tb_flush_groups<C, 1, C>(chg && live && cur[s] != TB_NOBLOCK, lane, cur[s], acc[s], a.H, a.W,
+                                                     wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                            if (chg) {
+                                cur[s] = xy;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) acc[s][t].v[0] = 0.f;
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) MVS_PIN1(tap[s][t].v[0]);
                         }
                     }
                 }
+                if (l_plane) {
+                    // ---- look-ahead: blocks entered on plane i + R are requested now, BEFORE this step's ring request ----
+#pragma unroll
+                    for (int s = 0; s < NS_T; ++s) {
+                        const int xl = txp[s * TSX + ti + R];
+                        const bool c = xl != txp[s * TSX + ti + R - 1];
+                        if (c && stage_xy[s] == TB_NOBLOCK) {
+                            const int x0 = tb_x(xl), y0 = tb_y(xl);
+                            const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                            const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                            const float* sb = a.src[s] + (size_t)b * HW * C;                    // wave-uniform
+                            const unsigned o = (unsigned)(((long)y0 * a.W + x0) * C + cq) * 4u;  // byte offset of tap 00 (used only where inside)
+                            float* st = &s_stage[wv][s][0][0];
+                            if (xin0 && yin0) MVS_DMA4(st, sb, o);
+                            if (xin1 && yin0) MVS_DMA4(st + 64, sb, o + (unsigned)C * 4u);
+                            if (xin0 && yin1) MVS_DMA4(st + 128, sb, o + (unsigned)(a.W * C) * 4u);
+                            if (xin1 && yin1) MVS_DMA4(st + 192, sb, o + (unsigned)(a.W * C + C) * 4u);
+                            stage_xy[s] = xl;
+                        }
+                    }
+                }
+                arith(g, wt);
+                // this step's ring request: plane i + R into the slot just read (past the segment: the last plane again)
+                MVS_DMA4(ring + (i % R) * 64, gseg + (size_t)min(i + R, L - 1) * gstep, voff * 4u);
+                ++i;
             }
             // the blocks still held in registers, then this group's share of grad_ref (a pixel's lanes cover whole texels)
 #pragma unroll
             for (int s = 0; s < NS_T; ++s)
-                tb_flush_groups<C, CPL, LPP>(live && cur[s] != TB_NOBLOCK, lane, cur[s], acc[s], a.H, a.W, wwin + s * VIEW_FLOATS + cq,
-                                             w[s], use[s], a.gsrc[s] + fbase);
-            if (!WARP_ONLY && live) {
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) MVS_GLOBAL_ATOMIC_ADD(a.gref + (size_t)b * HW * C + voff + k, gr.v[k]);
-            }
+                tb_flush_groups<C, 1, C>(live && cur[s] != TB_NOBLOCK, lane, cur[s], acc[s], a.H, a.W, wwin + s * VIEW_FLOATS + cq,
+                                         w[s], use[s], a.gsrc[s] + fbase);
+            if (!WARP_ONLY && live) MVS_GLOBAL_ATOMIC_ADD(a.gref + (size_t)b * HW * C + voff, gr);
+            // the next group's (segment's) ring prologue must not overtake this walk's last requests into the same slots: they are all
+            // older, and loads complete in order -- nothing to do
         }
         // ---- write the segment out: the four waves' windows summed on the fly, coalesced global atomics ----
         __syncthreads();
@@ -427,66 +498,73 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_tb_kernel(SweepA
 }
 
 // ---- launcher ------------------------------------------------------------------------------------------------------------
-int g_sweep_bwd_cpl = 1;     // knob "bwd_cpl": channels per lane of the table form (1, 2, 4; clipped to what the channel count allows)
-int g_sweep_bwd_wf = 2048;   // knob "bwd_wf": floats of LDS window space per wave (1536, 2048 or 3200)
+int g_sweep_bwd_cpl = 1;     // knob "bwd_cpl": accepted and ignored (the table form settled on one channel per lane)
+int g_sweep_bwd_wf = 1536;   // knob "bwd_wf": floats of LDS window space per wave (1536, 2048 or 3200), 1-2 source views at C = 32
+int g_sweep_bwd_pd = 8;      // knob "bwd_pd": depth of the LDS-DMA ring = look-ahead distance in planes (8 or 16)
 extern int g_sweep_bwd_dslab;   // plane_sweep.hip: knobs "bwd_dslab", "bwd_nowin"
 extern int g_sweep_bwd_nowin;
 
-template <int C, int NS_T, int CPL, int WF>
+template <int C, int NS_T, int WF, int R>
 static int launch_tb_mode(SweepArgs& a, dim3 grid, hipStream_t st) {
     if (a.warp_only) {
-        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, 1, CPL, 2, WF>), grid, dim3(256), 0, st, a);
-    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, NS_T, CPL, 1, WF>), grid, dim3(256), 0, st, a);
-    else MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, NS_T, CPL, 0, WF>), grid, dim3(256), 0, st, a);
+        if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, 1, 2, WF, R>), grid, dim3(256), 0, st, a);
+    } else if (a.ms_alias) MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, NS_T, 1, WF, R>), grid, dim3(256), 0, st, a);
+    else MVS_LAUNCH((plane_sweep_variance_bwd_tb_kernel<C, NS_T, 0, WF, R>), grid, dim3(256), 0, st, a);
     return mvs_check_launch("plane_sweep_variance_bwd_tb");
 }
 
-template <int C, int NS_T, int CPL>
-static int launch_tb_wf(SweepArgs& a, dim3 grid, hipStream_t st) {
-    // the A/B window sizes are instantiated for the benchmarked channel count only (C = 32); 3200 floats elsewhere (4 views need them)
-    if constexpr (C == 32) {
-        if (g_sweep_bwd_wf <= 1536 && NS_T <= 2) return launch_tb_mode<C, NS_T, CPL, 1536>(a, grid, st);
-        if (g_sweep_bwd_wf <= 2048 && NS_T <= 2) return launch_tb_mode<C, NS_T, CPL, 2048>(a, grid, st);
+template <int C, int NS_T, int WF>
+static int launch_tb_r(SweepArgs& a, dim3 grid, hipStream_t st) {
+    // the deeper ring is an A/B instantiation for the benchmarked shapes only (C = 32, 2 or 4 source views)
+    if constexpr (C == 32 && (NS_T == 2 || NS_T == 4)) {
+        if (g_sweep_bwd_pd >= 16) return launch_tb_mode<C, NS_T, WF, 16>(a, grid, st);
     }
-    return launch_tb_mode<C, NS_T, CPL, 3200>(a, grid, st);
+    return launch_tb_mode<C, NS_T, WF, 8>(a, grid, st);
 }
 
 template <int C, int NS_T>
-static int launch_tb_cpl(SweepArgs& a, dim3 grid, hipStream_t st) {
-    if constexpr (C == 32) {
-        if (g_sweep_bwd_cpl >= 4) return launch_tb_wf<C, NS_T, 4>(a, grid, st);
-        if (g_sweep_bwd_cpl == 2) return launch_tb_wf<C, NS_T, 2>(a, grid, st);
-    } else if constexpr (C == 16) {
-        if (g_sweep_bwd_cpl >= 2) return launch_tb_wf<C, NS_T, 2>(a, grid, st);
+static int launch_tb_wf(SweepArgs& a, dim3 grid, hipStream_t st) {
+    // 3-4 views: 2x2-pixel blocks, 2048 floats (16 texels per view at C = 32).  1-2 views: 4x2 blocks, 1536 floats by default
+    // (24 texels per view at C = 32; three workgroups per CU); the other sizes are A/B instantiations for C = 32, 2 views
+    if constexpr (NS_T >= 3) return launch_tb_r<C, NS_T, 2048>(a, grid, st);
+    if constexpr (C == 32 && NS_T == 2) {
+        if (g_sweep_bwd_wf >= 3200) return launch_tb_r<C, NS_T, 3200>(a, grid, st);
+        if (g_sweep_bwd_wf >= 2048) return launch_tb_r<C, NS_T, 2048>(a, grid, st);
     }
-    return launch_tb_wf<C, NS_T, 1>(a, grid, st);
+    return launch_tb_r<C, NS_T, 1536>(a, grid, st);
 }
 
 template <int C>
 static int launch_tb_c(SweepArgs& a, hipStream_t st) {
-    a.tiles_x = mvs_cdiv(a.W, 8);
+    const int bw = a.NS <= 2 ? TbCfg<C, 1>::BW : TbCfg<C, 4>::BW;
+    a.tiles_x = mvs_cdiv(a.W, 2 * bw);
     a.tiles_y = mvs_cdiv(a.H, 4);
     // depth slabs: >= ~2048 workgroups, each >= 16 planes: every extra slab re-gathers the blocks and writes its windows out once more
     const int tiles = a.tiles_x * a.tiles_y * a.B;
     int nslab = mvs_cdiv(2048, tiles);
     if (nslab > a.D / 16) nslab = a.D / 16;
+    if (nslab < mvs_cdiv(a.D, 256)) nslab = mvs_cdiv(a.D, 256);     // the kernel stages a slab's per-plane depths in LDS (256 planes)
     if (nslab < 1) nslab = 1;
     a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
+    if (a.dslab > 256) a.dslab = 256;
     a.no_window = g_sweep_bwd_nowin;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
     switch (a.NS) {
-        case 1: return launch_tb_cpl<C, 1>(a, grid, st);
-        case 2: return launch_tb_cpl<C, 2>(a, grid, st);
-        case 3: return launch_tb_cpl<C, 3>(a, grid, st);
-        case 4: return launch_tb_cpl<C, 4>(a, grid, st);
+        case 1: return launch_tb_wf<C, 1>(a, grid, st);
+        case 2: return launch_tb_wf<C, 2>(a, grid, st);
+        case 3: return launch_tb_wf<C, 3>(a, grid, st);
+        case 4: return launch_tb_wf<C, 4>(a, grid, st);
         default: break;
     }
     mvs_set_error("plane_sweep backward (table form): 1..4 source views, got %d", a.NS);
     return MVS_ERR_UNSUPPORTED;
 }
 
-// 1..4 source views, image sides < 32000 (the packed base texel); the caller falls back to the round-1 kernel otherwise
-bool sweep_bwd_tb_supports(const SweepArgs& a) { return a.NS >= 1 && a.NS <= 4 && a.W < 32000 && a.H < 32000; }
+// 1..4 source views, image sides < 32000 (the packed base texel), a feature map below 4 GiB (32-bit byte offsets of the DMA);
+// the caller falls back to the round-2 / round-1 kernels otherwise
+bool sweep_bwd_tb_supports(const SweepArgs& a, int C) {
+    return a.NS >= 1 && a.NS <= 4 && a.W < 32000 && a.H < 32000 && (double)a.H * a.W * C * 4.0 < 4.0e9;
+}
 
 int launch_sweep_bwd_tb(SweepArgs& a, int C, hipStream_t st) {
     if (C == 32) return launch_tb_c<32>(a, st);

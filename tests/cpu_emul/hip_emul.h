@@ -246,6 +246,9 @@ void launch(dim3 grid, dim3 block, F body) {
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 
+// LDS-DMA: the emulation copies synchronously (one lane = one thread), so the vmcnt waits are no-ops
+#define MVS_DMA4(lds_dst, gbase, voff_bytes) ((void)((lds_dst)[emul::lane] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gbase) + (voff_bytes))))
+#define MVS_WAIT_VMCNT(n) ((void)0)
 #define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_NT_STORE4(ptr, o) (*reinterpret_cast<float4*>(ptr) = (o))

@@ -81,7 +81,7 @@ def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
         gup = torch.randn(var.shape, generator=g)
         var.backward(gup)
     finally:
-        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_dslab", 0)
@@ -110,7 +110,7 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
     # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views); variant 6 = the projection-table
-    # form (round 3, the default), 7 = ... with its windows switched off; variants 0-5 are the round-1/2 kernels kept behind the knob
+    # form with the LDS-DMA ring (round 3, knob sweep_bwd=2; measured slower than variant 0, kept for A/B), 7 = ... with its windows off
     emul_lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else (2 if variant >= 6 else 0))
     emul_lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant in (2, 7) else 0)
     emul_lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
@@ -120,7 +120,7 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
         gup = torch.randn(var.shape, generator=g)
         var.backward(gup)
     finally:
-        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_nowin", 0)
         emul_lib.call("mvs_set_tuning", b"bwd_gd", 2)
         emul_lib.call("mvs_set_tuning", b"bwd_pf", 0)
@@ -133,18 +133,19 @@ def test_plane_sweep_backward_wide_depth_range(emul_lib, c, ns, step, hw, varian
         assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("c,ns,cpl,wf,mode", [
-    (32, 2, 1, 2048, "plane"), (32, 2, 2, 1536, "pixel"), (32, 2, 4, 3200, "alias"), (32, 1, 1, 2048, "warp"), (32, 1, 2, 2048, "plane"),
-    (32, 4, 1, 3200, "plane"), (32, 3, 2, 3200, "pixel"), (32, 4, 4, 3200, "alias"),
-    (16, 2, 1, 3200, "alias"), (16, 3, 2, 3200, "plane"), (16, 4, 1, 3200, "pixel"), (16, 1, 2, 3200, "warp"),
-    (8, 2, 1, 3200, "plane"), (8, 1, 1, 3200, "warp"), (8, 3, 1, 3200, "alias")])
-def test_plane_sweep_backward_table_form(emul_lib, c, ns, cpl, wf, mode):
-    """The projection-table backward (plane_sweep_bwd.hip, the default): every channels-per-lane layout (2, 4 or 8 pixels of a wave
-    side by side, 4 / 2 / 1 groups one after the other), window sizes, per-plane / per-pixel hypotheses, the jdacs-ms alias quirk
-    and plain homo_warping, on a ragged image (dead lanes), a depth range long enough for several table batches (> 32 planes) and
-    block changes in every batch, against the oracle's autograd."""
+@pytest.mark.parametrize("c,ns,wf,mode,pd", [
+    (32, 2, 1536, "plane", 8), (32, 2, 2048, "pixel", 16), (32, 2, 3200, "alias", 8), (32, 1, 1536, "warp", 8), (32, 1, 1536, "plane", 8),
+    (32, 4, 2048, "plane", 8), (32, 3, 2048, "pixel", 8), (32, 4, 2048, "alias", 16),
+    (16, 2, 1536, "alias", 8), (16, 3, 2048, "plane", 8), (16, 4, 2048, "pixel", 8), (16, 1, 1536, "warp", 8),
+    (8, 2, 1536, "plane", 8), (8, 1, 1536, "warp", 8), (8, 3, 2048, "alias", 8)])
+def test_plane_sweep_backward_table_form(emul_lib, c, ns, wf, mode, pd):
+    """The projection-table backward with the LDS-DMA ring (plane_sweep_bwd.hip, knob sweep_bwd=2): every channel count (2, 4 or 8
+    pixels of a wave side by side; 4x2- and 2x2-pixel blocks), window sizes, per-plane / per-pixel hypotheses, the jdacs-ms alias
+    quirk and plain homo_warping, both ring depths, on a ragged image (dead lanes), a depth range long enough for several table
+    batches with block changes in every batch -- some closer together than the look-ahead distance (the second one then takes the
+    register gather) --, against the oracle's autograd."""
     from mvs_amd import ops
-    g = torch.Generator().manual_seed(100 + c + ns + cpl)
+    g = torch.Generator().manual_seed(100 + c + ns + pd)
     b, d, h, w = 2, 37, 7, 11
     rot, trans = _cams(b, ns, h, w, g)
     ref = torch.randn(b, c, h, w, generator=g, requires_grad=True)
@@ -154,8 +155,8 @@ def test_plane_sweep_backward_table_form(emul_lib, c, ns, cpl, wf, mode):
     else:
         depth = (430 + 9.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     emul_lib.call("mvs_set_tuning", b"sweep_bwd", 2)
-    emul_lib.call("mvs_set_tuning", b"bwd_cpl", cpl)
     emul_lib.call("mvs_set_tuning", b"bwd_wf", wf)
+    emul_lib.call("mvs_set_tuning", b"bwd_pd", pd)
     try:
         if mode == "warp":
             from mvs_amd.ops import HomoWarp
@@ -167,8 +168,9 @@ def test_plane_sweep_backward_table_form(emul_lib, c, ns, cpl, wf, mode):
             gup = torch.randn(out.shape, generator=g)
             out.backward(gup)
     finally:
-        emul_lib.call("mvs_set_tuning", b"bwd_cpl", 1)
-        emul_lib.call("mvs_set_tuning", b"bwd_wf", 2048)
+        emul_lib.call("mvs_set_tuning", b"sweep_bwd", 0)
+        emul_lib.call("mvs_set_tuning", b"bwd_wf", 1536)
+        emul_lib.call("mvs_set_tuning", b"bwd_pd", 8)
     tens = [srcs[0]] if mode == "warp" else [ref] + srcs
     got = [t.grad.clone() for t in tens]
     for t in tens:

@@ -116,7 +116,7 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
     # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
-    # variant 6 = the projection-table form (round 3, the default), 7 = ... with its windows switched off
+    # variant 6 = the projection-table form with the LDS-DMA ring (round 3, knob sweep_bwd=2), 7 = ... with its windows switched off
     lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else (2 if variant >= 6 else 0))
     lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant in (2, 7) else 0)
     lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
@@ -127,7 +127,7 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
         var.backward(gup.to(dev))
         torch.cuda.synchronize()
     finally:
-        lib.call("mvs_set_tuning", b"sweep_bwd", 2)
+        lib.call("mvs_set_tuning", b"sweep_bwd", 0)
         lib.call("mvs_set_tuning", b"bwd_nowin", 0)
         lib.call("mvs_set_tuning", b"bwd_gd", 2)
         lib.call("mvs_set_tuning", b"bwd_pf", 0)

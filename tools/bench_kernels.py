@@ -94,16 +94,16 @@ def main():
         gv5 = torch.randn_like(v5)
         nbytes = C * vox * 4 + 2 * (ns_ + 1) * C * H * W * 4
         # round 3: the projection-table form (plane_sweep_bwd.hip) over its knobs, then the round-2 / round-1 kernels for reference
-        for cpl, wf, dslab in ((1, 2048, 0), (1, 1536, 0), (1, 3200, 0), (2, 2048, 0), (2, 1536, 0), (2, 3200, 0), (4, 2048, 0), (4, 3200, 0),
-                               (1, 2048, 96), (1, 2048, 192), (2, 2048, 96), (2, 2048, 192), (1, 2048, 24), (1, 2048, 0)):
+        for pd, wf, dslab in ((8, 1536, 0), (16, 1536, 0), (8, 2048, 0), (16, 2048, 0), (8, 3200, 0), (8, 1536, 24), (8, 1536, 32), (8, 1536, 64),
+                              (8, 1536, 96), (16, 1536, 96), (8, 1536, 192), (8, 1536, 0)):
             lib.call("mvs_set_tuning", b"sweep_bwd", 2)
-            lib.call("mvs_set_tuning", b"bwd_cpl", cpl)
+            lib.call("mvs_set_tuning", b"bwd_pd", pd)
             lib.call("mvs_set_tuning", b"bwd_wf", wf)
             lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
-            add("sweep_bwd N=%d [table form, %d ch/lane, %d window floats/wave%s]%s" % (ns_ + 1, cpl, wf, ", dslab %d" % dslab if dslab else "", label),
+            add("sweep_bwd N=%d [table form, DMA ring %d planes, %d window floats/wave%s]%s" % (ns_ + 1, pd, wf, ", dslab %d" % dslab if dslab else "", label),
                 lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
-        lib.call("mvs_set_tuning", b"bwd_cpl", _lib.DEFAULT_TUNING.get("bwd_cpl", 1))
-        lib.call("mvs_set_tuning", b"bwd_wf", _lib.DEFAULT_TUNING.get("bwd_wf", 2048))
+        lib.call("mvs_set_tuning", b"bwd_pd", _lib.DEFAULT_TUNING.get("bwd_pd", 8))
+        lib.call("mvs_set_tuning", b"bwd_wf", _lib.DEFAULT_TUNING.get("bwd_wf", 1536))
         lib.call("mvs_set_tuning", b"bwd_dslab", 0)
         for variant, gd, pf, dslab in ((1, 2, 0, 0), (0, 0, 0, 0), (0, 2, 0, 0)):
             lib.call("mvs_set_tuning", b"sweep_bwd", variant)
