@@ -228,6 +228,20 @@ int mvs_geo_consistency(const float* depth_ref, const float* const* depth_srcs, 
                         float pix_thresh, float rel_thresh, int* count, float* depth_sum, unsigned char* masks, float* reproj,
                         float* xy_src, hipStream_t stream);
 
+/* ---- depth-map fusion (the `fusibile` CUDA program behind jdacs/fusion/depthfusion.py:366-386) ---------
+ * Replaces the kernel `fusibile` (jdacs/fusion/fusibile/fusibile.cu:138-277) for ONE reference camera = one launch of the
+ * host loop fusibile.cu:416-421: per pixel, back-project with its depth, project into every other view of `subset`,
+ * accept the view when the disparities differ by less than depth_thresh and the normals by less than normal_thresh
+ * (radians), average the accepted 3-D points / normals / colours, keep the point when at least num_consistent views agree.
+ * normals_depths [V,H,W,4] (normal.xyz, depth): the texture of main.cpp:833-843; images [V,H,W,4] colour as float (or NULL);
+ * cams [V,32] floats: P (3x4 row-major) [12], M_inv [9], P(:,3) [3], camera centre C [3], 5 unused  (what
+ * cameraGeometryUtils.h:353-440 puts into Camera_cu); subset: DEVICE array of n_subset view ids; f = K(0,0).
+ * Texture fetches restate CUDA's linear filtering (1.8 fixed-point weights, clamped addressing): csrc/fusibile.hip header.
+ * out_points [H,W,12] = coord.xyz 0, normal.xyz 0, colour.xyz 0 -- all zeros where fewer views agree (fully overwritten). */
+int mvs_fusibile_fuse(const float* normals_depths, const float* images, const float* cams, const int* subset, int n_subset,
+                      int V, int H, int W, int ref_camera, float f, float depth_thresh, float normal_thresh,
+                      int num_consistent, int save_texture, float* out_points, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

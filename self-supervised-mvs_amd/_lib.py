@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),
     "mvs_depth_hypo": (_i, [_f, _f, _i, _i, _i, _f, _f, _s]),
     "mvs_geo_consistency": (_i, [_f, C.POINTER(C.c_void_p), _f, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _s]),
+    "mvs_fusibile_fuse": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _fl, _i, _i, _f, _s]),
     "mvs_unsup_loss_workspace_floats": (_ll, [_i, _i, _i, _i]),
     "mvs_unsup_loss_fwd": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _s]),
     "mvs_unsup_loss_bwd": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _fl, _f, _f, _f, _s]),

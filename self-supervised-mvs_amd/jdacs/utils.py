@@ -49,9 +49,21 @@ def load_checkpoint(model, ckpt, strict=True):
     return model.load_state_dict(sd, strict=strict)
 
 
-def save_depth_outputs(outputs, filenames, outdir):
+def write_depth_img(filename, depth):
+    """jdacs/eval.py:110-123: the depth map as an 8-bit PNG, grey = (depth - 500) / 2 through PIL's float -> "L" conversion
+    (the reference's own two calls; PIL is the reference's dependency for this file too).  Returns 1 like the reference."""
+    from PIL import Image
+    d = os.path.dirname(filename)
+    if d and not os.path.exists(d):
+        os.makedirs(d, exist_ok=True)
+    Image.fromarray((np.asarray(depth) - 500) / 2).convert("L").save(filename)
+    return 1
+
+
+def save_depth_outputs(outputs, filenames, outdir, depth_png=False):
     """What jdacs/eval.py:150-164 does with a batch of outputs: ``{}/depth_est/{:0>8}.pfm``-style names (``filename`` is
-    the dataset's format string with two slots) -> depth_est and confidence PFM files.  Returns the written paths."""
+    the dataset's format string with two slots) -> depth_est and confidence PFM files (+ `<depth>.pfm.png` through
+    write_depth_img when depth_png, eval.py:165).  Returns the written paths."""
     outputs = tensor2numpy(outputs)
     written = []
     for name, depth, conf in zip(filenames, outputs["depth"], outputs["photometric_confidence"]):
@@ -60,4 +72,7 @@ def save_depth_outputs(outputs, filenames, outdir):
             os.makedirs(os.path.dirname(path), exist_ok=True)
             save_pfm(path, np.ascontiguousarray(arr, dtype=np.float32))
             written.append(path)
+            if depth_png and kind == "depth_est":
+                write_depth_img(path + ".png", np.ascontiguousarray(arr, dtype=np.float32))
+                written.append(path + ".png")
     return written

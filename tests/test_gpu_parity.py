@@ -1096,6 +1096,88 @@ def test_geo_consistency_filter_golden(dev):
     assert float((r["final_mask"].cpu().numpy() != z["final_mask"]).mean()) < 2e-3
 
 
+def test_fusibile_fusion_kernel_and_folder_run(dev, tmp_path):
+    """the fusion kernel of the `fusibile` program (csrc/fusibile.hip; reference jdacs/fusion/fusibile/fusibile.cu:138-277)
+    vs oracle/fusibile_np.py at a DTU-like size, per reference camera; then the whole post-processing chain on files -- PFM depth /
+    confidence -> probability_filter -> gipuma folder (disp.dmb, fake normals.dmb, "<view>.png.P" cameras) -> depth_map_fusion
+    (in process on the GPU instead of the reference's os.system(fusibile)) -> final3d_model.ply -- against the oracle run on the same
+    arrays, byte for byte up to the few points whose consistency test sits exactly on a threshold."""
+    import numpy as np
+    from PIL import Image
+    from mvs_amd.jdacs.fusion import depthfusion as DF
+    from oracle import fusibile_np as FO
+    V, H, W = 5, 120, 160
+    Ps, nd, img, Ks, Es = FO.synthetic_scene(V, H, W, seed=4)
+    co = FO.fusibile_cameras(Ps)
+    lib = __import__("mvs_amd")._lib.get()
+    nd_t, img_t = torch.from_numpy(nd).to(dev), torch.from_numpy(img).to(dev)
+    cams_t = torch.from_numpy(co["cams"]).to(dev)
+    subset = torch.arange(V, dtype=torch.int32, device=dev)
+    nthr = float(np.float32(360.0) * np.float32(np.pi) / np.float32(180.0))
+    kept = 0
+    for ref in range(V):
+        out = torch.empty((H, W, 12), dtype=torch.float32, device=dev)
+        lib.call("mvs_fusibile_fuse", nd_t.data_ptr(), img_t.data_ptr(), cams_t.data_ptr(), subset.data_ptr(), V, V, H, W, ref,
+                 float(co["f"]), 0.25, nthr, 2, 1, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        got = out.cpu().numpy()
+        exp, _ = FO.fuse_view(nd, img, co["cams"], list(range(V)), ref, co["f"], 0.25, nthr, 2, True)
+        same = (got[..., 0] != 0) == (exp[..., 0] != 0)
+        assert same.mean() > 0.999, (ref, same.mean())
+        both = same & (exp[..., 0] != 0)
+        kept += int(both.sum())
+        assert np.abs(got[both] - exp[both]).max() < 1e-3 * np.abs(exp[both]).max()
+    assert kept > 0.3 * V * H * W
+    # ---- the chain on files ----
+    scan = tmp_path / "scan9"
+    (scan / "depth_est").mkdir(parents=True)
+    (scan / "confidence").mkdir()
+    root = tmp_path / "dtu" / "scan9"
+    (root / "images").mkdir(parents=True)
+    (root / "cams").mkdir()
+    rng = np.random.RandomState(0)
+    conf = (0.7 + 0.3 * rng.rand(V, H, W)).astype(np.float32)
+    for v in range(V):
+        DF.write_pfm(str(scan / "depth_est" / ("%08d.pfm" % v)), np.ascontiguousarray(nd[v, ..., 3]))
+        DF.write_pfm(str(scan / "confidence" / ("%08d.pfm" % v)), conf[v])
+        Image.fromarray(img[v, ..., 2::-1].astype(np.uint8)).save(str(root / "images" / ("%08d.png" % v)))    # b,g,r -> RGB file
+        E, K = Es[v], Ks[v]
+        lines = ["extrinsic"] + [" ".join(repr(float(x)) for x in row) for row in E] + ["", "intrinsic"] + \
+                [" ".join(repr(float(x)) for x in row) for row in K] + ["", "425.0 2.5"]
+        (root / "cams" / ("%08d_cam.txt" % v)).write_text("\n".join(lines) + "\n")
+    DF.probability_filter(str(scan), 0.8, num_views=V)
+    point_folder = tmp_path / "points_mvsnet"
+    (point_folder / "cams").mkdir(parents=True)
+    (point_folder / "images").mkdir()
+    for v in range(V):                                      # mvsnet_to_gipuma with .png images (the reference copies .jpg files)
+        DF.mvsnet_to_gipuma_cam(str(root / "cams" / ("%08d_cam.txt" % v)), str(point_folder / "cams" / ("%08d.png.P" % v)))
+        (point_folder / "images" / ("%08d.png" % v)).write_bytes((root / "images" / ("%08d.png" % v)).read_bytes())
+        sub = point_folder / ("2333__%08d" % v)
+        sub.mkdir()
+        DF.mvsnet_to_gipuma_dmb(str(scan / "depth_est" / ("%08d_prob_filtered.pfm" % v)), str(sub / "disp.dmb"))
+        DF.fake_gipuma_normal(str(sub / "disp.dmb"), str(sub / "normals.dmb"))
+    ply = DF.depth_map_fusion(str(point_folder), "unused-fusibile-exe", 0.25, 2)
+    data = open(ply, "rb").read()
+    # the oracle on the same files' content: filtered depths, normals.dmb re-read pixel-interleaved (the planar quirk), P files
+    nd2 = np.zeros_like(nd)
+    for v in range(V):
+        d = DF.load_pfm(str(scan / "depth_est" / ("%08d_prob_filtered.pfm" % v)))
+        nrm = DF._read_dmb_raw(str(point_folder / ("2333__%08d" % v) / "normals.dmb"))
+        nd2[v] = np.concatenate([nrm, d[..., None]], axis=2)
+    img2 = np.floor(img)                                    # the PNG holds 8-bit colours
+    P2 = [DF.read_p_file(str(point_folder / "cams" / ("%08d.png.P" % v))) for v in range(V)]
+    co2 = FO.fusibile_cameras(P2)
+    exp_pts = FO.fuse_all(nd2, img2, co2["cams"], co2["f"], 0.25, nthr, 2)
+    head, _, body = data.partition(b"end_header\n")
+    n = int(head.split(b"element vertex ")[1].split(b"\n")[0])
+    assert abs(n - exp_pts.shape[0]) <= max(3, exp_pts.shape[0] // 2000) and n > 0.2 * V * H * W and len(body) == 15 * n
+    if n == exp_pts.shape[0]:
+        rec = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+        a, b = np.frombuffer(body, dtype=rec), np.frombuffer(FO.ply_bytes(exp_pts).partition(b"end_header\n")[2], dtype=rec)
+        for k in "xyz":
+            assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-2)
+        assert float((np.abs(a["r"].astype(int) - b["r"].astype(int)) > 1).mean()) < 1e-3
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(3, 64, (61, 83)), (64, 64, (37, 65)), (64, 32, (40, 52)), (32, 16, (33, 70)), (16, 16, (45, 37)), (4, 32, (64, 96)),
                                          (32, 1, (64, 96))])
 def test_conv2d_lrelu_block_and_wide_channels(dev, cin, cout, hw):
