@@ -124,3 +124,49 @@ def calibrate_batchnorm(net, *inputs):
     for m, mo in zip(bns, old):
         m.momentum = mo
     net.eval()
+
+
+def build_fusion_folders(tmp_path, V, H, W, seed, prob_threshold=0.8):
+    """A synthetic multi-view scene written to disk the way jdacs/eval.py + jdacs/fusion/depthfusion.py lay it out, through the
+    product's own format functions: PFM depth / confidence -> probability_filter -> gipuma folder (cams/<view>.png.P, images/,
+    2333__<view>/disp.dmb + normals.dmb).  Returns (point_folder, oracle inputs read back from those files)."""
+    import pathlib
+    from PIL import Image
+    from mvs_amd.jdacs.fusion import depthfusion as DF
+    from oracle import fusibile_np as FO
+    tmp_path = pathlib.Path(tmp_path)
+    Ps, nd, img, Ks, Es = FO.synthetic_scene(V, H, W, seed=seed)
+    scan = tmp_path / "scan9"
+    (scan / "depth_est").mkdir(parents=True)
+    (scan / "confidence").mkdir()
+    root = tmp_path / "dtu" / "scan9"
+    (root / "images").mkdir(parents=True)
+    (root / "cams").mkdir()
+    rng = np.random.RandomState(seed)
+    conf = (0.7 + 0.3 * rng.rand(V, H, W)).astype(np.float32)
+    for v in range(V):
+        DF.write_pfm(str(scan / "depth_est" / ("%08d.pfm" % v)), np.ascontiguousarray(nd[v, ..., 3]))
+        DF.write_pfm(str(scan / "confidence" / ("%08d.pfm" % v)), conf[v])
+        Image.fromarray(img[v, ..., 2::-1].astype(np.uint8)).save(str(root / "images" / ("%08d.png" % v)))    # b,g,r -> RGB file
+        lines = ["extrinsic"] + [" ".join(repr(float(x)) for x in row) for row in Es[v]] + ["", "intrinsic"] + \
+                [" ".join(repr(float(x)) for x in row) for row in Ks[v]] + ["", "425.0 2.5"]
+        (root / "cams" / ("%08d_cam.txt" % v)).write_text("\n".join(lines) + "\n")
+    DF.probability_filter(str(scan), prob_threshold, num_views=V)
+    pf = tmp_path / "points_mvsnet"
+    (pf / "cams").mkdir(parents=True)
+    (pf / "images").mkdir()
+    for v in range(V):                                      # mvsnet_to_gipuma's steps, with .png images (the reference copies .jpg files)
+        DF.mvsnet_to_gipuma_cam(str(root / "cams" / ("%08d_cam.txt" % v)), str(pf / "cams" / ("%08d.png.P" % v)))
+        (pf / "images" / ("%08d.png" % v)).write_bytes((root / "images" / ("%08d.png" % v)).read_bytes())
+        sub = pf / ("2333__%08d" % v)
+        sub.mkdir()
+        DF.mvsnet_to_gipuma_dmb(str(scan / "depth_est" / ("%08d_prob_filtered.pfm" % v)), str(sub / "disp.dmb"))
+        DF.fake_gipuma_normal(str(sub / "disp.dmb"), str(sub / "normals.dmb"))
+    # what the fusion program sees: filtered depths, normals.dmb re-read pixel-interleaved (the planar quirk), 8-bit colours, P files
+    nd2 = np.zeros_like(nd)
+    for v in range(V):
+        d = DF.load_pfm(str(scan / "depth_est" / ("%08d_prob_filtered.pfm" % v)))
+        nrm = DF._read_dmb_raw(str(pf / ("2333__%08d" % v) / "normals.dmb"))
+        nd2[v] = np.concatenate([nrm, d[..., None]], axis=2)
+    P2 = [DF.read_p_file(str(pf / "cams" / ("%08d.png.P" % v))) for v in range(V)]
+    return str(pf), {"nd": nd2, "img": np.floor(img), "cams": FO.fusibile_cameras(P2)}

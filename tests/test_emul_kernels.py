@@ -1070,3 +1070,19 @@ def test_fusibile_fusion_kernel_vs_numpy_oracle(emul_lib):
     with pytest.raises(ValueError, match="reference camera"):
         lib.call("mvs_fusibile_fuse", nd_t.data_ptr(), None, cams_t.data_ptr(), subset.data_ptr(), 5, 5, 20, 28, 7, 1.0, 0.25, 1.0, 2, 0,
                  out.data_ptr(), None)
+
+
+def test_fusion_chain_on_files_vs_oracle(emul_lib, tmp_path):
+    """PFM -> probability_filter -> gipuma folder -> run_fusibile (the program's folder / camera / .dmb reading, the kernel on the
+    emulation, compaction, .ply layout): the written final3d_model.ply equals the oracle's bytes for the same files' content."""
+    from conftest import build_fusion_folders
+    from mvs_amd.jdacs.fusion import depthfusion as DF
+    from oracle import fusibile_np as FO
+    point_folder, ins = build_fusion_folders(tmp_path, 4, 20, 28, seed=4)
+    ply = DF.run_fusibile(point_folder, os.path.join(point_folder, "cams"), os.path.join(point_folder, "images"), 0.25, 2, 360.0,
+                          device="cpu", timestamp="20260927-000000")
+    assert ply.endswith(os.path.join("consistencyCheck-20260927-000000", "final3d_model.ply"))
+    nthr = float(np.float32(360.0) * np.float32(np.pi) / np.float32(180.0))
+    exp = FO.fuse_all(ins["nd"], ins["img"], ins["cams"]["cams"], ins["cams"]["f"], 0.25, nthr, 2)
+    assert exp.shape[0] > 100
+    assert open(ply, "rb").read() == FO.ply_bytes(exp)
