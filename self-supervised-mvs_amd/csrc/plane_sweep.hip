@@ -94,7 +94,8 @@ template <int C, int CPT> struct TileC {
 // {2, 4}): the per-plane projection of source view s (homography, reciprocal, floor, fractions) is the same for the four
 // lanes, so lane q computes only view q % NS_T and the others fetch (wx, wy, x0, y0) with quad-broadcast DPP moves
 // instead of recomputing them: ~20 (NS_T = 2) / ~70 (NS_T = 4) fewer VALU instructions per plane in a kernel whose VALU
-// is busy 73 % of the time.  Bit-identical results.  Variant 6 of the "sweep_fwd" knob; not yet measured on the GPU.
+// is busy 73 % of the time.  Bit-identical results.  Knob "fwd_qs" (or variant 6 of "sweep_fwd").  Round 3: also 3 views, and 6
+// views at 4 channels per lane (8 lanes per pixel: the values travel by ds_bpermute_b32 instead of a DPP move).
 // BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns CPT
 // CONSECUTIVE channels so that its values are one 16- (8-) byte store and the lanes of a pixel write one 64-byte segment.
 // DL (per-plane hypotheses only): the slab's depths are staged in LDS once and read back one plane ahead, and the taps of a
@@ -105,7 +106,7 @@ template <int C, int NS_T, int CPT, bool QS = false, bool BF = false, int DL = 0
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
     constexpr int V = CPT / 4;                     // float4s per tap per thread
-    static_assert(!QS || (C == 32 && CPT == 8 && (NS_T == 2 || NS_T == 4)), "quad sharing needs 4 lanes per pixel");
+    static_assert(!QS || ((C / CPT == 4 || C / CPT == 8) && NS_T <= C / CPT), "shared projection: 4 or 8 lanes per pixel, one view per lane");
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
     const int TW = a.tile_w, TH = PPB / TW;
     const int tid = threadIdx.x;
@@ -196,9 +197,16 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             float wx, wy;
             int x0, y0;
             if (QS) {
-                // view s was computed by quad lane s (NS_T == 2: lanes 0/1; lanes 2/3 computed the same pair again)
-                wx = MVS_QUAD_BCAST_F(own_wx, s); wy = MVS_QUAD_BCAST_F(own_wy, s);
-                x0 = MVS_QUAD_BCAST_I(own_x0, s); y0 = MVS_QUAD_BCAST_I(own_y0, s);
+                // view s was computed by lane s of the pixel's lane group (fewer views than lanes: the others computed some again).
+                // 4 lanes per pixel: one quad-broadcast DPP move per value; 8 lanes: ds_bpermute_b32 (LDS crossbar, no LDS memory)
+                if constexpr (LPP == 4) {
+                    wx = MVS_QUAD_BCAST_F(own_wx, s); wy = MVS_QUAD_BCAST_F(own_wy, s);
+                    x0 = MVS_QUAD_BCAST_I(own_x0, s); y0 = MVS_QUAD_BCAST_I(own_y0, s);
+                } else {
+                    const int srcl = (tid & 63 & ~(LPP - 1)) | s;
+                    wx = __shfl(own_wx, srcl); wy = __shfl(own_wy, srcl);
+                    x0 = __shfl(own_x0, srcl); y0 = __shfl(own_y0, srcl);
+                }
             } else {
                 const float zz = fmaf(rz[s], dep, tz[s]);
                 float iz = MVS_RCP(zz);                 // v_rcp_f32 (1 ulp) + one Newton step: < 1 ulp, 3 instructions
@@ -1281,6 +1289,7 @@ extern int g_conv2d_wgrad_groups;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views; the default), 1 = view-pair kernel with LDS atomics, 2 = projection-table form with an LDS-DMA ring (plane_sweep_bwd.hip; round 3, measured slower: DESIGN.md section 4)
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
+static int g_sweep_fwd_qs = 0;        // knob "fwd_qs": 1 = one projection per (pixel, view) shared by the pixel's channel lanes (C = 32; 2-4 views: quad DPP, 6 views: ds_bpermute); also selected by sweep_fwd = 6
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 int g_sweep_bwd_nowin = 0;            // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
@@ -1295,7 +1304,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 2}, {"bwd_cpl", &g_sweep_bwd_cpl, 1, 4}, {"bwd_wf", &g_sweep_bwd_wf, 1024, 8192}, {"bwd_pd", &g_sweep_bwd_pd, 0, 16},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"fwd_qs", &g_sweep_fwd_qs, 0, 1},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1353,20 +1362,30 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             a.dslab = g_sweep_dslab > 0 ? g_sweep_dslab : slab;
             if (dl && a.dslab > 512) a.dslab = 512;
             dim3 gridb(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
+            const bool qsb = (g_sweep_fwd_qs || variant == 6) && C == 32 && a.NS >= 2;
 #define MVS_BF_CASE(N, CPTN)                                                                                                   \
     case N:                                                                                                                    \
-        if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 1>), gridb, block, 0, st, a);      \
+        if (qsb && N >= 2 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 1>), gridb, block, 0, st, a); \
+        else if (qsb && N >= 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 0>), gridb, block, 0, st, a); \
+        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 1>), gridb, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 0>), gridb, block, 0, st, a);         \
         break;
             switch (a.NS) { MVS_BF_CASE(1, 8) MVS_BF_CASE(2, 8) MVS_BF_CASE(3, 8) MVS_BF_CASE(4, 8) MVS_BF_CASE(6, 4) }
 #undef MVS_BF_CASE
             return mvs_check_launch("plane_sweep_variance_fwd_cached (bf16 volume)");
         }
+        const bool qs = (g_sweep_fwd_qs || variant == 6) && C == 32 && !c16;
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
-        else if (c8 && variant == 6 && C == 32 && (N == 2 || N == 4))                                            \
-            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, (N == 2 || N == 4) ? N : 2, CPT8, (C == 32 && (N == 2 || N == 4))>), gridc, block, 0, st, a); \
+        else if (qs && N >= 2 && N <= 4 && c8 && dl)                                                              \
+            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, (C == 32 && N >= 2 && N <= 4), false, 1>), gridc, block, 0, st, a); \
+        else if (qs && N >= 2 && N <= 4 && c8)                                                                    \
+            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, (C == 32 && N >= 2 && N <= 4), false, 0>), gridc, block, 0, st, a); \
+        else if (qs && N == 6 && !c8 && dl)                                                                       \
+            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, (C == 32 && N == 6), false, 1>), gridc, block, 0, st, a); \
+        else if (qs && N == 6 && !c8)                                                                             \
+            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, (C == 32 && N == 6), false, 0>), gridc, block, 0, st, a); \
         else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 2>), gridc, block, 0, st, a); \
         else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 1>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \

@@ -836,10 +836,12 @@ def test_conv2d_wgrad_persistent_workgroups_walk_several_tiles(emul_lib):
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
 
 
-@pytest.mark.parametrize("ns,hw", [(2, (13, 21)), (4, (10, 19))])
-def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw):
-    """Forward variant 6 (the per-view projection computed once per pixel quad and broadcast) on ragged image sizes -- tiles
-    overhang the image, so some quads follow along on a dummy pixel -- for N = 3 and N = 5 views: bit-identical to variant 3."""
+@pytest.mark.parametrize("ns,hw,dl", [(2, (13, 21), 1), (4, (10, 19), 1), (3, (9, 17), 0), (6, (10, 13), 1), (6, (7, 19), 0)])
+def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw, dl):
+    """Forward with the shared projection (knob fwd_qs: the per-view projection computed by ONE lane of a pixel's lane group and
+    handed to the others -- quad DPP for 2-4 views at 8 channels per lane, ds_bpermute for 6 views at 4 channels per lane) on ragged
+    image sizes -- tiles overhang the image, so some lane groups follow along on a dummy pixel --, with and without the LDS-staged
+    depths, fp32 and bf16 volume: bit-identical to the default kernel."""
     from mvs_amd import ops
     g = torch.Generator().manual_seed(31 + ns)
     b, c, d = 2, 32, 9
@@ -849,16 +851,21 @@ def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw):
     ref = torch.randn(b, c, h, w, generator=g)
     srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
     depth = (430 + 21.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
-    outs = {}
-    for variant in (3, 6):
-        emul_lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-        try:
-            outs[variant] = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
-        finally:
-            emul_lib.call("mvs_set_tuning", b"sweep_fwd", 3)
-    assert torch.equal(outs[3], outs[6])
+    outs, outs16 = {}, {}
+    emul_lib.call("mvs_set_tuning", b"fwd_dl", dl)
+    try:
+        for qs in (0, 1):
+            emul_lib.call("mvs_set_tuning", b"fwd_qs", qs)
+            with torch.no_grad():
+                outs[qs] = ops.plane_sweep_variance(ref, srcs, rot, trans, depth)
+                outs16[qs] = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, out_dtype=torch.bfloat16)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"fwd_qs", 0)
+        emul_lib.call("mvs_set_tuning", b"fwd_dl", 1)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs16[0], outs16[1])
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
-    assert float((outs[6] - exp).abs().max()) < 2e-4
+    assert float((outs[1] - exp).abs().max()) < 2e-4
 
 
 @pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="1.5 minutes of emulation for a non-default variant; set MVS_EMUL_FULL=1")

@@ -324,3 +324,14 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(d['ms_per_step'], d['value'], d.get('ms_per_step_async_wgrad_off'), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_[$t].json"
   done
 fi
+if [ "$what" = "r3b" ]; then
+  # round 3, session B: the whole GPU suite (new: fusibile chain, tightened config-3 test), then the shared-projection forward (fwd_qs)
+  timeout 1500 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error|config-3|worst" gpurun_out/pytest_gpu.log | tail -15
+  for cfg in 2 3 5; do for t in "fwd_qs=0" "fwd_qs=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_c${cfg}_[$t].json" 2> "gpurun_out/bench_c${cfg}_[$t].err"
+    echo "bench config $cfg [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_c${cfg}_[$t].json"
+  done; done
+fi
