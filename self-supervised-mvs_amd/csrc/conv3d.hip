@@ -398,6 +398,199 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stride-1 implicit GEMM with PERSISTENT workgroups (round 3; layers with many tiles: conv0's input gradient, the 16->16 layers at
+// L1, CVP's full-resolution layers).  The one-tile-per-workgroup kernel above exposes every tile's halo staging (global -> registers
+// -> LDS, ~2 us of latency) to the MFMA pipe unless another resident workgroup happens to be in its k-loop, and the last round of a
+// launch runs half empty (1920 tiles on 768 slots).  Here a workgroup walks tiles t, t + G, t + 2G, ... in the XCD-aware brick order
+// and keeps the NEXT chunk's / tile's halo in flight in registers while the MFMAs of the current chunk run (the recipe of the
+// Cout = 8 kernels below: 15 % there).  Same arithmetic and the same k-order as conv_igemm_kernel<GEOM_S1>: bit-identical output,
+// one BatchNorm partial row per TILE (not per workgroup) so that the statistics buffer is the same.
+// ------------------------------------------------------------------------------------------------
+template <int CC, int NB>
+__global__ __launch_bounds__(256) MVS_MIN_WAVES_PER_SIMD((NB == 4 ? 2 : 3)) void conv_igemm_s1p_kernel(ConvArgs a, int xcd) {
+    using G = ConvGeom<GEOM_S1>;
+    constexpr int CCP = CC + 4, CQ = CC / 4, MB = G::MB;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ int tapoff[32];
+    __shared__ float red[4 * NB * 16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    const int vb = xcd ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    if (tid < 32) tapoff[tid] = tid < 27 ? (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP : 0;
+    int baseA[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int f = wave * MB + mb;
+        baseA[mb] = (((f / G::TQH) * G::RH + f % G::TQH) * G::RW + l15) * CCP;
+    }
+    auto tile_origin = [&](int t, int& b, int& qd0, int& qh0, int& qw0) {
+        int td, th, tw;
+        if (xcd) brick_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        else linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        qd0 = td * G::TQD; qh0 = th * G::TQH; qw0 = tw * G::TQW;
+    };
+    // halo tile -> registers (all loads issued back to back; zero outside the volume), registers -> LDS; the offset of item k relative
+    // to the tile's origin voxel does not depend on the tile; interior tiles skip the per-item bounds checks
+    constexpr int XIT = (NR * CQ + 255) / 256;
+    float4 xv[XIT];
+    // (the offsets are recomputed per chunk: a dozen integer operations per item against 11 registers held across the MFMA loop)
+    auto rel_of = [&](int i) {
+        const int vox = i / CQ, cq = i % CQ;
+        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+        return (((rd - 1) * a.Hi + (rh - 1)) * a.Wi + (rw - 1)) * a.Cin + 4 * cq;
+    };
+    auto load_chunk = [&](int b, int qd0, int qh0, int qw0, int chunk) {
+        const float* __restrict__ base = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.Cin + chunk * CC;
+        const bool interior = qd0 >= 1 && qd0 + G::TQD + 1 <= a.Di && qh0 >= 1 && qh0 + G::TQH + 1 <= a.Hi &&
+                              qw0 >= 1 && qw0 + G::TQW + 1 <= a.Wi;
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k)
+                if (tid + 256 * k < NR * CQ) xv[k] = *reinterpret_cast<const float4*>(base + rel_of(tid + 256 * k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < XIT; ++k) {
+                const int i = tid + 256 * k;
+                xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < NR * CQ) {
+                    const int vox = i / CQ;
+                    const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+                    const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                    if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                        xv[k] = *reinterpret_cast<const float4*>(base + rel_of(i));
+                }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NR * CQ) *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = xv[k];
+        }
+    };
+    const int nchunks = a.Cin / CC;
+    const int KS = ksteps_for(27, CC);
+    int b, qd0, qh0, qw0;
+    if (vb < ntiles) {
+        tile_origin(vb, b, qd0, qh0, qw0);
+        load_chunk(b, qd0, qh0, qw0, 0);
+    }
+    for (int t = vb; t < ntiles; t += gridDim.x) {
+        tile_origin(t, b, qd0, qh0, qw0);
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            __syncthreads();                                   // the previous chunk's / tile's reads of the LDS image are done
+            store_chunk();
+            __syncthreads();
+            if (chunk + 1 < nchunks) load_chunk(b, qd0, qh0, qw0, chunk + 1);      // in flight while this chunk's MFMAs run
+            else if (t + (int)gridDim.x < ntiles) {
+                int b2, d2, h2, w2;
+                tile_origin(t + gridDim.x, b2, d2, h2, w2);
+                load_chunk(b2, d2, h2, w2, 0);
+            }
+            const int kk0 = chunk * KS;
+            constexpr int PD = 2;                              // weight fragments PD k-steps ahead (see conv_igemm_kernel)
+            float4 bq[PD][NB], af[MB];
+            auto load_b = [&](int ks, float4 (&dst)[NB]) {
+                const int kc = ks < KS ? ks : KS - 1;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    dst[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + kc) * a.nb_total + nb) * 64 + lane) * 4);
+            };
+            auto load_a = [&](int ks, float4 (&dst)[MB]) {
+                const int kc = ks < KS ? ks : KS - 1;
+                const int kflat = 16 * kc + 4 * g;
+                const int aoff = tapoff[kflat / CC] + kflat % CC;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) dst[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+            };
+#pragma unroll
+            for (int u = 0; u < PD; ++u) load_b(u, bq[u]);
+            load_a(0, af);
+            for (int ks0 = 0; ks0 < KS; ks0 += PD) {
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    const int ks = ks0 + u;
+                    if (ks < KS) {
+                        float4 an[MB];
+                        load_a(ks + 1, an);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bq[u][nb].y, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bq[u][nb].z, acc[mb][nb]);
+                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bq[u][nb].w, acc[mb][nb]);
+                            }
+                        load_b(ks + PD, bq[u]);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) af[mb] = an[mb];
+                    }
+                }
+            }
+        }
+        // ---- epilogue: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
+        float st1[NB], st2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { st1[nb] = 0.f; st2[nb] = 0.f; }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int f = wave * MB + mb;
+            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+            if (qd >= a.QD || qh >= a.QH) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = qw0 + 4 * g + r;
+                if (qw >= a.QW) continue;
+                const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = nb * 16 + l15;
+                    if (co >= a.Cout) continue;
+                    float v = acc[mb][nb][r];
+                    st1[nb] += v;
+                    st2[nb] += v * v;
+                    if (a.scale) v = v * a.scale[co] + a.shift[co];
+                    else if (a.shift) v = v + a.shift[co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.skip) v += a.skip[obase + co];
+                    a.y[obase + co] = v;
+                }
+            }
+        }
+        if (a.partials) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float s1 = st1[nb], s2 = st2[nb];
+                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+                if (lane < 16) {
+                    red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
+                    red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * NB * 16) {
+                const int stat = tid / (NB * 16), n = tid % (NB * 16);
+                if (n < a.Cout) {
+                    float sm = 0.f;
+                    for (int w = 0; w < 4; ++w) sm += red[(w * NB * 16 + n) * 2 + stat];
+                    a.partials[((size_t)t * 2 + stat) * a.Cout + n] = sm;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cin == 1 (input gradient of the Cout=1 probability layer): direct form, one thread per voxel.
 // y[v][co] = sum_t x[v + t - 1] * wt[t][co]   (wt already flipped / transposed by the caller-side packer)
 // ------------------------------------------------------------------------------------------------
@@ -1423,6 +1616,7 @@ int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv wit
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
+int g_conv_persist = 1;  // tuning knob "conv_persist": 1 = stride-1 layers with many tiles run the persistent implicit-GEMM kernel (next tile's halo in flight during the MFMAs), 0 = never, n > 1 = with exactly n workgroups (tests)
 int g_conv_fs = 0;      // tuning knob "fs": fast halo staging of interior tiles in the generic implicit-GEMM kernels (unmeasured)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
 
@@ -1523,6 +1717,19 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
                    a.nb_total, wlayout, flip, total);
     }
     a.wp = ws;
+    if (kgeom == GEOM_S1 && g_conv_persist && NB == a.nb_total && !g_conv_fs) {
+        // persistent workgroups when every slot gets >= 2 tiles: 3 workgroups per CU (52 KB of LDS with 16-channel chunks; the
+        // register allocation is held to 3 waves per SIMD), 2 for the 64-wide layers (register budget)
+        const int slots = g_conv_persist > 1 ? g_conv_persist : 256 * (NB == 4 ? 2 : 3);   // > 1: that many workgroups (tests)
+        if (nblocks >= 2 * slots && (NB == 1 || NB == 2 || NB == 4)) {
+            dim3 pgrid(slots), block(256);
+#define MVS_S1P(CCV, NBV) MVS_LAUNCH((conv_igemm_s1p_kernel<CCV, NBV>), pgrid, block, 0, st, a, g_conv_xcd)
+            if (cc == 16) { if (NB == 1) MVS_S1P(16, 1); else if (NB == 2) MVS_S1P(16, 2); else MVS_S1P(16, 4); }
+            else { if (NB == 1) MVS_S1P(8, 1); else if (NB == 2) MVS_S1P(8, 2); else MVS_S1P(8, 4); }
+#undef MVS_S1P
+            return mvs_check_launch("conv_igemm_s1p");
+        }
+    }
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);

@@ -1093,3 +1093,35 @@ def test_fusion_chain_on_files_vs_oracle(emul_lib, tmp_path):
     exp = FO.fuse_all(ins["nd"], ins["img"], ins["cams"]["cams"], ins["cams"]["f"], 0.25, nthr, 2)
     assert exp.shape[0] > 100
     assert open(ply, "rb").read() == FO.ply_bytes(exp)
+
+
+@pytest.mark.parametrize("cin,cout,dims,slots", [(16, 16, (5, 6, 19), 3), (8, 32, (3, 5, 33), 2), (32, 64, (5, 3, 9), 1)])
+def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
+    """The persistent stride-1 implicit-GEMM kernel (knob conv_persist; default for layers with many tiles): a handful of workgroups
+    walking several ragged tiles each (boundary tiles, the next tile's halo held in registers across the k-loop, one BatchNorm partial
+    row per TILE), forward and input gradient, one and several channel chunks / Cout tiles: BIT-IDENTICAL to the one-tile-per-workgroup
+    kernel (same k-order), and equal to ATen within fp32 rounding."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(1, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2
+    gy = torch.randn(1, cout, *dims, generator=g)
+    outs = {}
+    slots = slots + 1                      # knob values > 1 = that many workgroups
+    emul_lib.call("mvs_set_tuning", b"conv_small", 0)
+    try:
+        for mode in (0, slots):
+            emul_lib.call("mvs_set_tuning", b"conv_persist", mode)
+            y, parts = ops.conv3d_forward(x, w, 1, False, want_stats=True)
+            gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), 1, False)
+            outs[mode] = (y, parts, gx)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"conv_persist", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_small", 1)
+    for a, b_ in zip(outs[0], outs[slots]):
+        assert torch.equal(a, b_)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, padding=1)
+    yr.backward(gy)
+    assert float((outs[slots][0] - yr).abs().max()) < 2e-4
+    assert float((outs[slots][2] - xr.grad).abs().max()) < 5e-4

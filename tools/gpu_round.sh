@@ -335,3 +335,15 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_c${cfg}_[$t].json"
   done; done
 fi
+if [ "$what" = "r3c" ]; then
+  # round 3, session C: persistent stride-1 implicit GEMM (conv_persist) -- parity subset + A/B at configs 2 and 4
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "conv3d_family or golden_costregnet or fusibile or smallest_volumes" > gpurun_out/pytest_r3c.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_r3c.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3c.log | tail -8
+  for cfg in 2 4; do for t in "conv_persist=0" "conv_persist=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c${cfg}_[$t].json" 2> "gpurun_out/bench_c${cfg}_[$t].err"
+    echo "bench config $cfg [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_c${cfg}_[$t].json"
+    grep -E "s1:1x192x128x160|16>16:s1|64>64:s1|32>32:s1" "gpurun_out/bench_c${cfg}_[$t].err" | head -12
+  done; done
+fi
