@@ -394,8 +394,9 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.get()
-    # weight gradients on a side HIP stream: safe here -- gradients are read (bucket.gather) only after backward() has
-    # returned, no DDP / DataParallel hooks; the library default is off (ops.py)
+    # weight gradients on a side HIP stream.  Since round 3 this is the LIBRARY default for the regulariser (ops.UNetRegulariserFn:
+    # one autograd node, the side stream joined before its gradients are returned, so gradient hooks cannot see unfinished ones);
+    # MVS_ASYNC_WGRAD=0 times the synchronous mode, and the line reports the other mode's ms/step beside the headline either way
     from mvs_amd import ops as _ops
     async_wgrad = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
     _ops.set_async_wgrad(async_wgrad)
@@ -549,7 +550,8 @@ def main():
             "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if (world > 1 and train) else "none",
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
-            "async_wgrad": bool(async_wgrad) if train else None,
+            "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
+            "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }

@@ -105,6 +105,13 @@ int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, i
                    float* stat_partials, hipStream_t stream);
 int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W, int Cin,
                      int Cout, int stride, hipStream_t stream);
+/* Input gradients with a summand: gx = d conv / dx + add (add [B,D,H,W,Cin] like gx, or NULL).  A tensor with two consumers -- the
+ * U-Net skip connections, jdacs/models/mvsnet.py:70-72, jdacs-ms/models/network.py:71-72 -- receives its second gradient
+ * contribution in the epilogue of the kernel that computes the first, instead of autograd's separate add pass over both. */
+int mvs_conv3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
+                         int Cin, int Cout, int stride, hipStream_t stream);
+int mvs_convT3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
+                          int Cin, int Cout, int stride, hipStream_t stream);
 int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
                      int Cout, int stride, hipStream_t stream);
 int mvs_convT3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin,

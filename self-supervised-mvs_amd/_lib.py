@@ -36,6 +36,8 @@ SIGNATURES = {
     "mvs_conv3d_stat_rows": (_i, [_i] * 8),
     "mvs_conv3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
     "mvs_conv3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv3d_dgrad_acc": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_convT3d_dgrad_acc": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_convT3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
     "mvs_convT3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),

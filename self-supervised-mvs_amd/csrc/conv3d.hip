@@ -1616,7 +1616,7 @@ int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv wit
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
-int g_conv_persist = 1;  // tuning knob "conv_persist": 1 = stride-1 layers with many tiles run the persistent implicit-GEMM kernel (next tile's halo in flight during the MFMAs), 0 = never, n > 1 = with exactly n workgroups (tests)
+int g_conv_persist = 0;  // tuning knob "conv_persist": 0 = never (default: measured SLOWER than five small workgroups per CU, profiles/r03_run8_*), 1 = stride-1 layers with many tiles run the persistent implicit-GEMM kernel (next tile's halo in flight during the MFMAs), n > 1 = with exactly n workgroups (tests)
 int g_conv_fs = 0;      // tuning knob "fs": fast halo staging of interior tiles in the generic implicit-GEMM kernels (unmeasured)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
 
@@ -1897,6 +1897,22 @@ extern "C" int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, floa
     return run_igemm(GEOM_TR2, gy, w, WL_IOK, 0, gx, ws, B, D / 2, H / 2, W / 2, Cout, Cin, ep, stream);
 }
 
+// The same with `add` [B,D,H,W,Cin] (or NULL) summed into the result in the epilogue: gx = d conv3d / dx + add.  A tensor with two
+// consumers (the U-Net's skip connections, mvsnet.py:70-72) gets its second gradient contribution without a separate pass over it.
+extern "C" int mvs_conv3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
+                                    int Cin, int Cout, int stride, hipStream_t stream) {
+    if (!add || (stride == 1 && Cout == 1)) {
+        MVS_REQUIRE(!add, MVS_ERR_UNSUPPORTED, "conv3d_dgrad_acc: the Cout = 1 input gradient takes no summand");
+        return mvs_conv3d_dgrad(gy, w, gx, ws, B, D, H, W, Cin, Cout, stride, stream);
+    }
+    int rc = check_stride(stride, D, H, W, "conv3d_dgrad_acc");
+    if (rc) return rc;
+    Epilogue ep = {nullptr, nullptr, add, 0, nullptr};
+    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_IOK, 1, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
+    MVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MVS_ERR_SHAPE, "conv3d_dgrad_acc stride 2: D,H,W must be even");
+    return run_igemm(GEOM_TR2, gy, w, WL_IOK, 0, gx, ws, B, D / 2, H / 2, W / 2, Cout, Cin, ep, stream);
+}
+
 // gw[Cout][Cin][27] = d conv3d / dw
 extern "C" int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W,
                                 int Cin, int Cout, int stride, hipStream_t stream) {
@@ -1922,6 +1938,15 @@ extern "C" int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, flo
     int rc = check_stride(stride, D, H, W, "convT3d_dgrad");
     if (rc) return rc;
     Epilogue ep = {nullptr, nullptr, nullptr, 0, nullptr};
+    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_OIK, 0, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
+    return run_igemm(GEOM_S2, gy, w, WL_OIK, 0, gx, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, ep, stream);
+}
+
+extern "C" int mvs_convT3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H,
+                                     int W, int Cin, int Cout, int stride, hipStream_t stream) {
+    int rc = check_stride(stride, D, H, W, "convT3d_dgrad_acc");
+    if (rc) return rc;
+    Epilogue ep = {nullptr, nullptr, add, 0, nullptr};
     if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_OIK, 0, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
     return run_igemm(GEOM_S2, gy, w, WL_OIK, 0, gx, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, ep, stream);
 }

@@ -58,6 +58,18 @@ class CostRegNet(nn.Module):
             raise RuntimeError("CostRegNet: bf16 activations are the eval-mode inference path")
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("CostRegNet needs D,H,W divisible by 8, got %s" % (tuple(x.shape[2:]),))
+        if self.training and x.dtype == torch.float32 and ops.FUSED_REGULARISER:
+            # the whole U-Net as one autograd node (ops.UNetRegulariserFn): same kernels, skip gradients summed in the dgrad
+            # epilogues, weight gradients on a side stream
+            order = [name for name, *_ in _REG_ENCODER] + [name for name, *_ in _REG_DECODER]
+            blocks = []
+            for i, (name, _, _, stride) in enumerate(_REG_ENCODER):
+                m = getattr(self, name)
+                blocks.append((m.conv, m.bn, False, stride, i - 1, -1))
+            for j, (name, _, _, skip) in enumerate(_REG_DECODER):
+                m = getattr(self, name)
+                blocks.append((m[0], m[1], True, 2, len(_REG_ENCODER) + j - 1, order.index(skip)))
+            return ops.unet_regulariser(x, blocks, self.prob)
         keep = {}
         for name, *_ in _REG_ENCODER:
             x = getattr(self, name)(x)

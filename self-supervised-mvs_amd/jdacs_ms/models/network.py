@@ -67,6 +67,15 @@ class CostRegNet(nn.Module):
             raise ValueError("CVP CostRegNet expects [B,16,D,H,W], got %s" % (tuple(x.shape),))
         if any(s % 2 for s in x.shape[2:]):
             raise ValueError("CVP CostRegNet needs even D,H,W, got %s" % (tuple(x.shape[2:]),))
+        if self.training and x.dtype == torch.float32 and ops.FUSED_REGULARISER:
+            names = [name for name, *_ in _CVP_ENCODER]
+            blocks = []
+            for i, (name, _, _, stride) in enumerate(_CVP_ENCODER):
+                m = getattr(self, name)
+                blocks.append((m.conv, m.bn, False, stride, i - 1, -1))
+            blocks.append((self.conv5[0], self.conv5[1], True, 1, len(names) - 1, names.index("conv2a")))
+            blocks.append((self.conv6[0], self.conv6[1], True, 2, len(names), names.index("conv0a")))
+            return ops.unet_regulariser(x, blocks, self.prob0).squeeze(1)
         keep = {}
         for name, *_ in _CVP_ENCODER:
             x = getattr(self, name)(x)

@@ -305,7 +305,9 @@ def conv_bn_relu3d_eval_bf16(x, weight, gamma, beta, running_mean, running_var, 
     return conv3d_forward_bf16(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
 
 
-def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False):
+def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False, add=None):
+    """Input gradient of conv3d / conv_transpose3d; ``add`` (same shape as the result, channels_last_3d) is summed into it in the
+    kernel's epilogue (the second gradient contribution of a tensor with two consumers: the U-Net skips)."""
     lib = _lib_for(gy)
     gy = as_cl3(gy)
     b, cin, d, h, w = in_shape
@@ -314,8 +316,16 @@ def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False):
     op = OP_CONVT_DGRAD if transposed else OP_CONV_DGRAD
     gx = empty_cl3(b, cin, d, h, w, gy)
     ws = _ws(lib, op, b, d, h, w, cin, cout, stride, gy)
-    lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(gx), _p(ws), b, d, h, w,
-             cin, cout, stride, _stream(gy), tag=_ctag("dgradT" if transposed else "dgrad", cin, cout, stride, b, d, h, w))
+    tag = _ctag("dgradT" if transposed else "dgrad", cin, cout, stride, b, d, h, w)
+    if add is None:
+        lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(gx), _p(ws), b, d, h, w,
+                 cin, cout, stride, _stream(gy), tag=tag)
+    else:
+        add = as_cl3(add)
+        if tuple(add.shape) != tuple(in_shape):
+            raise ValueError("conv3d_dgrad: summand shape %s != input shape %s" % (tuple(add.shape), tuple(in_shape)))
+        lib.call("mvs_convT3d_dgrad_acc" if transposed else "mvs_conv3d_dgrad_acc", _p(gy), _p(wt), _p(add), _p(gx), _p(ws), b, d, h,
+                 w, cin, cout, stride, _stream(gy), tag=tag)
     return gx
 
 
@@ -358,8 +368,11 @@ _BWD_OPEN = {}          # device index -> [main stream, side stream used?] while
 
 
 def set_async_wgrad(flag: bool) -> None:
-    global _ASYNC_WGRAD
+    """Weight gradients on a side stream: the per-layer Functions (off by default: unsafe under gradient hooks) AND the fused
+    regulariser node (on by default: joined before its gradients are returned)."""
+    global _ASYNC_WGRAD, _ASYNC_WGRAD_FUSED
     _ASYNC_WGRAD = bool(flag)
+    _ASYNC_WGRAD_FUSED = bool(flag)
 
 
 def _note_weight_use(weight: torch.Tensor) -> None:
@@ -497,6 +510,145 @@ class ConvBnReLU3dFn(torch.autograd.Function):
         gw = _wgrad_maybe_async(x, draw, weight, stride, transposed) if ctx.needs_input_grad[1] else None
         gskip = gy if has_skip else None
         return gx, gw, dgb[0], dgb[1], None, None, gskip, None, None, None, None, None
+
+
+# ---- the whole regulariser as ONE autograd node ----------------------------------------------------------------------------
+# jdacs/models/mvsnet.py:37-74 and jdacs-ms/models/network.py:44-74 are short straight-line programs of ConvBnReLU3D /
+# Deconv+BN+ReLU blocks with skips added after the ReLU, closed by the bias-only `prob` convolution.  Running one program
+# through ONE torch.autograd.Function (the same kernels as the per-layer Functions above, launched in the same order) buys what the
+# per-layer graph cannot give:
+#  * the second gradient contribution of a skip source is summed in the EPILOGUE of the input-gradient kernel of its other
+#    consumer (conv3d_dgrad(add=...)) instead of autograd's out-of-place add (three passes over the 126 MB level-0 tensor);
+#  * weight gradients run on a side HIP stream BY DEFAULT: they are handed to autograd only after the side stream has been joined,
+#    at the end of this node's backward, so DataParallel / DDP hooks (which fire when a gradient is RETURNED) can never observe an
+#    unfinished one -- the per-layer form had to leave that off (see _wgrad_maybe_async);
+#  * one node instead of ~25 on the autograd tape.
+# MVS_REG_FUSED=0 (or ops.FUSED_REGULARISER = False) restores the per-layer graph; both are tested against the same goldens.
+FUSED_REGULARISER = os.environ.get("MVS_REG_FUSED", "1") != "0"
+_ASYNC_WGRAD_FUSED = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
+
+
+class UNetRegulariserFn(torch.autograd.Function):
+    """x [B,C,D,H,W] -> logits [B,1,D,H,W].  ``prog``: tuple of (transposed, stride, src, skip, eps, momentum) per Conv/Deconv+BN+ReLU
+    block (src / skip = index of the block whose output is this block's input / is added after the ReLU; -1 = the volume x / no skip).
+    ``params``: per block weight, gamma, beta, running_mean, running_var; then the prob layer's weight and bias.  Train mode only."""
+
+    @staticmethod
+    def forward(ctx, x, prog, *params):
+        lib = _lib_for(x)
+        st = _stream(x)
+        x = as_cl3(x)
+        dev = x.device
+        n = len(prog)
+        ys, raws, statss = [], [], []
+        for i, (transposed, stride, src, skip, eps, momentum) in enumerate(prog):
+            w, gamma, beta, rmean, rvar = params[5 * i:5 * i + 5]
+            xin = x if src < 0 else ys[src]
+            cout = w.shape[1] if transposed else w.shape[0]
+            raw, parts = conv3d_forward(xin, w, stride, transposed, want_stats=True)
+            b, _, od, oh, ow = raw.shape
+            count = b * od * oh * ow
+            stats = torch.empty((4, cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+            lib.call("mvs_bn_finalize", _p(parts), parts.shape[0], cout, count, _p(gamma), _p(beta), float(eps), float(momentum),
+                     _p(rmean), _p(rvar), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), st)
+            y = torch.empty_like(raw, memory_format=CL3)
+            lib.call("mvs_bn_relu_fwd", _p(raw), _p(stats[2]), _p(stats[3]), _p(ys[skip] if skip >= 0 else None), 1, count, cout,
+                     _p(y), st)
+            ys.append(y)
+            raws.append(raw)
+            statss.append(stats)
+        wp, bp = params[5 * n], params[5 * n + 1]
+        logits, _ = conv3d_forward(ys[-1], wp, 1, False, shift=bp.contiguous())
+        ctx.prog = prog
+        ctx.save_for_backward(x, wp, *[params[5 * i] for i in range(n)], *ys, *raws, *statss)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        prog = ctx.prog
+        n = len(prog)
+        sv = ctx.saved_tensors
+        x, wp = sv[0], sv[1]
+        ws_, ys, raws, statss = sv[2:2 + n], sv[2 + n:2 + 2 * n], sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n]
+        lib = _lib_for(x)
+        st = _stream(x)
+        dev = x.device
+        need = ctx.needs_input_grad          # [x, prog, *params]
+        main = torch.cuda.current_stream(dev) if x.is_cuda else None
+        side_used = [False]
+
+        def wgrad(xin, gout, weight, stride, transposed, wanted):
+            """weight gradient, on the side stream when allowed (joined before this node returns)"""
+            if not wanted:
+                return None
+            use_side = _ASYNC_WGRAD_FUSED and x.is_cuda
+            if use_side and lib.profiler is not None:
+                b, cin, d, h, w = xin.shape
+                cout = weight.shape[1] if transposed else weight.shape[0]
+                use_side = not lib.profiler.wants("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad",
+                                                  _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
+            if not use_side:
+                return conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
+            idx = dev.index
+            side = _SIDE_STREAMS.get(idx)
+            if side is None:
+                side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=dev))
+            side.wait_stream(main)                       # gout was produced on the main stream
+            with torch.cuda.stream(side):
+                gw = conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
+            for ten in (xin, gout):
+                ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
+            gw.record_stream(main)
+            side_used[0] = True
+            return gw
+
+        grads = [None] * (5 * n + 2)
+        g = [None] * n                                   # gradient w.r.t. block outputs, summed over their consumers
+        gx = None
+        # ---- prob layer ----
+        gy = as_cl3(glogits)
+        g[n - 1] = conv3d_dgrad(gy, wp, tuple(ys[-1].shape), 1, False)
+        grads[5 * n] = wgrad(ys[-1], gy, wp, 1, False, need[2 + 5 * n])
+        if need[2 + 5 * n + 1]:
+            grads[5 * n + 1] = gy.sum().reshape(1) if gy.shape[1] == 1 else gy.sum(dim=(0, 2, 3, 4))
+        # ---- blocks, last to first: every consumer of a block's output has run when the block is reached ----
+        for i in range(n - 1, -1, -1):
+            transposed, stride, src, skip, eps, momentum = prog[i]
+            gy = g[i]
+            g[i] = None
+            raw, stats, w = raws[i], statss[i], ws_[i]
+            cout = raw.shape[1]
+            count = raw.numel() // cout
+            wsb = torch.empty(1024 * 2 * cout + 2 * cout, dtype=torch.float32, device=dev)
+            draw = torch.empty_like(raw, memory_format=CL3)
+            dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            lib.call("mvs_bn_relu_bwd", _p(gy), _p(raw), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, count, cout,
+                     _p(wsb), _p(draw), _p(dgb[0]), _p(dgb[1]), st)
+            grads[5 * i + 1], grads[5 * i + 2] = dgb[0], dgb[1]
+            if skip >= 0:                                # y = relu(bn(raw)) + y_skip: the skip source receives gy as it is
+                g[skip] = gy if g[skip] is None else g[skip] + gy
+            xin = x if src < 0 else ys[src]
+            if src >= 0:
+                g[src] = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=g[src])
+            elif need[0]:
+                gx = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=gx)
+            grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
+        if side_used[0]:
+            main.wait_stream(_SIDE_STREAMS[dev.index])   # every weight gradient is complete before autograd sees it
+        return (gx, None) + tuple(grads)
+
+
+def unet_regulariser(x, blocks, prob):
+    """blocks: list of (module-with-.conv/.bn or Sequential(deconv, bn), transposed, stride, src, skip); prob: the bias-only conv.
+    Train-mode fp32 forward of a whole regulariser through UNetRegulariserFn (the modules are parameter containers)."""
+    from . import nn3d
+    prog, params = [], []
+    for conv, bn, transposed, stride, src, skip in blocks:
+        momentum = nn3d._bn_step(bn, True)
+        prog.append((bool(transposed), int(stride), int(src), int(skip), float(bn.eps), float(momentum)))
+        params += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    params += [prob.weight, prob.bias]
+    return UNetRegulariserFn.apply(x, tuple(prog), *params)
 
 
 class BnReLUFn(torch.autograd.Function):

@@ -1097,7 +1097,7 @@ def test_fusion_chain_on_files_vs_oracle(emul_lib, tmp_path):
 
 @pytest.mark.parametrize("cin,cout,dims,slots", [(16, 16, (5, 6, 19), 3), (8, 32, (3, 5, 33), 2), (32, 64, (5, 3, 9), 1)])
 def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
-    """The persistent stride-1 implicit-GEMM kernel (knob conv_persist; default for layers with many tiles): a handful of workgroups
+    """The persistent stride-1 implicit-GEMM kernel (knob conv_persist; not the default: measured slower): a handful of workgroups
     walking several ragged tiles each (boundary tiles, the next tile's halo held in registers across the k-loop, one BatchNorm partial
     row per TILE), forward and input gradient, one and several channel chunks / Cout tiles: BIT-IDENTICAL to the one-tile-per-workgroup
     kernel (same k-order), and equal to ATen within fp32 rounding."""
@@ -1116,7 +1116,7 @@ def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
             gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), 1, False)
             outs[mode] = (y, parts, gx)
     finally:
-        emul_lib.call("mvs_set_tuning", b"conv_persist", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_persist", 0)
         emul_lib.call("mvs_set_tuning", b"conv_small", 1)
     for a, b_ in zip(outs[0], outs[slots]):
         assert torch.equal(a, b_)
@@ -1125,3 +1125,74 @@ def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
     yr.backward(gy)
     assert float((outs[slots][0] - yr).abs().max()) < 2e-4
     assert float((outs[slots][2] - xr.grad).abs().max()) < 5e-4
+
+
+def test_fused_regulariser_node_on_a_small_program(emul_lib):
+    """The one-node regulariser (ops.UNetRegulariserFn) on a three-block U-Net small enough for the default CPU suite -- stride-1
+    conv, stride-2 conv, stride-2 transposed conv with the skip added after its ReLU, bias-only prob layer -- against the per-layer
+    autograd graph built from the same modules: logits, input gradient, parameter gradients, BatchNorm buffers bit-identical."""
+    from mvs_amd import nn3d, ops
+    torch.manual_seed(5)
+
+    def build():
+        torch.manual_seed(5)
+        return torch.nn.ModuleList([nn3d.ConvBnReLU3D(8, 8, stride=1), nn3d.ConvBnReLU3D(8, 16, stride=2), nn3d.DeconvBnReLU3D(16, 8, stride=2),
+                                    nn3d.ProbConv3d(8)]).train()
+    x0 = torch.randn(1, 8, 4, 4, 16)
+    gout = torch.randn(1, 1, 4, 4, 16)
+    res = {}
+    for fused in (True, False):
+        m = build()
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y = ops.unet_regulariser(x, [(m[0].conv, m[0].bn, False, 1, -1, -1), (m[1].conv, m[1].bn, False, 2, 0, -1),
+                                         (m[2][0], m[2][1], True, 2, 1, 0)], m[3])
+        else:
+            y0 = m[0](x)
+            y = m[3](m[2](m[1](y0), skip=y0))
+        y.backward(gout)
+        res[fused] = (y.detach(), x.grad, [p.grad for p in m.parameters()], [b.clone() for b in m.buffers()])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][3], res[False][3]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="3.5 minutes of emulation (64-channel layers); set MVS_EMUL_FULL=1")
+def test_fused_regulariser_node_equals_per_layer_graph(emul_lib):
+    """ops.UNetRegulariserFn (the whole regulariser as one autograd node: skip gradients summed in the dgrad epilogue through
+    mvs_conv3d_dgrad_acc / mvs_convT3d_dgrad_acc, one node on the tape) vs the per-layer graph on the CVP regulariser (stride-1 and
+    stride-2 transposed blocks with skips, shared code with MVSNet's): logits, input gradient, EVERY parameter gradient and the
+    BatchNorm buffers bit-identical; a frozen parameter gets no gradient.  (The goldens run through the fused node by default:
+    test_costregnet_golden / test_costregnet_cvp_golden here with MVS_EMUL_FULL=1, and on the GPU.)"""
+    from mvs_amd import ops
+    from mvs_amd.jdacs_ms.models.network import CostRegNet
+    torch.manual_seed(3)
+    ref = CostRegNet().train()
+    x0 = torch.randn(1, 16, 2, 4, 16)
+    gout = torch.randn(1, 2, 4, 16)
+    res = {}
+    for fused in (True, False):
+        net = CostRegNet().train()
+        net.load_state_dict(ref.state_dict())
+        net.conv2.bn.bias.requires_grad_(False)
+        x = x0.clone().requires_grad_(True)
+        old = ops.FUSED_REGULARISER
+        ops.FUSED_REGULARISER = fused
+        try:
+            y = net(x)
+            y.backward(gout)
+        finally:
+            ops.FUSED_REGULARISER = old
+        res[fused] = (y.detach(), x.grad, {k: p.grad for k, p in net.named_parameters()}, {k: v.clone() for k, v in net.state_dict().items()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in res[True][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.equal(a, b), k
+    assert res[True][2]["conv2.bn.bias"] is None
+    for k in res[True][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
+    assert int(res[True][3]["conv0.bn.num_batches_tracked"]) == 1

@@ -347,3 +347,16 @@ d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'
     grep -E "s1:1x192x128x160|16>16:s1|64>64:s1|32>32:s1" "gpurun_out/bench_c${cfg}_[$t].err" | head -12
   done; done
 fi
+if [ "$what" = "r3d" ]; then
+  # round 3, session D: the fused regulariser node (skip gradients in the dgrad epilogue, async weight gradients by default)
+  MVS_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "golden_costregnet or golden_mvsnet or golden_cvp or config2_train_step or cvp_three_level or fusibile or two_ranks" > gpurun_out/pytest_r3d.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_r3d.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3d.log | tail -8
+  for t in "1" "0"; do
+    MVS_REG_FUSED=$t timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_fused$t.json" 2> "gpurun_out/bench_fused$t.err"
+    echo "bench MVS_REG_FUSED=$t exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), 'other wgrad mode:', d.get('ms_per_step_async_wgrad_off'), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_fused$t.json"
+  done
+  MVS_REG_FUSED=1 timeout 300 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_c3_fused1.json 2> gpurun_out/bench_c3_fused1.err; python -c "
+import json; d=json.load(open('gpurun_out/bench_c3_fused1.json')); print('config 3', round(d['ms_per_step'],3), round(d['value'],1))"
+fi
