@@ -36,6 +36,7 @@ class ConvBnReLU(nn.Module):
     # SURVEY 8(f)-3, first cut: the convolution itself through csrc/conv2d.hip instead of MIOpen.  Parity-tested (CPU
     # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
     hip_conv = os.environ.get("MVS_HIP_FEATURE", "0") == "1"
+    split_bwd = os.environ.get("MVS_SPLIT_CONV2D_BWD", "1") != "0"   # with ops.set_async_wgrad(True): weight gradient of the MIOpen conv on the side stream
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -45,7 +46,14 @@ class ConvBnReLU(nn.Module):
     def forward(self, x, groups=1):
         """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one
         after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
-        y = conv2d_maybe_hip(self.conv, x) if self.hip_conv else self.conv(x)
+        if self.hip_conv:
+            y = conv2d_maybe_hip(self.conv, x)
+        elif (ops._ASYNC_WGRAD and self.split_bwd and x.is_cuda and self.training and torch.is_grad_enabled() and self.conv.bias is None
+              and self.conv.groups == 1 and self.conv.dilation == (1, 1)):
+            # opt-in side-stream weight gradients (ops.set_async_wgrad): the library convolution with its backward issued as two calls
+            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding)
+        else:
+            y = self.conv(x)
         bn = self.bn
         # the BatchNorm kernels serve 4/8/16/32/64 channels and an exponential moving average; anything else (e.g. 12 or 48
         # channels in a user's own ConvBnReLU, or momentum=None = cumulative average) takes the stock modules

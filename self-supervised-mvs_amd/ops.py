@@ -651,6 +651,65 @@ def unet_regulariser(x, blocks, prob):
     return UNetRegulariserFn.apply(x, tuple(prog), *params)
 
 
+class Conv2dSplitBwdFn(torch.autograd.Function):
+    """A bias-free nn.Conv2d of the feature extractor through the LIBRARY's convolution (MIOpen) whose backward is issued as two
+    calls -- input gradient on the main stream, weight gradient on the side stream (when _wgrad side-stream rules allow) -- instead
+    of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        if ctx.needs_input_grad[1]:
+            _note_weight_use(weight)
+        y = torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (list(stride), list(padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.cfg
+        bwd = torch.ops.aten.convolution_backward
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            gw = _maybe_on_side_stream(fn, weight, (x, gy))
+        return gx, gw, None, None
+
+
+def _maybe_on_side_stream(fn, weight, inputs):
+    """Run `fn` (which produces a weight gradient from `inputs`) on the side stream when the per-layer rules of _wgrad_maybe_async
+    allow it (opt-in flag, leaf weight without hooks / existing .grad, single forward use), else inline."""
+    ref = inputs[0]
+    if not (_ASYNC_WGRAD and ref.is_cuda):
+        return fn()
+    idx = ref.device.index
+    main = torch.cuda.current_stream(ref.device)
+    ent = _BWD_OPEN.get(idx)
+    if ent is None:
+        ent = _BWD_OPEN[idx] = [main, False]
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
+    # (any dense layout: the library convolution takes channels-last weights as they are)
+    ok = (weight.is_leaf and weight.grad is None and not getattr(weight, "_backward_hooks", None)
+          and not getattr(weight, "_post_accumulate_grad_hooks", None) and weight.data_ptr() not in _WEIGHT_MULTI.get(idx, ()))
+    _weight_use_done(idx, weight.data_ptr())
+    if not ok:
+        return fn()
+    side = _SIDE_STREAMS.get(idx)
+    if side is None:
+        side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=ref.device))
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for ten in inputs:
+        ten.record_stream(side)
+    out.record_stream(main)
+    ent[1] = True
+    return out
+
+
 class BnReLUFn(torch.autograd.Function):
     """BatchNorm (+ReLU) over the channel dim of a channels-last tensor [B,C,H,W] / [B,C,D,H,W] with the same
     HIP kernels as the 3-D regulariser (statistics partials -> fp64 finalize -> one apply pass; two-pass

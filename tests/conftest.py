@@ -53,7 +53,7 @@ def assert_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=4.0, floor=
         "%s mean err %.3e vs reference fp32 err %.3e" % (what, float(e_ours.mean()), float(e_ref.mean()))
 
 
-def assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=8.0, floor=2e-5, what=""):
+def assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=4.0, floor=2e-5, what=""):
     """Gradient parity criterion of the same kind as the forward one: with an fp64 evaluation of the reference's formulas
     as the truth, the L1 error of every HIP gradient tensor must be of the order of the error the reference's own fp32
     backward makes on it (train-mode BatchNorm over small batches amplifies fp32 rounding, so a blanket relative bound
@@ -62,7 +62,8 @@ def assert_grads_as_accurate_as_fp32_reference(ours, ref32, truth64, slack=8.0, 
         ||ours - t||_1  <=  slack * ||ref32 - t||_1  +  floor * ||t||_1        for every tensor of the dicts,
 
     where the reference's error on a tensor is not taken below its median error over all tensors of the model (a single
-    tensor on which the reference's rounding happened to cancel is no yardstick).  slack = 8 = "same order of magnitude":
+    tensor on which the reference's rounding happened to cancel is no yardstick).  slack = 4 (8 in round 2; the measured worst ratio
+    over every big test of round 3 is 1.92: profiles/r03_grad_error_ratios.jsonl) = "same order of magnitude":
     the yardstick is ONE fp32 evaluation with its own summation order (oneDNN on the CPU for the fixtures, MIOpen / ATen on
     the GPU), and the ratio between two fp32 evaluations of the same gradient scatters by a few x (measured on the MI355X:
     worst ratio 4.5 on the g6 fixture at errors of 1.5e-3 vs 3.4e-4; at BASELINE config 2's full size both fp32 paths are

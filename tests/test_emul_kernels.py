@@ -1095,7 +1095,11 @@ def test_fusion_chain_on_files_vs_oracle(emul_lib, tmp_path):
     assert open(ply, "rb").read() == FO.ply_bytes(exp)
 
 
-@pytest.mark.parametrize("cin,cout,dims,slots", [(16, 16, (5, 6, 19), 3), (8, 32, (3, 5, 33), 2), (32, 64, (5, 3, 9), 1)])
+_full = pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="a non-default kernel: 30 s of emulation per case; set MVS_EMUL_FULL=1")
+
+
+@pytest.mark.parametrize("cin,cout,dims,slots", [(16, 16, (5, 6, 19), 3), pytest.param(8, 32, (3, 5, 33), 2, marks=_full),
+                                                 pytest.param(32, 64, (5, 3, 9), 1, marks=_full)])
 def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
     """The persistent stride-1 implicit-GEMM kernel (knob conv_persist; not the default: measured slower): a handful of workgroups
     walking several ragged tiles each (boundary tiles, the next tile's halo held in registers across the k-loop, one BatchNorm partial

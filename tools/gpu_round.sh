@@ -360,3 +360,21 @@ d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'
   MVS_REG_FUSED=1 timeout 300 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 > gpurun_out/bench_c3_fused1.json 2> gpurun_out/bench_c3_fused1.err; python -c "
 import json; d=json.load(open('gpurun_out/bench_c3_fused1.json')); print('config 3', round(d['ms_per_step'],3), round(d['value'],1))"
 fi
+if [ "$what" = "r3e" ]; then
+  for t in "1" "0" "1" "0"; do
+    MVS_REG_FUSED=$t timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_fused$t.json" 2> "gpurun_out/bench_fused$t.err"
+    echo "bench MVS_REG_FUSED=$t exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), 'other wgrad mode:', d.get('ms_per_step_async_wgrad_off'), {k:round(v['ms'],4) for k,v in d['kernels'].items()})" "gpurun_out/bench_fused$t.json"
+  done
+fi
+if [ "$what" = "r3f" ]; then
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "golden_mvsnet or config2_train_step or two_ranks" > gpurun_out/pytest_r3f.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_r3f.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3f.log | tail -8
+  for t in "1" "0" "1" "0"; do
+    MVS_SPLIT_CONV2D_BWD=$t timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_split$t.json" 2> "gpurun_out/bench_split$t.err"
+    echo "bench MVS_SPLIT_CONV2D_BWD=$t exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), 'other wgrad mode:', d.get('ms_per_step_async_wgrad_off'))" "gpurun_out/bench_split$t.json"
+  done
+fi
