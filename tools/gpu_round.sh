@@ -378,3 +378,8 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), 'other wgrad mode:', d.get('ms_per_step_async_wgrad_off'))" "gpurun_out/bench_split$t.json"
   done
 fi
+if [ "$what" = "r3final_a" ]; then
+  timeout 1700 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error|config-3|worst" gpurun_out/pytest_gpu.log | tail -15
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -2 gpurun_out/smoke.log
+fi
