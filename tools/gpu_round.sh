@@ -383,3 +383,22 @@ if [ "$what" = "r3final_a" ]; then
   echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error|config-3|worst" gpurun_out/pytest_gpu.log | tail -15
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -2 gpurun_out/smoke.log
 fi
+if [ "$what" = "r3final_b" ]; then
+  # round-3 validation, part B: the default bench line (cpu_baseline + reference_gpu_path + PMC), rocprofv3 stats of the timed region,
+  # configs 3 / 4 / 5 with their own PMC roofline
+  timeout 900 python bench.py --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cat gpurun_out/bench.json; grep "ms/step" gpurun_out/bench.err | head -14
+  rm -rf gpurun_out/prof
+  (cd /tmp && MVS_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --stats --selected-regions --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  echo "prof exit $?"
+  mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+  rm -rf gpurun_out/prof
+  f=gpurun_out/prof_keep/trace_kernel_stats.csv; [ -f "$f" ] && head -n 14 "$f" | cut -c1-170
+  for c in 3 4 5; do
+    timeout 500 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --gpu-reference 0 --time-all-kernels > gpurun_out/bench_c$c.json 2> gpurun_out/bench_c$c.err
+    echo "bench config $c exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline'], {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c$c.json
+  done
+fi
