@@ -21,6 +21,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_ROCTX = None
+if os.environ.get("MVS_ROCTX"):
+    # rocprofv3 --selected-regions: rocprofiler-sdk's roctx library has to be in the process before torch brings its own
+    # (older, without roctxProfilerPause / Resume) libroctx64 and before the HIP runtime starts
+    import ctypes
+    for _name in ("/opt/rocm/lib/librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so"):
+        try:
+            _cand = ctypes.CDLL(_name, mode=ctypes.RTLD_GLOBAL)
+            _cand.roctxProfilerPause.argtypes = [ctypes.c_uint64]
+            _cand.roctxProfilerResume.argtypes = [ctypes.c_uint64]
+            _ROCTX = _cand
+            break
+        except (OSError, AttributeError):
+            continue
+    if _ROCTX is None:
+        sys.stderr.write("MVS_ROCTX: no roctx library with roctxProfilerPause / Resume; the whole run is profiled\n")
+
 import torch
 import torch.distributed as dist
 
@@ -122,7 +139,9 @@ def pmc_traffic(cfg, dtype="f32"):
                            cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             shutil.rmtree(tmp, ignore_errors=True)
-            return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            err = r.stderr or r.stdout or ""
+            at = err.rfind("Traceback")
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, err[at:at + 1200] if at >= 0 else err[-600:])
         dirs.append(d)
     summ = summarise(dirs)
     shutil.rmtree(tmp, ignore_errors=True)
@@ -135,8 +154,12 @@ def pmc_traffic(cfg, dtype="f32"):
             if sub in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 out[tag] = {"fetch_bytes": 2.0 * 1024.0 * c["FETCH_SIZE"]["mean"], "write_bytes": 1024.0 * c["WRITE_SIZE"]["mean"],
                             "hip_kernel": name}
-    return out, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py at the --config %d shapes; "
-                 "FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)" % cfg)
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py at the --config %d shapes; "
+            "FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)" % cfg)
+    missing = [t for t in PMC_TAGS.get(cfg, ()) if t not in out and not ((dtype == "f32") == t.endswith("_bf16") and cfg == 5)]
+    if missing:
+        note += "; no counter rows matched %s among %s" % (missing, sorted(n[:60] for n in summ)[:12])
+    return out, note
 
 
 def host_cpu():
@@ -437,15 +460,7 @@ def main():
             sys.stderr.write("hipGraph capture failed (%r); running eager\n" % (e,))
             step = eager_step
             torch.cuda.synchronize()
-    roctx = None
-    if os.environ.get("MVS_ROCTX"):  # rocprofv3 --selected-regions: collect the timed region only (no MIOpen find noise)
-        import ctypes
-        try:
-            roctx = ctypes.CDLL("libroctx64.so")
-            roctx.roctxProfilerPause.argtypes = [ctypes.c_uint64]
-            roctx.roctxProfilerResume.argtypes = [ctypes.c_uint64]
-        except OSError:
-            roctx = None
+    roctx = _ROCTX   # rocprofv3 --selected-regions: collect the timed region only (no MIOpen find noise)
     for _ in range(args.warmup):
         step()
     # live HIP-event timing of the roofline kernels over the timed region, on the launch stream

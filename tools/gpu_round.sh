@@ -402,3 +402,39 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline'], {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c$c.json
   done
 fi
+if [ "$what" = "r3final_c" ]; then
+  MVS_PMC_CONFIG=5 MVS_PMC_DTYPE=bf16 timeout 200 python tools/pmc_driver.py 2>&1 | grep -v Warning | tail -12
+  rm -rf gpurun_out/prof
+  (cd /tmp && MVS_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --stats --selected-regions --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  echo "prof exit $?"; cut -c1-120 gpurun_out/prof_bench.json
+  mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+  rm -rf gpurun_out/prof
+  f=gpurun_out/prof_keep/trace_kernel_stats.csv; [ -f "$f" ] && head -n 14 "$f" | cut -c1-170
+  timeout 500 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline --gpu-reference 0 --time-all-kernels > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
+  echo "bench config 5 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline'])" gpurun_out/bench_c5.json
+fi
+if [ "$what" = "r3final_d" ]; then
+  rm -rf gpurun_out/prof gpurun_out/prof_keep
+  (cd /tmp && MVS_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --stats --selected-regions --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  echo "prof(selected regions) exit $?"; cut -c1-120 gpurun_out/prof_bench.json
+  mkdir -p gpurun_out/prof_keep
+  [ -d gpurun_out/prof ] && find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+  rm -rf gpurun_out/prof
+  if [ ! -f gpurun_out/prof_keep/trace_kernel_stats.csv ]; then
+    echo "selected regions recorded nothing: whole run, 100 steps"
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+        python "$OLDPWD/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+    echo "prof(whole run) exit $?"; cut -c1-120 gpurun_out/prof_bench.json
+    find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+    rm -rf gpurun_out/prof
+  fi
+  f=gpurun_out/prof_keep/trace_kernel_stats.csv; [ -f "$f" ] && head -n 16 "$f" | cut -c1-170
+  timeout 500 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline --gpu-reference 0 --time-all-kernels > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
+  echo "bench config 5 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline'], {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c5.json
+fi

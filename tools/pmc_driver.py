@@ -49,8 +49,8 @@ for _ in range(3):
         continue
     with torch.no_grad():
         v = var.detach()
-        lib = ops._lib_for(v)
         if CFG in (2, 3):
+            lib = ops._lib_for(v)
             w0 = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.05).to(dev)
             if os.environ.get("MVS_PMC_VARIANTS"):   # A/B of the Cout==8 kernel forms / tile orders (per-dispatch order in the summary)
                 for k8, xcd in ((1, 0), (1, 1), (7, 0), (7, 1)):
