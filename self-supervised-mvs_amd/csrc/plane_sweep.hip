@@ -98,10 +98,13 @@ template <int C, int CPT> struct TileC {
 // views at 4 channels per lane (8 lanes per pixel: the values travel by ds_bpermute_b32 instead of a DPP move).
 // BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns CPT
 // CONSECUTIVE channels so that its values are one 16- (8-) byte store and the lanes of a pixel write one 64-byte segment.
-// DL (per-plane hypotheses only): the slab's depths are staged in LDS once and read back one plane ahead, and the taps of a
-// re-gather are waited for INSIDE the re-gather block.  Without it the plane loop starts with a vmcnt(0) (the depth is a vector
-// load) that also waits for the previous plane's stores -- on gfx9 stores and loads share the counter -- and every plane pays a
-// second vmcnt(0) at the join after the re-gather blocks whether or not a lane re-gathered.
+// DL (per-plane hypotheses only): the slab's depths are staged in LDS once and read back one plane ahead.  DL == 2 is the MERGED
+// form: a plane first walks all views (projection, block test, re-gather loads issued), then samples all views -- the taps of
+// every view that left its block are in flight together, one memory round trip per plane instead of one per such view (the
+// plain form consumes view s's taps right after requesting them: up to NS_T sequential round trips).  Same arithmetic, same order.
+// (An earlier DL == 2, waiting for the taps INSIDE the re-gather block, measured slower and is gone.)  Without DL the plane loop
+// starts with a vmcnt(0) (the depth is a vector load) that also waits for the previous plane's stores -- on gfx9 stores and loads
+// share the counter.
 template <int C, int NS_T, int CPT, bool QS = false, bool BF = false, int DL = 0>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
@@ -111,9 +114,10 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     const int TW = a.tile_w, TH = PPB / TW;
     const int tid = threadIdx.x;
     const int q = tid % LPP, pl = tid / LPP;
-    const int xr = (blockIdx.x % a.tiles_x) * TW + pl % TW, yr = (blockIdx.x / a.tiles_x) * TH + pl / TW;
-    const int b = blockIdx.z;
-    const int d0 = blockIdx.y * a.dslab;
+    const SweepWg wg = sweep_wg(a);
+    const int xr = (wg.tile % a.tiles_x) * TW + pl % TW, yr = (wg.tile / a.tiles_x) * TH + pl / TW;
+    const int b = wg.b;
+    const int d0 = wg.slab * a.dslab;
     const int d1 = min(a.D, d0 + a.dslab);
     __shared__ float s_dep[DL ? 512 : 1];            // DL: the launcher keeps a slab <= 512 planes
     if constexpr (DL != 0) {
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
             own_wx = ix - fx; own_wy = iy - fy;
             own_x0 = MVS_F2I(fx); own_y0 = MVS_F2I(fy);
         }
+        float wxs[DL == 2 ? NS_T : 1], wys[DL == 2 ? NS_T : 1];
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
             float wx, wy;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 // weights, i.e. NaN out like ATen), so no float clamp is needed before the conversion
                 x0 = MVS_F2I(fx); y0 = MVS_F2I(fy);
             }
+            if constexpr (DL == 2) { wxs[s] = wx; wys[s] = wy; }
             const float ex = 1.0f - wx, ey = 1.0f - wy;
             if (x0 != cx[s] || y0 != cy[s]) {
                 cx[s] = x0; cy[s] = y0;
@@ -226,26 +232,15 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
                 const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (DL == 2 && xin0 && xin1 && yin0 && yin1) {   // common case: the four loads back to back, no selects
 #pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        t00[s][k] = ld4(f + ck * k); t01[s][k] = ld4(f + C + ck * k);
-                        t10[s][k] = ld4(f + a.W * C + ck * k); t11[s][k] = ld4(f + a.W * C + C + ck * k);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
-                        t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
-                        t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
-                        t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
-                    }
-                }
-                if constexpr (DL == 2) {
-#pragma unroll
-                    for (int k = 0; k < V; ++k) { MVS_PIN4(t00[s][k]); MVS_PIN4(t01[s][k]); MVS_PIN4(t10[s][k]); MVS_PIN4(t11[s][k]); }
+                for (int k = 0; k < V; ++k) {
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
                 }
             }
+            if constexpr (DL == 2) continue;   // merged form: every view's re-gather is in flight before the first sample (below)
             const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -257,6 +252,26 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
                 Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
                 Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
+            }
+        }
+        if constexpr (DL == 2) {
+            // second phase of the merged form: the samples, in the same order and with the same arithmetic as above
+#pragma unroll
+            for (int s = 0; s < NS_T; ++s) {
+                const float wx = wxs[s], wy = wys[s];
+                const float ex = 1.0f - wx, ey = 1.0f - wy;
+                const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float4 v;
+                    v.x = fmaf(t11[s][k].x, w11, fmaf(t10[s][k].x, w10, fmaf(t01[s][k].x, w01, t00[s][k].x * w00)));
+                    v.y = fmaf(t11[s][k].y, w11, fmaf(t10[s][k].y, w10, fmaf(t01[s][k].y, w01, t00[s][k].y * w00)));
+                    v.z = fmaf(t11[s][k].z, w11, fmaf(t10[s][k].z, w10, fmaf(t01[s][k].z, w01, t00[s][k].z * w00)));
+                    v.w = fmaf(t11[s][k].w, w11, fmaf(t10[s][k].w, w10, fmaf(t01[s][k].w, w01, t00[s][k].w * w00)));
+                    S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
+                    Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
+                    Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
+                }
             }
         }
         const size_t oidx = (((size_t)b * a.D + d) * HW + pix) * C + cq;
@@ -841,9 +856,10 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     __shared__ float s_dep[4][64];                   // per wave: the per-plane depth hypotheses of 64 planes of the segment
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int q = lane % LPP, pl = lane / LPP;
-    const int bx0 = (blockIdx.x % a.tiles_x) * (2 * BW) + (wv & 1) * BW, by0 = (blockIdx.x / a.tiles_x) * (2 * BH) + (wv >> 1) * BH;
+    const SweepWg wg = sweep_wg(a);
+    const int bx0 = (wg.tile % a.tiles_x) * (2 * BW) + (wv & 1) * BW, by0 = (wg.tile / a.tiles_x) * (2 * BH) + (wv >> 1) * BH;
     const int xr = bx0 + pl % BW, yr = by0 + pl / BW;
-    const int b = blockIdx.z;
+    const int b = wg.b;
     const bool live = xr < a.W && yr < a.H;          // lanes outside the image follow along (wave-wide exchanges) on a clamped pixel
     const int x = min(xr, a.W - 1), y = min(yr, a.H - 1);
     const int HW = a.H * a.W, pix = y * a.W + x;
@@ -875,7 +891,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     float* const wwin = lds + (size_t)wv * NS_T * VIEW_FLOATS;     // this wave's windows
 #define z4 (make_float4(0.f, 0.f, 0.f, 0.f))   /* a literal: a const object captured by the lambdas below lives in scratch */
 
-    int ds = blockIdx.y * a.dslab;
+    int ds = wg.slab * a.dslab;
     const int dend = min(a.D, ds + a.dslab);
     while (ds < dend) {
         // ---- segment [ds, de): the longest one for which every wave's windows fit (workgroup-uniform) ----
@@ -1291,6 +1307,7 @@ static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows 
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
 static int g_sweep_fwd_qs = 0;        // knob "fwd_qs": 1 = one projection per (pixel, view) shared by the pixel's channel lanes (C = 32; 2-4 views: quad DPP, 6 views: ds_bpermute); also selected by sweep_fwd = 6
+static int g_sweep_xcd = 0;           // knob "sweep_xcd": XCD-compact workgroup order of the cached forward and the per-wave-window backward
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 int g_sweep_bwd_nowin = 0;            // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
@@ -1305,7 +1322,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"fs", &g_conv_fs, 0, 1}, {"conv_persist", &g_conv_persist, 0, 4096},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
         {"xcd", &g_conv_xcd, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 2}, {"bwd_cpl", &g_sweep_bwd_cpl, 1, 4}, {"bwd_wf", &g_sweep_bwd_wf, 1024, 8192}, {"bwd_pd", &g_sweep_bwd_pd, 0, 16},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"fwd_qs", &g_sweep_fwd_qs, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1}, {"fwd_qs", &g_sweep_fwd_qs, 0, 1},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1323,6 +1340,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     const int variant = sweep_fwd_variant();
     a.nt_store = g_sweep_nt;
+    a.xcd = g_sweep_xcd;
     if (g_sweep_dslab > 0) a.dslab = g_sweep_dslab;
     if (!a.warp_only && variant >= 2 && (a.NS <= 4 || a.NS == 6) && !(variant == 4 && a.NS > 2)) {
         constexpr int CPT8 = C >= 16 ? 8 : 4;
@@ -1368,6 +1386,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     case N:                                                                                                                    \
         if (qsb && N >= 2 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 1>), gridb, block, 0, st, a); \
         else if (qsb && N >= 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 0>), gridb, block, 0, st, a); \
+        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 2>), gridb, block, 0, st, a); \
         else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 1>), gridb, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 0>), gridb, block, 0, st, a);         \
         break;
@@ -1390,6 +1409,7 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 2>), gridc, block, 0, st, a); \
         else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 1>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
+        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, false, 2>), gridc, block, 0, st, a); \
         else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, false, 1>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;
@@ -1440,6 +1460,7 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     if (nslab < 1) nslab = 1;
     a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
     a.no_window = g_sweep_bwd_nowin;
+    a.xcd = g_sweep_xcd;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     if (a.warp_only) {
         if constexpr (NS_T == 1) MVS_LAUNCH((plane_sweep_variance_bwd_pw_kernel<C, 1, CPT, 2, GD, WPS, false, PFL>), grid, block, 0, st, a);

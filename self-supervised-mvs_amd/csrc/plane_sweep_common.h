@@ -23,7 +23,25 @@ struct SweepArgs {
     int no_window;   // test knob "bwd_nowin": per-wave-window backward sends every flush down its global-atomic path
     int bf16_out;    // forward: the volume is stored in bf16 (inference path)
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
+    int xcd;         // knob "sweep_xcd": XCD-compact workgroup order (sweep_wg below)
 };
+
+// Workgroup -> (pixel tile, depth slab, batch).  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
+// with its own 4 MB L2: with the plain blockIdx decoding every XCD walks the WHOLE image (every 8th tile) and its L2 has to hold
+// the source footprints of a full-width band of all views.  With a.xcd the ids are re-dealt so that XCD k owns one contiguous
+// eighth of the (batch, slab, tile) sequence: the workgroups resident on an XCD at any time are neighbouring tiles, whose taps
+// share texels.  A bijection for any grid size (XCD x owns T/8 ids, the first T%8 XCDs one more).
+struct SweepWg { int tile, slab, b; };
+__device__ __forceinline__ SweepWg sweep_wg(const SweepArgs& a) {
+    SweepWg w;
+    if (!a.xcd) { w.tile = blockIdx.x; w.slab = blockIdx.y; w.b = blockIdx.z; return w; }
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned per = total >> 3, rem = total & 7u, x = lin & 7u, i = lin >> 3;
+    const unsigned nw = (x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per) + i;
+    w.tile = (int)(nw % nx); w.slab = (int)((nw / nx) % ny); w.b = (int)(nw / (nx * ny));
+    return w;
+}
 
 struct Taps {
     float w00, w01, w10, w11;   // nw, ne, sw, se weights

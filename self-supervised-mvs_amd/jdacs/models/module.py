@@ -17,15 +17,18 @@ from ...nn3d import ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, count_batch  # noq
 ALIGN_CORNERS = False  # what the reference's F.grid_sample call does on torch >= 1.3
 
 
-def conv2d_maybe_hip(conv: nn.Conv2d, x):
-    """nn.Conv2d through csrc/conv2d.hip when it is one of the feature extractors' shapes (3x3 s1 p1 or 5x5 s2 p2, <= 32 or
-    exactly 64 channels, fp32 on the GPU); the stock module otherwise."""
+def hip_conv2d_serves(conv: nn.Conv2d, x) -> bool:
+    """csrc/conv2d.hip serves the feature extractors' shapes: 3x3 s1 p1 or 5x5 s2 p2, <= 32 or exactly 64 channels, fp32 on the GPU."""
     k, s, p = conv.kernel_size, conv.stride, conv.padding
     wide = lambda c: c <= 32 or c == 64
-    ok = (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and conv.dilation == (1, 1)
-          and wide(conv.in_channels) and wide(conv.out_channels) and (k == (3, 3) or max(conv.in_channels, conv.out_channels) <= 32)
-          and ((k, s, p) == ((3, 3), (1, 1), (1, 1)) or (k, s, p) == ((5, 5), (2, 2), (2, 2))))
-    return ops.Conv2dFn.apply(x, conv.weight, conv.bias, s[0]) if ok else conv(x)
+    return (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and conv.dilation == (1, 1)
+            and wide(conv.in_channels) and wide(conv.out_channels) and (k == (3, 3) or max(conv.in_channels, conv.out_channels) <= 32)
+            and ((k, s, p) == ((3, 3), (1, 1), (1, 1)) or (k, s, p) == ((5, 5), (2, 2), (2, 2))))
+
+
+def conv2d_maybe_hip(conv: nn.Conv2d, x):
+    """nn.Conv2d through csrc/conv2d.hip when it is one of the feature extractors' shapes; the stock module otherwise."""
+    return ops.Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride[0]) if hip_conv2d_serves(conv, x) else conv(x)
 
 
 class ConvBnReLU(nn.Module):
@@ -37,6 +40,10 @@ class ConvBnReLU(nn.Module):
     # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
     hip_conv = os.environ.get("MVS_HIP_FEATURE", "0") == "1"
     split_bwd = os.environ.get("MVS_SPLIT_CONV2D_BWD", "1") != "0"   # with ops.set_async_wgrad(True): weight gradient of the MIOpen conv on the side stream
+    # Inference (eval mode, no autograd): BatchNorm's running statistics folded into the convolution's weights and bias, ReLU in
+    # the same csrc/conv2d.hip pass -- no separate normalisation pass over the activation (jdacs/eval.py:143 runs the model
+    # in eval mode under no_grad).  MVS_FOLD_EVAL_BN=0 keeps convolution and BatchNorm apart.
+    fold_eval = os.environ.get("MVS_FOLD_EVAL_BN", "1") != "0"
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -46,6 +53,10 @@ class ConvBnReLU(nn.Module):
     def forward(self, x, groups=1):
         """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one
         after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
+        if (self.fold_eval and not self.training and not torch.is_grad_enabled() and self.bn.track_running_stats
+                and self.bn.running_mean is not None and self.bn.affine and hip_conv2d_serves(self.conv, x)):
+            w, b = self._folded()
+            return ops.conv2d_forward(x, w, b, self.conv.stride[0], negative_slope=0.0)
         if self.hip_conv:
             y = conv2d_maybe_hip(self.conv, x)
         elif (ops._ASYNC_WGRAD and self.split_bwd and x.is_cuda and self.training and torch.is_grad_enabled() and self.conv.bias is None
@@ -67,6 +78,30 @@ class ConvBnReLU(nn.Module):
         if groups > 1:
             return torch.cat([F.relu(bn(c)) for c in y.chunk(groups, 0)], 0)
         return F.relu(bn(y), inplace=True)
+
+
+def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(w', b') with  conv(x, w') + b' == bn_eval(conv(x, w) + bias)."""
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    if conv.bias is not None:
+        shift = shift + conv.bias * scale
+    return (conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), shift.contiguous()
+
+
+def _folded(self):
+    # recomputed only when one of the five tensors changed (in-place updates bump ._version; load_state_dict copies in place)
+    srcs = (self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in srcs) + (self.bn.eps, None if self.conv.bias is None else self.conv.bias._version)
+    cache = self.__dict__.get("_fold_cache")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            cache = (key, _fold_bn(self.conv, self.bn))
+        self.__dict__["_fold_cache"] = cache
+    return cache[1]
+
+
+ConvBnReLU._folded = _folded
 
 
 def homo_warping(src_fea, src_proj, ref_proj, depth_values, align_corners=None):

@@ -36,7 +36,9 @@ class FeatureNet(nn.Module):
         """groups: number of views stacked along the batch dim (per-view BatchNorm statistics are kept)."""
         for name, *_ in _FEATURE_LAYERS:
             x = getattr(self, name)(x, groups)
-        return conv2d_maybe_hip(self.feature, x) if ConvBnReLU.hip_conv else self.feature(x)
+        # inference: the closing convolution through csrc/conv2d.hip like the folded blocks before it
+        hip = ConvBnReLU.hip_conv or (ConvBnReLU.fold_eval and not self.training and not torch.is_grad_enabled())
+        return conv2d_maybe_hip(self.feature, x) if hip else self.feature(x)
 
 
 class CostRegNet(nn.Module):

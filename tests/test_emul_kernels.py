@@ -1200,3 +1200,62 @@ def test_fused_regulariser_node_equals_per_layer_graph(emul_lib):
     for k in res[True][3]:
         assert torch.equal(res[True][3][k], res[False][3][k]), k
     assert int(res[True][3]["conv0.bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("ns,hw,d", [(2, (13, 21), 9), (4, (10, 19), 20), (6, (7, 19), 11)])
+def test_plane_sweep_xcd_compact_order_and_merged_regather(emul_lib, ns, hw, d):
+    """Knob sweep_xcd (workgroup ids re-dealt so that each XCD owns a contiguous run of tiles: a bijection for grid sizes that are
+    not multiples of 8, here with 2 batch entries and several depth slabs) and fwd_dl=2 (merged re-gather phase): forward (fp32 and
+    bf16 volume) and backward bit-identical to the default order / loop."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(77 + ns)
+    b, c = 2, 32
+    h, w = hw
+    rot, trans = _cams(b, ns, h, w, g)
+    trans = trans * torch.tensor([3.0, -2.0, 1.0])
+    ref = torch.randn(b, c, h, w, generator=g)
+    srcs = [torch.randn(b, c, h, w, generator=g) for _ in range(ns)]
+    depth = (430 + 21.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
+    gvar = torch.randn(b, c, d, h, w, generator=g)
+    res = {}
+    try:
+        for key, knobs in (("base", {}), ("xcd", {b"sweep_xcd": 1}), ("merged", {b"fwd_dl": 2}), ("both", {b"sweep_xcd": 1, b"fwd_dl": 2})):
+            emul_lib.call("mvs_set_tuning", b"sweep_xcd", knobs.get(b"sweep_xcd", 0))
+            emul_lib.call("mvs_set_tuning", b"fwd_dl", knobs.get(b"fwd_dl", 1))
+            emul_lib.call("mvs_set_tuning", b"dslab", 4)        # several slabs per tile: the slab index goes through the re-deal too
+            emul_lib.call("mvs_set_tuning", b"bwd_dslab", 4)
+            fr = [t.clone().requires_grad_(True) for t in [ref] + srcs]
+            var = ops.plane_sweep_variance(fr[0], fr[1:], rot, trans, depth)
+            grads = torch.autograd.grad(var, fr, gvar)
+            with torch.no_grad():
+                v16 = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, out_dtype=torch.bfloat16)
+            res[key] = (var.detach(), v16, grads)
+    finally:
+        for k, v in ((b"sweep_xcd", 0), (b"fwd_dl", 1), (b"dslab", 0), (b"bwd_dslab", 0)):
+            emul_lib.call("mvs_set_tuning", k, v)
+    for key in ("xcd", "merged", "both"):
+        assert torch.equal(res[key][0], res["base"][0]), key
+        assert torch.equal(res[key][1], res["base"][1]), key
+        for ga, gb in zip(res[key][2], res["base"][2]):
+            # the backward's atomics land in a different order under sweep_xcd: equal up to fp32 summation order
+            assert float((ga - gb).abs().max()) <= 1e-4 * max(1.0, float(gb.abs().max())), key
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (9, 21)), (8, 16, 5, 2, (11, 22)), (16, 32, 5, 2, (9, 14)), (32, 32, 3, 1, (6, 13))])
+def test_conv2d_folded_batchnorm_relu_eval(emul_lib, cin, cout, ks, stride, hw):
+    """Inference form of ConvBnReLU (module.py:15-22 in eval mode): BatchNorm's running statistics folded into weights + bias
+    (module._fold_bn), ReLU as LeakyReLU(0) in the same csrc/conv2d.hip pass -- vs conv2d -> batch_norm(eval) -> relu of ATen."""
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.module import ConvBnReLU, _fold_bn
+    torch.manual_seed(cin + cout)
+    m = ConvBnReLU(cin, cout, ks, stride, ks // 2).eval()
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.3); m.bn.running_var.uniform_(0.5, 2.0)
+        m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.normal_(0, 0.2)
+        x = torch.randn(2, cin, *hw).contiguous(memory_format=torch.channels_last)
+        exp = F.relu(m.bn(m.conv(x)))
+        w, b = _fold_bn(m.conv, m.bn)
+        got = ops.conv2d_forward(x, w, b, stride, negative_slope=0.0)
+    assert got.shape == exp.shape
+    assert float((got - exp).abs().max()) < 2e-5 * max(1.0, float(exp.abs().max()))
+    assert float(got.min()) >= 0.0

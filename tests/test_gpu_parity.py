@@ -957,6 +957,40 @@ def test_featurenet_hip_convs_vs_stock(dev):
         assert rel_l1(p.grad, q.grad) < 3e-2, k
 
 
+def test_featurenet_eval_folded_batchnorm_vs_stock(dev):
+    """Inference FeatureNet (eval mode, no_grad): BatchNorm folded into the csrc/conv2d.hip convolutions (ConvBnReLU.fold_eval,
+    the default) vs the unfolded path (MIOpen convolution + BatchNorm kernel) and vs the oracle's stock modules, 3 views 128x160
+    with non-trivial running statistics."""
+    import copy
+    from mvs_amd.jdacs.models import module as MM
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(5)
+    net = FeatureNet().to(dev)
+    x = torch.randn(3, 3, 128, 160, device=dev)
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):
+            net(x * (1.0 + 0.1 * torch.randn(1, device=dev)), 3)      # moves the running statistics away from (0, 1)
+    net.eval()
+    old = MM.ConvBnReLU.fold_eval
+    try:
+        with torch.no_grad():
+            MM.ConvBnReLU.fold_eval = False
+            y0 = net(x, 3)
+            MM.ConvBnReLU.fold_eval = True
+            y1 = net(x, 3)
+    finally:
+        MM.ConvBnReLU.fold_eval = old
+    ref = R.OracleFeatureNet()
+    ref.load_state_dict(copy.deepcopy(net.state_dict()))
+    ref.eval()
+    with torch.no_grad():
+        yr = ref(x.cpu())
+    scale = float(yr.abs().max())
+    assert float((y1 - y0).abs().max()) < 2e-5 * scale
+    assert float((y1.cpu() - yr).abs().max()) < 1e-4 * scale
+
+
 @pytest.mark.parametrize("ns,hw", [(2, (61, 83)), (4, (32, 40))])
 def test_plane_sweep_fwd_quad_shared_projection(dev, ns, hw):
     """Forward variant 6 (per-view projection computed once per pixel quad, quad-broadcast DPP moves; not the default) must be

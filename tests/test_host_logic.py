@@ -388,3 +388,26 @@ def test_fusibile_oracle_fuses_a_consistent_scene_onto_its_surface():
     assert ply == DF.ply_bytes(allp)
     head, _, body = ply.partition(b"end_header\n")
     assert b"element vertex %d\n" % allp.shape[0] in head and len(body) == 15 * allp.shape[0]
+
+
+def test_folded_eval_batchnorm_cache_follows_parameter_updates():
+    """ConvBnReLU._folded (inference: BatchNorm folded into the convolution): the cached (w', b') is rebuilt after in-place updates of
+    any of its five source tensors (optimizer step, load_state_dict) and conv(x, w') + b' equals the eval-mode block before ReLU."""
+    import torch.nn.functional as F
+    from mvs_amd.jdacs.models.module import ConvBnReLU
+    torch.manual_seed(3)
+    m = ConvBnReLU(4, 8).eval()
+    x = torch.randn(1, 4, 6, 7)
+    with torch.no_grad():
+        w1, b1 = m._folded()
+        assert m._folded()[0] is w1                      # cached
+        assert float((F.conv2d(x, w1, b1, padding=1) - m.bn(m.conv(x))).abs().max()) < 1e-5
+        m.bn.running_mean.add_(0.5)
+        m.conv.weight.mul_(1.5)
+        w2, b2 = m._folded()
+        assert w2 is not w1
+        assert float((F.conv2d(x, w2, b2, padding=1) - m.bn(m.conv(x))).abs().max()) < 1e-5
+        sd = {k: v.clone() + 0.1 for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+        m.load_state_dict(sd, strict=False)
+        w3, b3 = m._folded()
+        assert float((F.conv2d(x, w3, b3, padding=1) - m.bn(m.conv(x))).abs().max()) < 1e-5

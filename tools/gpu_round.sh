@@ -438,3 +438,28 @@ if [ "$what" = "r3final_d" ]; then
 import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['roofline'], {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c5.json
 fi
+if [ "$what" = "r3g" ]; then
+  # round 3: XCD-compact workgroup order of the sweep kernels (sweep_xcd) and the merged re-gather forward (fwd_dl=2)
+  MVS_SKIP_HEAVY=1 timeout 400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "sweep or homo_warp or golden_mvsnet" > gpurun_out/pytest_r3g.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3g.log | tail -5
+  for cfg in 5 3 2 4; do for t in "sweep_xcd=0" "sweep_xcd=1" "fwd_dl=2" "sweep_xcd=1,fwd_dl=2"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "gpurun_out/bench_c${cfg}_[$t].json" 2> "gpurun_out/bench_c${cfg}_[$t].err"
+    echo "bench config $cfg [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:round(v['ms'],4) for k,v in d['kernels'].items() if 'sweep' in k})" "gpurun_out/bench_c${cfg}_[$t].json"
+  done; done
+fi
+if [ "$what" = "r3h" ]; then
+  # round 3: inference FeatureNet with BatchNorm folded into the csrc/conv2d.hip convolutions
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "featurenet or config1_eval or config5_shape or bf16_inference or refinenet or golden_mvsnet or geo" > gpurun_out/pytest_r3h.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3h.log | tail -8
+  for cfg in 5; do for f in 0 1; do
+    MVS_FOLD_EVAL_BN=$f timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c${cfg}_fold$f.json" 2> "gpurun_out/bench_c${cfg}_fold$f.err"
+    echo "bench config $cfg fold=$f exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c${cfg}_fold$f.json"; grep "ms/step" "gpurun_out/bench_c${cfg}_fold$f.err" | head -24
+  done; done
+  MVS_FOLD_EVAL_BN=1 timeout 300 python bench.py --config 5 --dtype f32 --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_c5_f32_fold1.json 2>/dev/null; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print('f32', round(d['ms_per_step'],3), round(d['value'],1))" gpurun_out/bench_c5_f32_fold1.json
+fi
