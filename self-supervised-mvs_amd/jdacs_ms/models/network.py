@@ -86,6 +86,8 @@ class CostRegNet(nn.Module):
 
 
 class CVPMVSNet(nn.Module):
+    batch_views = os.environ.get("MVS_CVP_BATCH_VIEWS", "1") != "0"   # feature pyramid of all views in one batch
+
     def __init__(self, args, align_corners=ALIGN_CORNERS):
         super().__init__()
         self.featurePyramid = FeaturePyramid()
@@ -97,8 +99,16 @@ class CVPMVSNet(nn.Module):
         a = self.args
         depth_est_list = []
         # feature pyramids (stock PyTorch)
-        ref_fp = self.featurePyramid(ref_img, a.nscale)
-        src_fps = [self.featurePyramid(src_imgs[:, i], a.nscale) for i in range(a.nsrc)]
+        if self.batch_views:
+            # the pyramid has no batch statistics: all views as ONE batch (per-sample results are the same launches' tiles), so
+            # the small pyramid levels fill the chip (a 216x288 level of one view is 243 workgroups on 256 CUs)
+            nb = ref_img.shape[0]
+            fps = self.featurePyramid(torch.cat([ref_img] + [src_imgs[:, i] for i in range(a.nsrc)], 0), a.nscale)
+            ref_fp = [f[:nb] for f in fps]
+            src_fps = [[f[(i + 1) * nb:(i + 2) * nb] for f in fps] for i in range(a.nsrc)]
+        else:   # network.py:100-105: one pyramid call per view
+            ref_fp = self.featurePyramid(ref_img, a.nscale)
+            src_fps = [self.featurePyramid(src_imgs[:, i], a.nscale) for i in range(a.nsrc)]
         ref_in_ms = conditionIntrinsics(ref_in, ref_img.shape, [f.shape for f in ref_fp])
         src_in_ms = torch.stack([conditionIntrinsics(src_in[:, i], ref_img.shape, [f.shape for f in src_fps[i]])
                                  for i in range(a.nsrc)]).permute(1, 0, 2, 3, 4)

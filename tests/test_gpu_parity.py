@@ -686,6 +686,15 @@ def test_golden_cvpmvsnet_end_to_end(dev):
     assert rel_l1(out["depth_est_list"][1].cpu(), g["depth1"]) < 1e-3
     assert rel_l1(out["depth_est_list"][0].cpu(), g["depth0"]) < 1e-3
     assert float((out["prob_confidence"].cpu() - g["conf"]).abs().mean()) < 5e-3
+    # the pyramid of all views as one batch (default) == one call per view (network.py:100-105), bit for bit
+    try:
+        CVPMVSNet.batch_views = False
+        with torch.no_grad():
+            out1 = net(t["ref_img"], t["src_imgs"], t["ref_in"], t["src_in"], t["ref_ex"], t["src_ex"], t["depth_min"], t["depth_max"])
+    finally:
+        CVPMVSNet.batch_views = True
+    for da, db in zip(out["depth_est_list"], out1["depth_est_list"]):
+        assert torch.equal(da, db)
 
 
 @pytest.mark.parametrize("ih,iw,with_grad", [(128, 160, True), pytest.param(864, 1152, False, marks=_heavy)])

@@ -463,3 +463,26 @@ d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'
 import json,sys
 d=json.load(open(sys.argv[1])); print('f32', round(d['ms_per_step'],3), round(d['value'],1))" gpurun_out/bench_c5_f32_fold1.json
 fi
+if [ "$what" = "r3i" ]; then
+  # round 3: CVP pyramid with all views as one batch; SQ counters of the bf16 conv0 at config 5
+  MVS_SKIP_HEAVY=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "cvp" > gpurun_out/pytest_r3i.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3i.log | tail -5
+  for f in 0 1; do
+    MVS_CVP_BATCH_VIEWS=$f timeout 300 python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c4_batch$f.json" 2> "gpurun_out/bench_c4_batch$f.err"
+    echo "bench config 4 batch_views=$f exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c4_batch$f.json"; grep "fwd2d" "gpurun_out/bench_c4_batch$f.err" | head -12
+  done
+  export MVS_PMC_CONFIG=5 MVS_PMC_DTYPE=bf16; bash tools/gpu_round.sh sq 2>&1 | grep "conv_bf16"
+fi
+if [ "$what" = "r3j" ]; then
+  # round 3: BatchNorm reductions finished by their last workgroup (no separate finalize launches)
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "bn or batchnorm or golden or featurenet or conv_bn or regulariser or two_rank or train_step" > gpurun_out/pytest_r3j.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3j.log | tail -8
+  for cfg in 2 3; do
+    timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c${cfg}_bnfin.json" 2> "gpurun_out/bench_c${cfg}_bnfin.err"
+    echo "bench config $cfg exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d.get('ms_per_step_async_wgrad_off'))" "gpurun_out/bench_c${cfg}_bnfin.json"; grep "mvs_bn" "gpurun_out/bench_c${cfg}_bnfin.err" | head -8
+  done
+fi
