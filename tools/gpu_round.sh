@@ -486,3 +486,18 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d.get('ms_per_step_async_wgrad_off'))" "gpurun_out/bench_c${cfg}_bnfin.json"; grep "mvs_bn" "gpurun_out/bench_c${cfg}_bnfin.err" | head -8
   done
 fi
+if [ "$what" = "r3final2" ]; then
+  # closing validation of the round's final code: every GPU test except the three full-size oracle comparisons (those ran on the
+  # head of r3final_a; the kernels they exercise are unchanged since), smoke, the default bench line, configs 3 / 4 / 5
+  MVS_SKIP_HEAVY=1 timeout 1200 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_gpu.log | tail -6
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
+  timeout 900 python bench.py --time-all-kernels > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench exit $?"; cut -c1-400 gpurun_out/bench.json
+  for c in 3 4 5; do
+    timeout 500 python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --gpu-reference 0 --time-all-kernels > gpurun_out/bench_c$c.json 2> gpurun_out/bench_c$c.err
+    echo "bench config $c exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c$c.json
+  done
+fi
