@@ -15,6 +15,11 @@
 #include "mvs_rt.h"
 #include "conv_map.h"
 
+// tuning knob "cout1_d4": the Cout = 1 layer with four outputs per thread -- bit 0: the fp32 forward and input gradient
+// (measured, profiles/r03_run16_*: forward 0.089 -> 0.091 ms, 16 channels 0.331 -> 0.473, input gradient 0.083 -> 0.107: the
+// smaller LDS traffic does not pay for 1-2 waves per SIMD -- off), bit 1: the bf16 inference forward (0.426 -> 0.368 ms -- on)
+int g_conv_cout1_d4 = 2;
+
 extern int g_conv_split, g_conv_small, g_conv_small_wgs, g_conv_tr2pw;
 
 struct ConvArgs {
@@ -619,6 +624,64 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
         *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
 }
 
+// The same with a column of FOUR depth slices per thread (knob "cout1_d4"): each of the 6 x 9 input values under the column is
+// loaded once and feeds up to three outputs; the 27 taps are unrolled, the bounds tests are three small per-axis tables instead of
+// six compares per tap, and the weights are read at compile-time offsets of a kernel-argument pointer (scalar loads, SGPR operands
+// of the FMAs) instead of two LDS reads per tap.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_cin1_d4_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                           float* __restrict__ y, int B, int D, int H, int W) {
+    const int D4 = (D + 3) / 4;
+    const size_t total = (size_t)B * D4 * H * W;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= total) return;
+    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), dq = (int)((v / ((size_t)W * H)) % D4), b = (int)(v / ((size_t)W * H * D4));
+    const int d0 = 4 * dq;
+    // per-axis clamped coordinates and validity of the 6 / 3 / 3 input positions
+    int dc[6], hc[3], wc[3];
+    bool vd[6], vh[3], vw[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int d = d0 + i - 1; vd[i] = d >= 0 && d < D; dc[i] = min(max(d, 0), D - 1) * H * W; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int h = h_ + i - 1, w = w_ + i - 1;
+        vh[i] = h >= 0 && h < H; hc[i] = min(max(h, 0), H - 1) * W;
+        vw[i] = w >= 0 && w < W; wc[i] = min(max(w, 0), W - 1);
+    }
+    const float* __restrict__ xb = x + (size_t)b * D * H * W;
+    float acc[4][COUT];
+#pragma unroll
+    for (int pd = 0; pd < 4; ++pd)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[pd][c] = 0.f;
+#pragma unroll
+    for (int khw = 0; khw < 9; ++khw) {
+        const int kh = khw / 3, kw = khw % 3;
+        const bool vhw = vh[kh] && vw[kw];
+        const int col = hc[kh] + wc[kw];
+#pragma unroll
+        for (int din = 0; din < 6; ++din) {
+            float xv = xb[dc[din] + col];
+            xv = (vhw && vd[din]) ? xv : 0.f;
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd) {
+                const int kd = din - pd;
+                if (kd < 0 || kd > 2) continue;
+                const int t = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[pd][c] = fmaf(xv, wt[t * COUT + c], acc[pd][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int pd = 0; pd < 4; ++pd) {
+        if (d0 + pd >= D) continue;
+        float* __restrict__ o = y + ((((size_t)b * D + d0 + pd) * H + h_) * W + w_) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[pd][c], acc[pd][c + 1], acc[pd][c + 2], acc[pd][c + 3]);
+    }
+}
+
 // wt[t][co] = W[0][co][2-kd][2-kh][2-kw]   (W is [1][Cin][3][3][3], OIK with O == 1)
 __global__ void conv_cin1_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -865,6 +928,107 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.skip) v += a.skip[o];
         a.y[o] = v;
+    }
+}
+
+// The same layer with FOUR outputs per thread (a column of 4 depth slices): the kernel above is LDS-bandwidth bound -- every output
+// reads its 27 x CIN inputs and the 27 x CIN weights from LDS (108 ds_read_b128 per output at CIN = 8: 0.086 ms of LDS time for the
+// 3.9 M voxels of MVSNet's probability layer, measured 0.095).  A thread that owns outputs d .. d+3 of one (h, w) reads each of the 6
+// input slices under a (kh, kw) offset once and each weight once per four outputs: 40 reads per output instead of 108 (measured: no
+// gain, see the knob).  The halo is
+// kept as one plane per channel quad ([cq][voxel] float4), so the 16 lanes along W read consecutive 16-byte words: no padding, no
+// bank conflicts.  Tile 4 x 8 x 16 outputs, 128 threads, halo 6 x 10 x 18.  Knob "cout1_d4" (1 = this form).
+template <int CIN>
+__global__ __launch_bounds__(128) void conv_cout1_d4_kernel(ConvArgs a, const float* __restrict__ w) {
+    constexpr int TD = 4, TH = 8, TW = 16, RD = TD + 2, RH = TH + 2, RW = TW + 2, NR = RD * RH * RW, CQ = CIN / 4;
+    __shared__ float4 tile[CQ * NR];      // [cq][voxel]
+    __shared__ float4 wl[27 * CQ];        // [tap][cq]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * TD, qh0 = th * TH, qw0 = tw * TW;
+    if (tid < 27 * CQ) {
+        const int tap = tid / CQ, cq = tid % CQ;   // W[0][ci][tap]
+        wl[tid] = make_float4(w[(size_t)(4 * cq) * 27 + tap], w[(size_t)(4 * cq + 1) * 27 + tap], w[(size_t)(4 * cq + 2) * 27 + tap],
+                              w[(size_t)(4 * cq + 3) * 27 + tap]);
+    }
+    // halo: all loads of a batch first, then the LDS writes (zero outside the volume)
+    constexpr int NITEMS = NR * CQ, NIT = (NITEMS + 127) / 128, BATCH = NIT < 12 ? NIT : 12;
+#pragma unroll
+    for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+        float4 v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int i = tid + 128 * (k0 + k);
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + k < NIT && i < NITEMS) {
+                const int vox = i / CQ, cq = i % CQ;
+                const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    v[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CIN + 4 * cq);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int i = tid + 128 * (k0 + k);
+            if (k0 + k < NIT && i < NITEMS) tile[(i % CQ) * NR + i / CQ] = v[k];
+        }
+    }
+    __syncthreads();
+    const int pw = tid % TW, ph = tid / TW;
+    float acc[TD];
+#pragma unroll
+    for (int pd = 0; pd < TD; ++pd) acc[pd] = 0.f;
+    // NOT unrolled over (kh, kw) and the channel-quad pairs: fully unrolled, hipcc hoists all 54 x CQ tile reads to the top and
+    // runs out of registers (256 VGPRs + scratch); one iteration = 12 reads + 6 weight reads + 96 FMAs
+#pragma unroll 1
+    for (int khw = 0; khw < 9; ++khw) {
+        const int kh = khw / 3, kw = khw % 3;
+        const int col = (ph + kh) * RW + pw + kw;
+#pragma unroll 1
+        for (int cq0 = 0; cq0 < CQ; cq0 += 2) {
+            float4 wv[3][2];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) wv[kd][c] = wl[((kd * 3 + kh) * 3 + kw) * CQ + cq0 + c];
+            float4 xv[RD][2];
+#pragma unroll
+            for (int din = 0; din < RD; ++din)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) xv[din][c] = tile[(cq0 + c) * NR + din * RH * RW + col];
+#pragma unroll
+            for (int din = 0; din < RD; ++din)
+#pragma unroll
+                for (int pd = 0; pd < TD; ++pd) {
+                    const int kd = din - pd;
+                    if (kd < 0 || kd > 2) continue;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        acc[pd] = fmaf(xv[din][c].x, wv[kd][c].x, acc[pd]); acc[pd] = fmaf(xv[din][c].y, wv[kd][c].y, acc[pd]);
+                        acc[pd] = fmaf(xv[din][c].z, wv[kd][c].z, acc[pd]); acc[pd] = fmaf(xv[din][c].w, wv[kd][c].w, acc[pd]);
+                    }
+                }
+        }
+    }
+    const int qh = qh0 + ph, qw = qw0 + pw;
+    if (qh < a.QH && qw < a.QW) {
+#pragma unroll
+        for (int pd = 0; pd < TD; ++pd) {
+            const int qd = qd0 + pd;
+            if (qd >= a.QD) continue;
+            const size_t o = (((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw;
+            float v = acc[pd];
+            if (a.scale) v = v * a.scale[0] + a.shift[0];
+            else if (a.shift) v = v + a.shift[0];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.skip) v += a.skip[o];
+            a.y[o] = v;
+        }
     }
 }
 
@@ -1700,6 +1864,13 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     }
     int nblocks = B * a.ntd * a.nth * a.ntw;
     if (geom == GEOM_S1 && cout == 1 && wlayout == WL_OIK && !flip && !ep.partials && (cin == 8 || cin == 16)) {
+        if (g_conv_cout1_d4 & 1) {   // four outputs per thread, tile 4 x 8 x 16
+            a.nth = mvs_cdiv(a.QH, 8);
+            const int nb4 = B * a.ntd * a.nth * a.ntw;
+            if (cin == 8) MVS_LAUNCH((conv_cout1_d4_kernel<8>), dim3(nb4), dim3(128), 0, st, a, wsrc);
+            else MVS_LAUNCH((conv_cout1_d4_kernel<16>), dim3(nb4), dim3(128), 0, st, a, wsrc);
+            return mvs_check_launch("conv_cout1_d4");
+        }
         if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         return mvs_check_launch("conv_cout1");
@@ -1885,6 +2056,13 @@ extern "C" int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, floa
             MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv3d_dgrad: null pointer argument");
             MVS_REQUIRE(Cin == 8 || Cin == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", Cin);
             MVS_LAUNCH(conv_cin1_pack_kernel, dim3(mvs_cdiv(27 * Cin, 256)), dim3(256), 0, stream, w, ws, Cin);
+            if (g_conv_cout1_d4 & 1) {
+                const size_t total4 = (size_t)B * ((D + 3) / 4) * H * W;
+                dim3 grid4((unsigned)((total4 + 255) / 256));
+                if (Cin == 8) MVS_LAUNCH((conv_cin1_d4_kernel<8>), grid4, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
+                else MVS_LAUNCH((conv_cin1_d4_kernel<16>), grid4, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
+                return mvs_check_launch("conv_cin1_d4");
+            }
             const size_t total = (size_t)B * D * H * W;
             dim3 grid((unsigned)((total + 255) / 256));
             if (Cin == 8) MVS_LAUNCH((conv_cin1_kernel<8>), grid, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);

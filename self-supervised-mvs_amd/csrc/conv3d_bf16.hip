@@ -19,6 +19,7 @@
 #include "conv_map.h"
 
 typedef unsigned short bf16_t;
+extern int g_conv_cout1_d4;   // conv3d.hip: knob "cout1_d4"
 
 struct Bf16ConvArgs {
     const bf16_t* x;        // [B,Di,Hi,Wi,CIN] bf16
@@ -295,6 +296,105 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     }
 }
 
+// Cout == 1 (the probability layer, mvsnet.py:63) on bf16 activations as a direct convolution: the MFMA form above uses one of its 16
+// rows here (0.43 ms at config 5 against 0.12 ms of HBM time).  Same scheme as conv_cout1_d4_kernel of conv3d.hip: a thread owns a
+// column of four depth slices of one (h, w), the halo tile is one 16-byte word (8 bf16 channels) per voxel and channel octet, the
+// weights are rounded to bf16 like the packed image of the MFMA form (bf16 operands, fp32 accumulation).  Tile 4 x 8 x 16, 128 threads.
+template <int CIN>
+__global__ __launch_bounds__(128) void conv_bf16_cout1_d4_kernel(Bf16ConvArgs a, const float* __restrict__ w) {
+    constexpr int TD = 4, TH = 8, TW = 16, RD = TD + 2, RH = TH + 2, RW = TW + 2, NR = RD * RH * RW, CO = CIN / 8;
+    __shared__ uint4 tile[CO * NR];       // [octet][voxel]
+    __shared__ float4 wl[27 * CIN / 4];   // [tap][ci]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * TD, qh0 = th * TH, qw0 = tw * TW;
+    for (int i = tid; i < 27 * CIN; i += 128) {
+        const int tap = i / CIN, ci = i % CIN;   // W[0][ci][tap]
+        reinterpret_cast<float*>(wl)[i] = bf2f(f2bf(w[(size_t)ci * 27 + tap]));
+    }
+    constexpr int NITEMS = NR * CO, NIT = (NITEMS + 127) / 128, BATCH = NIT < 12 ? NIT : 12;
+    const bf16_t* __restrict__ xb = a.x + (size_t)b * a.Di * a.Hi * a.Wi * CIN;
+#pragma unroll
+    for (int k0 = 0; k0 < NIT; k0 += BATCH) {
+        uint4 v[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int i = tid + 128 * (k0 + k);
+            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (k0 + k < NIT && i < NITEMS) {
+                const int vox = i / CO, oc = i % CO;
+                const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
+                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    v[k] = *reinterpret_cast<const uint4*>(xb + (((size_t)id * a.Hi + ih) * a.Wi + iw) * CIN + 8 * oc);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int i = tid + 128 * (k0 + k);
+            if (k0 + k < NIT && i < NITEMS) tile[(i % CO) * NR + i / CO] = v[k];
+        }
+    }
+    __syncthreads();
+    const int pw = tid % TW, ph = tid / TW;
+    float acc[TD];
+#pragma unroll
+    for (int pd = 0; pd < TD; ++pd) acc[pd] = 0.f;
+    // not unrolled over (kh, kw) / the channel octets: see conv_cout1_d4_kernel (register pressure)
+#pragma unroll 1
+    for (int khw = 0; khw < 9; ++khw) {
+        const int kh = khw / 3, kw = khw % 3;
+        const int col = (ph + kh) * RW + pw + kw;
+#pragma unroll 1
+        for (int oc = 0; oc < CO; ++oc) {
+            float4 wv[3][2];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                wv[kd][0] = wl[(((kd * 3 + kh) * 3 + kw) * CIN + 8 * oc) / 4];
+                wv[kd][1] = wl[(((kd * 3 + kh) * 3 + kw) * CIN + 8 * oc) / 4 + 1];
+            }
+#pragma unroll
+            for (int din = 0; din < RD; ++din) {
+                const uint4 u = tile[oc * NR + din * RH * RW + col];
+                float xv[8];
+                xv[0] = bf2f((bf16_t)(u.x & 0xffffu)); xv[1] = bf2f((bf16_t)(u.x >> 16));
+                xv[2] = bf2f((bf16_t)(u.y & 0xffffu)); xv[3] = bf2f((bf16_t)(u.y >> 16));
+                xv[4] = bf2f((bf16_t)(u.z & 0xffffu)); xv[5] = bf2f((bf16_t)(u.z >> 16));
+                xv[6] = bf2f((bf16_t)(u.w & 0xffffu)); xv[7] = bf2f((bf16_t)(u.w >> 16));
+#pragma unroll
+                for (int pd = 0; pd < TD; ++pd) {
+                    const int kd = din - pd;
+                    if (kd < 0 || kd > 2) continue;
+                    acc[pd] = fmaf(xv[0], wv[kd][0].x, acc[pd]); acc[pd] = fmaf(xv[1], wv[kd][0].y, acc[pd]);
+                    acc[pd] = fmaf(xv[2], wv[kd][0].z, acc[pd]); acc[pd] = fmaf(xv[3], wv[kd][0].w, acc[pd]);
+                    acc[pd] = fmaf(xv[4], wv[kd][1].x, acc[pd]); acc[pd] = fmaf(xv[5], wv[kd][1].y, acc[pd]);
+                    acc[pd] = fmaf(xv[6], wv[kd][1].z, acc[pd]); acc[pd] = fmaf(xv[7], wv[kd][1].w, acc[pd]);
+                }
+            }
+        }
+    }
+    const int qh = qh0 + ph, qw = qw0 + pw;
+    if (qh < a.QH && qw < a.QW) {
+#pragma unroll
+        for (int pd = 0; pd < TD; ++pd) {
+            const int qd = qd0 + pd;
+            if (qd >= a.QD) continue;
+            const size_t o = (((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw;
+            float v = acc[pd];
+            if (a.scale) v = fmaf(v, a.scale[0], a.shift[0]);
+            else if (a.shift) v += a.shift[0];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.skip) v += bf2f(a.skip[o]);
+            if (a.out_f32) reinterpret_cast<float*>(a.y)[o] = v;
+            else reinterpret_cast<bf16_t*>(a.y)[o] = f2bf(v);
+        }
+    }
+}
+
 // fp32 -> bf16 (feature maps are fp32; the volume is produced in bf16 by the sweep kernel directly)
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -359,6 +459,14 @@ extern "C" int mvs_conv3d_bf16_fwd(const void* x, const float* w, void* y, void*
         a.QD = a.Do; a.QH = a.Ho; a.QW = a.Wo;
     } else { a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; a.QD = D; a.QH = H; a.QW = W; }
     a.ntd = mvs_cdiv(a.QD, geom == GEOM_S2 ? 2 : 4); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
+    if (geom == GEOM_S1 && Cout == 1 && (Cin == 8 || Cin == 16) && (g_conv_cout1_d4 & 2)) {   // direct form, four outputs per thread
+        a.nth = mvs_cdiv(a.QH, 8);
+        const long long nb4 = (long long)B * a.ntd * a.nth * a.ntw;
+        MVS_REQUIRE(nb4 < (1ll << 31), MVS_ERR_SHAPE, "conv3d bf16: too many tiles");
+        if (Cin == 8) MVS_LAUNCH((conv_bf16_cout1_d4_kernel<8>), dim3((unsigned)nb4), dim3(128), 0, stream, a, w);
+        else MVS_LAUNCH((conv_bf16_cout1_d4_kernel<16>), dim3((unsigned)nb4), dim3(128), 0, stream, a, w);
+        return mvs_check_launch("conv_bf16_cout1_d4");
+    }
     const int MB = mvs_cdiv(Cout, 16);
     const int total = bf16_total_ksteps(geom, Cin) * MB * 512;
     MVS_LAUNCH(conv_bf16_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, stream, w, (bf16_t*)ws, geom, Cin, Cout, MB,

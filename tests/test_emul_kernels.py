@@ -895,7 +895,7 @@ def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, di
 
 
 # ---- bf16-storage inference path (BASELINE configs[4]) -------------------------------------------------------------------
-BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)),
+BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)), (16, 1, 1, False, (5, 9, 18)),
                    (8, 16, 2, False, (6, 8, 34)), (32, 64, 2, False, (4, 6, 18)), (64, 32, 2, True, (2, 3, 9)), (16, 8, 2, True, (3, 4, 17))]
 
 
@@ -925,6 +925,16 @@ def test_conv3d_bf16_inference(emul_lib, cin, cout, stride, transposed, dims):
     exp = ref_bn + skip.float()
     assert float((y.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
     assert float((yb - (ref + shift.view(1, -1, 1, 1, 1))).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    if cout == 1:   # the default above is the direct four-outputs-per-thread form (knob cout1_d4, bit 1); here the MFMA form
+        emul_lib.call("mvs_set_tuning", b"cout1_d4", 0)
+        try:
+            with torch.no_grad():
+                y4 = ops.conv3d_forward_bf16(x, wt, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
+                yb4 = ops.conv3d_forward_bf16(x, wt, stride, transposed, shift=shift, out_f32=True)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)
+        assert float((y4.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
+        assert float((yb4 - (ref + shift.view(1, -1, 1, 1, 1))).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
 def test_plane_sweep_variance_bf16_volume(emul_lib):
@@ -1259,3 +1269,41 @@ def test_conv2d_folded_batchnorm_relu_eval(emul_lib, cin, cout, ks, stride, hw):
     assert got.shape == exp.shape
     assert float((got - exp).abs().max()) < 2e-5 * max(1.0, float(exp.abs().max()))
     assert float(got.min()) >= 0.0
+
+
+@pytest.mark.parametrize("cin,dims,b", [(8, (4, 8, 16), 1), (8, (5, 11, 19), 2), (16, (6, 9, 17), 1), (16, (3, 2, 5), 2)])
+def test_conv3d_probability_layer_four_outputs_per_thread(emul_lib, cin, dims, b):
+    """Knob cout1_d4: the Cout = 1 layer (mvsnet.py:63 / network.py:65: Conv3d(C, 1, 3, padding 1) with bias) with a column of four
+    depth slices per thread and the halo as one plane per channel quad -- ragged sizes (tiles overhang in all three dimensions, a
+    volume thinner than one tile), bias, skip and ReLU epilogues -- against ATen and against the one-output-per-thread kernel."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + sum(dims))
+    x = torch.randn(b, cin, *dims, generator=g)
+    w = torch.randn(1, cin, 3, 3, 3, generator=g) * 0.2
+    bias = torch.randn(1, generator=g)
+    skip = torch.randn(b, 1, *dims, generator=g)
+    exp = F.conv3d(x, w, bias, padding=1)
+    outs = {}
+    try:
+        for knob in (0, 1):
+            emul_lib.call("mvs_set_tuning", b"cout1_d4", knob)      # bit 0: the fp32 kernels
+            y, _ = ops.conv3d_forward(x, w, 1, False, shift=bias)
+            y2, _ = ops.conv3d_forward(x, w, 1, False, shift=bias, skip=skip, relu=True)
+            outs[knob] = (y, y2)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)
+    for knob in (0, 1):
+        assert float((outs[knob][0] - exp).abs().max()) < 2e-4, knob
+        assert float((outs[knob][1] - (F.relu(exp) + skip)).abs().max()) < 2e-4, knob
+    assert float((outs[1][0] - outs[0][0]).abs().max()) < 2e-5      # same products, another summation order
+    # the layer's input gradient (1 -> C channels), same knob
+    gy = torch.randn(b, 1, *dims, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv3d(xr, w, None, padding=1).backward(gy)
+    try:
+        for knob in (0, 1):
+            emul_lib.call("mvs_set_tuning", b"cout1_d4", knob)
+            gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), 1, False)
+            assert float((gx - xr.grad).abs().max()) < 3e-4, knob
+    finally:
+        emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)

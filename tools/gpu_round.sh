@@ -501,3 +501,14 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c$c.json
   done
 fi
+if [ "$what" = "r3k" ]; then
+  # round 3: the Cout = 1 (probability) layer, its input gradient and its bf16 form with four outputs per thread (knob cout1_d4)
+  MVS_SKIP_HEAVY=1 MVS_TUNING=cout1_d4=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "conv3d_family or golden_costregnet or bf16_inference or conv3d_bf16 or smallest" > gpurun_out/pytest_r3k.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3k.log | tail -5
+  for cfg in 2 4 5; do for t in "cout1_d4=0" "cout1_d4=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c${cfg}_[$t].json" 2> "gpurun_out/bench_c${cfg}_[$t].err"
+    echo "bench config $cfg [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c${cfg}_[$t].json"; grep -E ">1:s1" "gpurun_out/bench_c${cfg}_[$t].err" | head -6
+  done; done
+fi
