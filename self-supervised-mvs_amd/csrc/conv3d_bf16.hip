@@ -20,6 +20,8 @@
 
 typedef unsigned short bf16_t;
 extern int g_conv_cout1_d4;   // conv3d.hip: knob "cout1_d4"
+extern int g_conv_tr2pw;       // conv3d.hip: knob "tr2pw"
+int g_conv_bf16_dp = 1;         // knob "bf16_dp": conv0 of the bf16 path (32 -> 8) with two output depth slices per MFMA (GEOM_S1_DP)
 
 struct Bf16ConvArgs {
     const bf16_t* x;        // [B,Di,Hi,Wi,CIN] bf16
@@ -52,9 +54,18 @@ __host__ __device__ static inline float bf2f(bf16_t h) {
 // taps of a class: S1 / S2 have one class of 27 taps; TR2 has 8 parity classes of 1..8 taps
 template <int GEOM> struct Bf16Geom {
     using G = ConvGeom<GEOM>;
-    static constexpr int NBW = GEOM == GEOM_S2 ? 2 : 4;          // 16-voxel rows per wave
+    static constexpr int NBW = (GEOM == GEOM_S2 || GEOM == GEOM_S1_DP) ? 2 : 4;          // 16-voxel rows per wave
 };
-MVS_HD inline int bf16_ntaps(int geom, int cls) { return geom == GEOM_TR2 ? tr2_ntaps(cls) : 27; }
+// GEOM_TR2_PW (transposed, Cout == 8): the two output parities along W share one MFMA -- row m = pw*8 + co, class = (pd, ph), taps
+// = the (d, h) taps of the class times the two input offsets along W (conv_map.h: tr2p_*): all 16 rows carry channels, 9 k-steps
+// instead of 14 at Cin = 16, and the lanes of a voxel pair store 32 consecutive bytes
+MVS_HD inline int bf16_ncls(int geom) { return geom == GEOM_TR2 ? 8 : (geom == GEOM_TR2_PW ? 4 : 1); }
+// GEOM_S1_DP (stride 1, Cout == 8): two output depth slices share one MFMA -- row m = pd*8 + co, 36 taps = the 4 input slices under
+// the pair x 3 x 3 (tap (kd', kh, kw) carries W[kd' - pd] for row parity pd, zero where kd' - pd is outside 0..2): all 16 rows carry
+// channels, 36 k-steps per slice pair instead of 54, and a wave reads each input row once for both slices
+MVS_HD inline int bf16_ntaps(int geom, int cls) {
+    return geom == GEOM_TR2 ? tr2_ntaps(cls) : (geom == GEOM_TR2_PW ? tr2p_ntaps(cls) : (geom == GEOM_S1_DP ? 36 : 27));
+}
 MVS_HD inline int bf16_ksteps(int geom, int cls, int cin) { return (bf16_ntaps(geom, cls) * cin + 31) / 32; }
 MVS_HD inline int bf16_kstep_prefix(int geom, int cls, int cin) {
     int s = 0;
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __rest
     const int mb = (idx >> 9) % MB;
     int kk = (idx >> 9) / MB;
     int cls = 0;
-    const int ncls = geom == GEOM_TR2 ? 8 : 1;
+    const int ncls = bf16_ncls(geom);
     for (; cls < ncls; ++cls) {
         const int n = bf16_ksteps(geom, cls, cin);
         if (kk < n) break;
@@ -81,9 +92,29 @@ __global__ __launch_bounds__(256) void conv_bf16_pack_kernel(const float* __rest
     }
     const int kflat = 32 * kk + 8 * (lane >> 4) + j;
     const int tap = kflat / cin, ci = kflat % cin;
-    const int co = 16 * mb + (lane & 15);
+    int co = 16 * mb + (lane & 15);
     float v = 0.f;
-    if (co < cout && tap < bf16_ntaps(geom, cls)) {
+    if (geom == GEOM_TR2_PW) {   // row = pw*8 + co (cout == 8, one m-block)
+        const int pw = (lane & 15) >> 3;
+        co = lane & 7;
+        if (tap < tr2p_ntaps(cls)) {
+            int dd, dh, dw, kd, kh;
+            tr2p_tap(cls, tap, dd, dh, dw, kd, kh);
+            const int kw = tr2p_kw(pw, dw);
+            if (kw >= 0) {
+                const int kidx = kd * 9 + kh * 3 + kw;
+                v = layout == WL_OIK ? w[((size_t)co * cin + ci) * 27 + kidx] : w[((size_t)ci * cout + co) * 27 + kidx];
+            }
+        }
+    } else if (geom == GEOM_S1_DP) {   // row = pd*8 + co (cout == 8, one m-block); tap = (kd', kh, kw), kd' in 0..3
+        const int pd = (lane & 15) >> 3;
+        co = lane & 7;
+        const int kd = tap / 9 - pd, kh = (tap / 3) % 3, kw = tap % 3;
+        if (tap < 36 && kd >= 0 && kd <= 2) {
+            const int kidx = kd * 9 + kh * 3 + kw;
+            v = layout == WL_OIK ? w[((size_t)co * cin + ci) * 27 + kidx] : w[((size_t)ci * cout + co) * 27 + kidx];
+        }
+    } else if (co < cout && tap < bf16_ntaps(geom, cls)) {
         int kd, kh, kw;
         if (geom == GEOM_TR2) {
             int dd, dh, dw;
@@ -107,7 +138,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     constexpr int CH = CIN / 8;                          // 16-byte chunks per voxel
     constexpr int NCLS = G::NCLS;
     __shared__ __attribute__((aligned(16))) bf16_t halo[NR * PITCH];
-    __shared__ int s_tapoff[NCLS * 32];                  // halo offset (bf16 elements) of tap t of class c; clamped beyond the class
+    constexpr bool DP = GEOM == GEOM_S1_DP;
+    constexpr int TAPS = DP ? 64 : 32;                   // table slots per class
+    __shared__ int s_tapoff[NCLS * TAPS];                // halo offset (bf16 elements) of tap t of class c; clamped beyond the class
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int t = blockIdx.x;
     const int tw = t % a.ntw; t /= a.ntw;
@@ -116,16 +149,19 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     const int b = t;
     const int q0d = td * G::TQD, q0h = th * G::TQH, q0w = tw * G::TQW;
     // ---- tap table ----
-    if (tid < NCLS * 32) {
-        const int cls = tid / 32;
-        int tap = tid % 32;
+    if (tid < NCLS * TAPS) {
+        const int cls = tid / TAPS;
+        int tap = tid % TAPS;
         const int nt = bf16_ntaps(GEOM, cls);
         if (tap >= nt) tap = nt - 1;                     // padded k: zero weights, any valid address
         int dz, dy, dx;
         if (GEOM == GEOM_TR2) {
             int kd, kh, kw;
             tr2_tap(cls, tap, dz, dy, dx, kd, kh, kw);
-        } else {
+        } else if (GEOM == GEOM_TR2_PW) {
+            int kd, kh;
+            tr2p_tap(cls, tap, dz, dy, dx, kd, kh);
+        } else {   // S1 / S2: dz in 0..2; S1_DP: dz in 0..3 (the input slices under an output slice pair)
             dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3;
         }
         s_tapoff[tid] = ((dz * G::RH + dy) * G::RW + dx) * PITCH;
@@ -137,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     constexpr int KS1 = (27 * CIN + 31) / 32;            // k-steps of the single class of S1 / S2
     // (measured, run 9: preloading conv0's 27 fragments cost a wave of occupancy and was 35 % SLOWER than fetching them in the
     //  loop, 2.39 vs 1.77 ms at config 5 -- only images of <= 8 fragments are preloaded)
-    constexpr bool PRELOAD = GEOM != GEOM_TR2 && KS1 * MB <= 8;
+    constexpr bool PRELOAD = G::BASE != GEOM_TR2 && KS1 * MB <= 8;
     constexpr int PD = 4;
     mvs_bf16x8 areg[PRELOAD ? KS1 : 1][MB];
     if constexpr (PRELOAD) {
@@ -186,9 +222,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
     int rowbase[NBW], rqd[NBW], rqh[NBW];
 #pragma unroll
     for (int r = 0; r < NBW; ++r) {
-        rqd[r] = GEOM == GEOM_S2 ? (wv >> 1) : wv;
-        rqh[r] = GEOM == GEOM_S2 ? 2 * (wv & 1) + r : r;
-        rowbase[r] = ((rqd[r] * G::IS * G::RH + rqh[r] * G::IS) * G::RW + n * G::IS) * PITCH;
+        rqd[r] = (GEOM == GEOM_S2 || DP) ? (wv >> 1) : wv;        // S1_DP: the slice PAIR
+        rqh[r] = (GEOM == GEOM_S2 || DP) ? 2 * (wv & 1) + r : r;
+        rowbase[r] = ((rqd[r] * (DP ? 2 : G::IS) * G::RH + rqh[r] * G::IS) * G::RW + n * G::IS) * PITCH;
     }
     const int Do = a.Do, Ho = a.Ho, Wo = a.Wo;
     int kbase = 0;                                       // global k-step index of the class's first step
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
                     const int ks = ks0 + u;
                     if (ks < nks) {
                         const int kflat = 32 * ks + 8 * kg;
-                        const int boff = s_tapoff[cls * 32 + kflat / CIN] + kflat % CIN;
+                        const int boff = s_tapoff[cls * TAPS + kflat / CIN] + kflat % CIN;
                         mvs_bf16x8 bfrag[NBW];
 #pragma unroll
                         for (int r = 0; r < NBW; ++r) bfrag[r] = *reinterpret_cast<const mvs_bf16x8*>(halo + rowbase[r] + boff);
@@ -245,17 +281,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(Bf16ConvArgs a) {
         }
         kbase += nks;
         // ---- epilogue: folded BatchNorm (or bias) + ReLU + skip, 4 consecutive channels of one voxel per lane ----
-        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        // TR2_PW: class = (pd, ph); the lane's four rows are channels 4*(kg & 1).. of the voxel with W parity kg >> 1
+        const int pd = G::PW ? (cls >> 1) & 1 : (cls >> 2) & 1, ph = G::PW ? cls & 1 : (cls >> 1) & 1, pw = G::PW ? kg >> 1 : cls & 1;
 #pragma unroll
         for (int r = 0; r < NBW; ++r) {
-            const int qd = q0d + rqd[r], qh = q0h + rqh[r], qw = q0w + n;
+            const int qd = q0d + (DP ? 2 * rqd[r] + (kg >> 1) : rqd[r]), qh = q0h + rqh[r], qw = q0w + n;
             if (qd >= a.QD || qh >= a.QH || qw >= a.QW) continue;
-            const int od = qd * G::OS + (GEOM == GEOM_TR2 ? pd : 0), oh = qh * G::OS + (GEOM == GEOM_TR2 ? ph : 0),
-                      ow = qw * G::OS + (GEOM == GEOM_TR2 ? pw : 0);
+            const int od = qd * G::OS + (G::BASE == GEOM_TR2 ? pd : 0), oh = qh * G::OS + (G::BASE == GEOM_TR2 ? ph : 0),
+                      ow = qw * G::OS + (G::BASE == GEOM_TR2 ? pw : 0);
             const size_t vox = (((size_t)b * Do + od) * Ho + oh) * Wo + ow;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const int c0 = 16 * m + 4 * kg;
+                const int c0 = (G::PW || DP) ? 4 * (kg & 1) : 16 * m + 4 * kg;
                 if (c0 >= COUT) continue;
                 float v[4];
 #pragma unroll
@@ -418,20 +455,25 @@ static int launch_bf16(const Bf16ConvArgs& a, int geom, int cin, int cout, int n
     MVS_BF16_CASE(GEOM_S1, 32, 8) MVS_BF16_CASE(GEOM_S1, 8, 8) MVS_BF16_CASE(GEOM_S1, 16, 16) MVS_BF16_CASE(GEOM_S1, 32, 32)
     MVS_BF16_CASE(GEOM_S1, 64, 64) MVS_BF16_CASE(GEOM_S1, 8, 1) MVS_BF16_CASE(GEOM_S1, 16, 1) MVS_BF16_CASE(GEOM_S1, 16, 8)
     MVS_BF16_CASE(GEOM_S2, 8, 16) MVS_BF16_CASE(GEOM_S2, 16, 32) MVS_BF16_CASE(GEOM_S2, 32, 64)
-    MVS_BF16_CASE(GEOM_TR2, 64, 32) MVS_BF16_CASE(GEOM_TR2, 32, 16) MVS_BF16_CASE(GEOM_TR2, 16, 8)
+    MVS_BF16_CASE(GEOM_TR2, 64, 32) MVS_BF16_CASE(GEOM_TR2, 32, 16) MVS_BF16_CASE(GEOM_TR2, 16, 8) MVS_BF16_CASE(GEOM_TR2_PW, 16, 8) MVS_BF16_CASE(GEOM_S1_DP, 32, 8)
     mvs_set_error("conv3d bf16: no kernel for %s %d -> %d channels (supported: the CostRegNet layer shapes)",
                   geom == GEOM_S1 ? "stride-1 conv" : (geom == GEOM_S2 ? "stride-2 conv" : "transposed stride-2 conv"), cin, cout);
     return MVS_ERR_UNSUPPORTED;
 }
 #undef MVS_BF16_CASE
 
-static int bf16_total_ksteps(int geom, int cin) { return bf16_kstep_prefix(geom, geom == GEOM_TR2 ? 8 : 1, cin); }
+static int bf16_total_ksteps(int geom, int cin) { return bf16_kstep_prefix(geom, bf16_ncls(geom), cin); }
 
 // bytes of workspace (the packed bf16 weight image) a call needs
 extern "C" long long mvs_conv3d_bf16_workspace_bytes(int Cin, int Cout, int stride, int transposed) {
     if (!(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) || Cout < 1 || Cout > 64) return -1;
     const int geom = transposed ? GEOM_TR2 : (stride == 2 ? GEOM_S2 : GEOM_S1);
-    return (long long)bf16_total_ksteps(geom, Cin) * mvs_cdiv(Cout, 16) * 512 * 2;
+    int ks = bf16_total_ksteps(geom, Cin);
+    if (geom == GEOM_S1 && Cout == 8) {   // whichever form the knob picks
+        const int dp = bf16_total_ksteps(GEOM_S1_DP, Cin);
+        ks = ks > dp ? ks : dp;
+    }
+    return (long long)ks * mvs_cdiv(Cout, 16) * 512 * 2;
 }
 
 // y = conv3d(x, w, stride 1|2, pad 1)  |  conv_transpose3d(x, w, stride 2, pad 1, output_padding 1), then
@@ -468,13 +510,17 @@ extern "C" int mvs_conv3d_bf16_fwd(const void* x, const float* w, void* y, void*
         return mvs_check_launch("conv_bf16_cout1_d4");
     }
     const int MB = mvs_cdiv(Cout, 16);
-    const int total = bf16_total_ksteps(geom, Cin) * MB * 512;
-    MVS_LAUNCH(conv_bf16_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, stream, w, (bf16_t*)ws, geom, Cin, Cout, MB,
+    // transposed with 8 output channels (16 -> 8, the last decoder block): both W parities in one MFMA (knob "tr2pw", shared with
+    // the fp32 kernels' GEOM_TR2_PW)
+    const int kgeom = (geom == GEOM_TR2 && Cout == 8 && Cin == 16 && g_conv_tr2pw) ? GEOM_TR2_PW
+                    : ((geom == GEOM_S1 && Cout == 8 && Cin == 32 && g_conv_bf16_dp) ? GEOM_S1_DP : geom);   // knob "bf16_dp"
+    const int total = bf16_total_ksteps(kgeom, Cin) * MB * 512;
+    MVS_LAUNCH(conv_bf16_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, stream, w, (bf16_t*)ws, kgeom, Cin, Cout, MB,
                transposed ? WL_IOK : WL_OIK, total);
     a.wp = (const bf16_t*)ws;
     const long long nblocks = (long long)B * a.ntd * a.nth * a.ntw;
     MVS_REQUIRE(nblocks < (1ll << 31), MVS_ERR_SHAPE, "conv3d bf16: too many tiles");
-    return launch_bf16(a, geom, Cin, Cout, (int)nblocks, stream);
+    return launch_bf16(a, kgeom, Cin, Cout, (int)nblocks, stream);
 }
 
 // elementwise fp32 -> bf16 (n % 4 == 0)

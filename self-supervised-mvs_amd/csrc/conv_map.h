@@ -21,7 +21,10 @@ enum { GEOM_S1 = 0, GEOM_S2 = 1, GEOM_TR2 = 2,
        // levels, whose volumes (24x16x20 at config 2) give the full-size tiles fewer workgroups than the chip has CUs
        GEOM_S1_SMALL = 3, GEOM_S2_SMALL = 4, GEOM_TR2_SMALL = 5,
        // transposed stride-2 conv with Cout == 8: the two W-parity classes of a (pd, ph) pair as ONE GEMM with N = 16 = (pw, co)
-       GEOM_TR2_PW = 6 };
+       GEOM_TR2_PW = 6,
+       // stride-1 conv with Cout == 8 on the bf16 path (conv3d_bf16.hip only): two output depth slices per MFMA, row = pd*8 + co,
+       // K = the 4 x 3 x 3 input offsets under the slice pair
+       GEOM_S1_DP = 7 };
 // source weight tensor layout: OIK = [out'][in'][3][3][3], IOK = [in'][out'][3][3][3]
 enum { WL_OIK = 0, WL_IOK = 1 };
 
@@ -29,6 +32,14 @@ template <int GEOM>
 struct ConvGeom;
 template <>
 struct ConvGeom<GEOM_S1> {
+    static constexpr bool PW = false;
+    static constexpr int BASE = GEOM_S1;
+    static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;
+    static constexpr int IS = 1, OS = 1, NCLS = 1, PAD = 1;
+    static constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
+};
+template <>
+struct ConvGeom<GEOM_S1_DP> {
     static constexpr bool PW = false;
     static constexpr int BASE = GEOM_S1;
     static constexpr int TQD = 4, TQH = 4, TQW = 16, MB = 4;

@@ -895,8 +895,8 @@ def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, di
 
 
 # ---- bf16-storage inference path (BASELINE configs[4]) -------------------------------------------------------------------
-BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)), (16, 1, 1, False, (5, 9, 18)),
-                   (8, 16, 2, False, (6, 8, 34)), (32, 64, 2, False, (4, 6, 18)), (64, 32, 2, True, (2, 3, 9)), (16, 8, 2, True, (3, 4, 17))]
+BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (32, 8, 1, False, (7, 3, 33)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)), (16, 1, 1, False, (5, 9, 18)),
+                   (8, 16, 2, False, (6, 8, 34)), (32, 64, 2, False, (4, 6, 18)), (64, 32, 2, True, (2, 3, 9)), (16, 8, 2, True, (3, 4, 17)), (16, 8, 2, True, (5, 5, 9))]
 
 
 @pytest.mark.parametrize("cin,cout,stride,transposed,dims", BF16_CONV_CASES)
@@ -925,6 +925,24 @@ def test_conv3d_bf16_inference(emul_lib, cin, cout, stride, transposed, dims):
     exp = ref_bn + skip.float()
     assert float((y.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
     assert float((yb - (ref + shift.view(1, -1, 1, 1, 1))).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    if (cin, cout, stride) == (32, 8, 1):   # the default above is the depth-slice-pair form (knob bf16_dp); here one slice per MFMA
+        emul_lib.call("mvs_set_tuning", b"bf16_dp", 0)
+        try:
+            with torch.no_grad():
+                y1 = ops.conv3d_forward_bf16(x, wt, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"bf16_dp", 1)
+        assert float((y1.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
+        assert float((y1.float() - y.float()).abs().max()) <= 2 ** -7 * float(exp.abs().max())
+    if transposed and cout == 8:   # the default above is the W-parity-merged form (knob tr2pw); here one MFMA per parity class
+        emul_lib.call("mvs_set_tuning", b"tr2pw", 0)
+        try:
+            with torch.no_grad():
+                y8 = ops.conv3d_forward_bf16(x, wt, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"tr2pw", 1)
+        assert float((y8.float() - exp).abs().max()) <= 2 ** -7 * float(exp.abs().max()) + 1e-5
+        assert float((y8.float() - y.float()).abs().max()) <= 2 ** -7 * float(exp.abs().max())
     if cout == 1:   # the default above is the direct four-outputs-per-thread form (knob cout1_d4, bit 1); here the MFMA form
         emul_lib.call("mvs_set_tuning", b"cout1_d4", 0)
         try:

@@ -512,3 +512,25 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c${cfg}_[$t].json"; grep -E ">1:s1" "gpurun_out/bench_c${cfg}_[$t].err" | head -6
   done; done
 fi
+if [ "$what" = "r3l" ]; then
+  # round 3: transposed bf16 convolution 16 -> 8 with both W parities in one MFMA (GEOM_TR2_PW), config 5
+  MVS_SKIP_HEAVY=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "bf16" > gpurun_out/pytest_r3l.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3l.log | tail -5
+  for t in "tr2pw=0" "tr2pw=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c5_[$t].json" 2> "gpurun_out/bench_c5_[$t].err"
+    echo "bench config 5 [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c5_[$t].json"; grep -E "fwdT_bf16" "gpurun_out/bench_c5_[$t].err" | head -4
+  done
+fi
+if [ "$what" = "r3m" ]; then
+  # round 3: conv0 of the bf16 path with two output depth slices per MFMA (GEOM_S1_DP), config 5
+  MVS_SKIP_HEAVY=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "bf16" > gpurun_out/pytest_r3m.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3m.log | tail -5
+  for t in "bf16_dp=0" "bf16_dp=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c5_[$t].json" 2> "gpurun_out/bench_c5_[$t].err"
+    echo "bench config 5 [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c5_[$t].json"; grep -E "fwd_bf16:32>8" "gpurun_out/bench_c5_[$t].err" | head -2
+  done
+fi
