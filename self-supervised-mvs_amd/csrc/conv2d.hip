@@ -43,15 +43,25 @@ MVS_HD inline int c2_s2_tap(int tp, int par) {   // tp in 0..2 = offset -1, 0, +
     const int t = par + 2 - 2 * (tp - 1);
     return (t >= 0 && t < 5) ? t : -1;
 }
+// pp (pixel pairs, 3x3 stride 1, Cout <= 8, one column tile): column n = p*8 + co is output channel co of the pixel with X parity p
+// of the row's pixel pair; K walks the 3 x 4 input offsets under the pair: tap' = ty*4 + tx', the weight of column (p, co) at tap'
+// is W[ty][tx' - p] (zero where tx' - p is outside 0..2).  All 16 columns carry channels (a plain Cout = 8 layer fills 8 of them),
+// 12 taps per pixel PAIR instead of 9 per pixel, and the 16 lanes of a row store 64 consecutive bytes.
 __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
-                                                          int Cin, int Cout, int NB, int transposed, int total, int cls) {
+                                                          int Cin, int Cout, int NB, int transposed, int total, int cls, int pp) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
-    const int KS = c2_ksteps(NT, CC), chunk = kk / KS, ks = kk % KS;
-    const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = nb * 16 + (lane & 15);
+    const int KS = c2_ksteps(pp ? 12 : NT, CC), chunk = kk / KS, ks = kk % KS;
+    const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = pp ? (lane & 7) : nb * 16 + (lane & 15);
     float v = 0.f;
-    if (tap < NT && ci < Cin && co < Cout) {
+    if (pp) {
+        const int p = (lane & 15) >> 3, ty = tap / 4, tx = tap % 4 - p;
+        if (tap < 12 && tx >= 0 && tx <= 2 && ci < Cin && co < Cout) {
+            const int t9 = ty * 3 + tx;
+            v = transposed ? w[((size_t)ci * Cout + co) * 9 + (8 - t9)] : w[((size_t)co * Cin + ci) * 9 + t9];
+        }
+    } else if (tap < NT && ci < Cin && co < Cout) {
         if (cls >= 0) {
             const int ty = c2_s2_tap(tap / 3, cls >> 1), tx = c2_s2_tap(tap % 3, cls & 1);
             if (ty >= 0 && tx >= 0) v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
@@ -62,12 +72,15 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restric
     wp[idx] = v;
 }
 
-template <int KS, int S, int CC, int NB>
+template <int KS, int S, int CC, int NB, bool PP = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
-    constexpr int CCP = CC + 4, CQ = CC / 4, NR = G::RH * G::RW, KSTEPS = (G::NT * CC + 15) / 16;
+    static_assert(!PP || (KS == 3 && S == 1 && NB == 1), "pixel pairs: 3x3 stride 1, one column tile");
+    constexpr int NTK = PP ? 12 : G::NT;                 // taps the K dimension walks
+    constexpr int MBW = PP ? 2 : 4;                      // m-blocks per wave: a block is 16 pixel PAIRS of a row with PP
+    constexpr int CCP = CC + 4, CQ = CC / 4, NR = G::RH * G::RW, KSTEPS = (NTK * CC + 15) / 16;
     __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
-    __shared__ int tapoff[(G::NT + 4 + 3) & ~3];
+    __shared__ int tapoff[(NTK + 4 + 3) & ~3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
     int t = blockIdx.x;
     const int tw = t % a.ntw; t /= a.ntw;
@@ -75,15 +88,17 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     const int n = t;
     const int oy0 = th * G::TH, ox0 = tw * G::TW;
     const int nb0 = blockIdx.y * NB;
-    for (int i = tid; i < (int)(sizeof(tapoff) / sizeof(int)); i += 256)
-        tapoff[i] = i < G::NT ? ((i / KS) * G::RW + i % KS) * CCP : 0;   // padded k-steps read a valid location (zero weights)
+    for (int i = tid; i < (int)(sizeof(tapoff) / sizeof(int)); i += 256)   // padded k-steps read a valid location (zero weights)
+        tapoff[i] = i < NTK ? (PP ? ((i / 4) * G::RW + i % 4) * CCP : ((i / KS) * G::RW + i % KS) * CCP) : 0;
     // wave -> output rows 2w, 2w+1; m-block mb: row 2w + (mb >> 1), columns 16 (mb & 1) + l15
-    int baseA[4];
+    // (PP: m-block mb = row 2w + mb, pixel pair l15 = columns 2 l15, 2 l15 + 1)
+    int baseA[MBW];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) baseA[mb] = (((2 * wave + (mb >> 1)) * S) * G::RW + (16 * (mb & 1) + l15) * S) * CCP;
-    f32x4 acc[4][NB];
+    for (int mb = 0; mb < MBW; ++mb)
+        baseA[mb] = PP ? ((2 * wave + mb) * G::RW + 2 * l15) * CCP : (((2 * wave + (mb >> 1)) * S) * G::RW + (16 * (mb & 1) + l15) * S) * CCP;
+    f32x4 acc[MBW][NB];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nchunks = (a.Cin + CC - 1) / CC;
@@ -139,11 +154,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
                 if (ks < KSTEPS) {
                     const int kflat = 16 * ks + 4 * g;
                     const int aoff = tapoff[kflat / CC] + kflat % CC;
-                    float4 af[4];
+                    float4 af[MBW];
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
+                    for (int mb = 0; mb < MBW; ++mb) af[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
+                    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
@@ -157,18 +172,19 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
         }
     }
     // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
+    // (PP: column = p*8 + co, row = pixel pair: pixel 2 (4 g + r) + p of the row)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int oy = (oy0 + 2 * wave + (mb >> 1)) * a.os + a.py;
+    for (int mb = 0; mb < MBW; ++mb) {
+        const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
         if (oy >= a.YH) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ox = (ox0 + 16 * (mb & 1) + 4 * g + r) * a.os + a.px;
+            const int ox = (ox0 + (PP ? 2 * (4 * g + r) + (l15 >> 3) : 16 * (mb & 1) + 4 * g + r)) * a.os + a.px;
             if (ox >= a.YW) continue;
             float* __restrict__ o = a.y + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int co = (nb0 + nb) * 16 + l15;
+                const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15;
                 if (co < a.Cout) {
                     float v = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
                     if (a.act) v = v > 0.f ? v : v * a.slope;
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 static const int C2_WGRAD_GROUPS = 1024;  // partial images the workspace holds
 int g_conv2d_wgrad_groups = 256;          // tuning knob "wgrad2d_groups" (<= 1024): persistent workgroups of the weight gradient (256 = one per CU;
                                           // more let a CU overlap one workgroup's tile staging with another's MFMA loop -- not yet measured)
+int g_conv2d_pp = 1;        // tuning knob "conv2d_pp": 3x3 stride-1 layers with <= 8 output channels as pixel-pair GEMMs (conv2d_igemm_kernel<.., PP>)
 int g_conv2d_s2_mfma = 1;   // tuning knob "conv2d_s2_mfma": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
@@ -372,7 +389,8 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
         return 4LL * ((ci + cc3 - 1) / cc3) * c2_ksteps(9, cc3) * ((co + 15) / 16) * 256;
     }
     const int cc = c2_cc(ks, ci), nch = (ci + cc - 1) / cc;
-    return (long long)nch * c2_ksteps(nt, cc) * ((co + 15) / 16) * 256;
+    const int ntk = (ks == 3 && co <= 8) ? 12 : nt;   // the pixel-pair form of narrow layers walks 12 taps
+    return (long long)nch * c2_ksteps(ntk, cc) * ((co + 15) / 16) * 256;
 }
 
 template <int KS, int S, int CC>
@@ -391,8 +409,18 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
     a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32);
     const int cc = c2_cc(ks, Cin), nt = ks * ks, nch = mvs_cdiv(Cin, cc);
     a.nb_total = mvs_cdiv(Cout, 16);
+    if (ks == 3 && stride == 1 && Cout <= 8 && (cc == 4 || cc == 8) && g_conv2d_pp) {
+        // narrow layers (3 -> 8, 8 -> 8 of FeatureNet): pixel pairs fill the MFMA's 16 columns (knob "conv2d_pp")
+        const int totalp = nch * c2_ksteps(12, cc) * 256;
+        MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
+        a.wp = ws;
+        dim3 gridp(N * a.nth * a.ntw, 1);
+        if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true>), gridp, dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true>), gridp, dim3(256), 0, st, a);
+        return mvs_check_launch("conv2d_igemm (pixel pairs)");
+    }
     const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
-    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1);
+    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1, 0);
     a.wp = ws;
     const int nb = a.nb_total <= 2 ? a.nb_total : 2;   // 16-wide Cout tiles per workgroup; the rest over blockIdx.y
     dim3 grid(N * a.nth * a.ntw, mvs_cdiv(a.nb_total, nb));
@@ -453,7 +481,7 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
             if (a.Ho <= 0 || a.Wo <= 0) continue;
             a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32); a.nb_total = nbt;
             float* wpc = ws + (size_t)cls * total_w;
-            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls);
+            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls, 0);
             a.wp = wpc;
             MVS_REQUIRE(nbt <= 2, MVS_ERR_UNSUPPORTED, "conv2d_dgrad: the 5x5 stride-2 layers have <= 32 input channels");
             dim3 grid(N * a.nth * a.ntw, 1);

@@ -760,7 +760,7 @@ def test_jdacs_self_supervised_step_end_to_end(emul_lib):
     assert checked >= 3
 
 
-@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (11, 37)), (8, 8, 3, 1, (8, 32)), (8, 16, 5, 2, (18, 70)),
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (11, 37)), (8, 8, 3, 1, (8, 32)), (8, 8, 3, 1, (9, 35)), (4, 3, 3, 1, (5, 66)), (8, 16, 5, 2, (18, 70)),
                                                     (16, 16, 3, 1, (9, 33)), (16, 32, 5, 2, (17, 41)), (32, 32, 3, 1, (10, 20))])
 def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
     """SURVEY 8(f)-3 first cut: every 2-D convolution shape of FeatureNet (mvsnet.py:17-34) -- forward (+ bias), input and
@@ -784,6 +784,15 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
     assert float((ba.grad - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
     y2 = ops.conv2d_forward(x, w, None, stride)
     assert float((y2 - F.conv2d(x, w, None, stride=stride, padding=ks // 2)).abs().max()) < 2e-4
+    if ks == 3 and min(cin, cout) <= 8:   # forward and / or input gradient above ran as pixel-pair GEMMs (knob conv2d_pp); here without
+        emul_lib.call("mvs_set_tuning", b"conv2d_pp", 0)
+        try:
+            y0 = ops.conv2d_forward(x, w, b, stride)
+            gx0 = ops.conv2d_dgrad(gy, w, tuple(x.shape), stride)
+        finally:
+            emul_lib.call("mvs_set_tuning", b"conv2d_pp", 1)
+        assert float((y0 - yr).abs().max()) < 2e-4 and float((gx0 - xr.grad).abs().max()) < 3e-4
+        assert float((y0 - y.detach()).abs().max()) < 2e-5      # same products, another summation order
     if stride == 2:   # the direct form of the stride-2 input gradient (tuning knob "2" = 0) agrees with the parity-class MFMA passes
         emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 0)
         try:

@@ -534,3 +534,14 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c5_[$t].json"; grep -E "fwd_bf16:32>8" "gpurun_out/bench_c5_[$t].err" | head -2
   done
 fi
+if [ "$what" = "r3n" ]; then
+  # round 3: narrow 2-D convolutions (3 -> 8, 8 -> 8) as pixel-pair GEMMs (knob conv2d_pp), config 5
+  MVS_SKIP_HEAVY=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "conv2d or featurenet or refinenet or pyramid or config1_eval" > gpurun_out/pytest_r3n.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r3n.log | tail -5
+  for t in "conv2d_pp=0" "conv2d_pp=1"; do
+    MVS_TUNING=$t timeout 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c5_[$t].json" 2> "gpurun_out/bench_c5_[$t].err"
+    echo "bench config 5 [$t] exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c5_[$t].json"; grep -E "fwd2d" "gpurun_out/bench_c5_[$t].err" | head -8
+  done
+fi
