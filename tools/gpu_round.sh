@@ -545,3 +545,16 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c5_[$t].json"; grep -E "fwd2d" "gpurun_out/bench_c5_[$t].err" | head -8
   done
 fi
+if [ "$what" = "r3final3" ]; then
+  # closing validation after the inference-path kernel changes: every GPU test except the three full-size oracle comparisons,
+  # smoke, config 2 (short line) and config 5 (with PMC)
+  MVS_SKIP_HEAVY=1 timeout 600 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_gpu.log | tail -6
+  timeout 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log
+  timeout 200 python bench.py --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_short.json 2> gpurun_out/bench_short.err
+  echo "bench exit $?"; cut -c1-160 gpurun_out/bench_short.json
+  timeout 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 --time-all-kernels > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
+  echo "bench config 5 exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c5.json
+fi
