@@ -44,6 +44,9 @@ class ConvBnReLU(nn.Module):
     # the same csrc/conv2d.hip pass -- no separate normalisation pass over the activation (jdacs/eval.py:143 runs the model
     # in eval mode under no_grad).  MVS_FOLD_EVAL_BN=0 keeps convolution and BatchNorm apart.
     fold_eval = os.environ.get("MVS_FOLD_EVAL_BN", "1") != "0"
+    # training: forward convolution through csrc/conv2d.hip, backward through the library (its weight gradient is 3x faster than
+    # conv2d.hip's).  Opt-in (MVS_HIP_FEATURE_FWD=1) until measured.
+    hip_fwd_train = os.environ.get("MVS_HIP_FEATURE_FWD", "0") == "1"
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -62,7 +65,9 @@ class ConvBnReLU(nn.Module):
         elif (ops._ASYNC_WGRAD and self.split_bwd and x.is_cuda and self.training and torch.is_grad_enabled() and self.conv.bias is None
               and self.conv.groups == 1 and self.conv.dilation == (1, 1)):
             # opt-in side-stream weight gradients (ops.set_async_wgrad): the library convolution with its backward issued as two calls
-            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding)
+            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding,
+                                           self.hip_fwd_train and hip_conv2d_serves(self.conv, x)
+                                           and x.is_contiguous(memory_format=torch.channels_last))
         else:
             y = self.conv(x)
         bn = self.bn

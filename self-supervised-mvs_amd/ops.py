@@ -657,10 +657,15 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
+    def forward(ctx, x, weight, stride, padding, hip_forward=False):
+        """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
+        the library's two calls."""
         if ctx.needs_input_grad[1]:
             _note_weight_use(weight)
-        y = torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
+        if hip_forward:
+            y = conv2d_forward(x, weight, None, stride[0])
+        else:
+            y = torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
         return y
@@ -676,7 +681,7 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
             gw = _maybe_on_side_stream(fn, weight, (x, gy))
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 def _maybe_on_side_stream(fn, weight, inputs):

@@ -558,3 +558,11 @@ if [ "$what" = "r3final3" ]; then
 import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3), v.get('traffic')) for k,v in d['kernels'].items()})" gpurun_out/bench_c5.json
 fi
+if [ "$what" = "r3o" ]; then
+  for f in 0 1; do
+    MVS_HIP_FEATURE_FWD=$f timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_hipfwd$f.json 2> gpurun_out/bench_hipfwd$f.err
+    echo "hip_fwd_train=$f exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['final_loss'])" gpurun_out/bench_hipfwd$f.json
+  done
+fi
