@@ -162,6 +162,10 @@ int mvs_bn_relu_bwd(const float* dy, const float* x, const float* mean, const fl
 int mvs_bn_group_relu_fwd(const float* x, int G, long long Vg, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, int training, int relu, float* ws,
                           float* stats, float* y, hipStream_t stream);
+/* train-mode mvs_bn_group_relu_fwd with the partial sums already computed (by mvs_conv2d_fwd_stats): partials [G][nparts][2][C] */
+int mvs_bn_group_relu_fwd_parts(const float* x, const float* partials, int nparts, int G, long long Vg, int C,
+                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                float* running_var, int relu, float* stats, float* y, hipStream_t stream);
 int mvs_bn_group_relu_bwd(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg, int C,
                           float* ws, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
 
@@ -214,6 +218,12 @@ int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int Cout, int ks, int stride, hipStream_t stream);
 /* conv2d + bias + LeakyReLU(negative_slope) in one pass: the `conv` block of the CVP feature pyramid
  * (jdacs-ms/models/modules.py:15-19, network.py:16-41; widths 3/16/32/64).  Channels: 1..32 or exactly 64. */
+/* conv2d forward (no bias) that also writes BatchNorm partial sums of its output: partials [rows][2][Cout] with
+ * rows = mvs_conv2d_stat_rows (one per workgroup tile; image n owns rows [n*T, (n+1)*T)), read by mvs_bn_group_relu_fwd_parts.
+ * The convolution + statistics half of ConvBnReLU in training (jdacs/models/module.py:15-22). */
+int mvs_conv2d_stat_rows(int N, int H, int W, int ks, int stride);
+int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, float* partials, int N, int H, int W, int Cin,
+                         int Cout, int ks, int stride, hipStream_t stream);
 int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, float negative_slope, hipStream_t stream);
 int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,

@@ -49,12 +49,15 @@ SIGNATURES = {
     "mvs_bn_relu_fwd": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _s]),
     "mvs_bn_relu_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f, _f, _f, _s]),
     "mvs_bn_group_relu_fwd": (_i, [_f, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _i, _i, _f, _f, _f, _s]),
+    "mvs_bn_group_relu_fwd_parts": (_i, [_f, _f, _i, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _i, _f, _f, _s]),
     "mvs_bn_group_relu_bwd": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "mvs_conv2d_workspace_floats": (_ll, [_i] * 8),
     "mvs_conv2d_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_lrelu_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
+    "mvs_conv2d_stat_rows": (_i, [_i, _i, _i, _i, _i]),
+    "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),

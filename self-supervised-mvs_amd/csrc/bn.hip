@@ -333,6 +333,22 @@ extern "C" int mvs_bn_group_relu_fwd(const float* x, int G, long long Vg, int C,
     return mvs_check_launch("bn_group_relu_fwd");
 }
 
+// The same in train mode with the partial sums already there (a convolution epilogue wrote them: mvs_conv2d_fwd_stats):
+// partials [G][nparts][2][C], nparts rows per statistics group.  No statistics pass over x.
+extern "C" int mvs_bn_group_relu_fwd_parts(const float* x, const float* partials, int nparts, int G, long long Vg, int C,
+                                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                           float* running_var, int relu, float* stats, float* y, hipStream_t stream) {
+    MVS_REQUIRE(x && partials && gamma && beta && stats && y, MVS_ERR_NULL, "bn_group_relu_fwd_parts: null pointer argument");
+    MVS_REQUIRE(bn_c_ok(C), MVS_ERR_UNSUPPORTED, "bn: C must be 4/8/16/32/64, got %d", C);
+    MVS_REQUIRE(G >= 1 && G <= 64 && Vg > 0 && nparts > 0, MVS_ERR_SHAPE, "bn_group_relu_fwd_parts: bad group shape G=%d rows=%d", G, nparts);
+    const size_t n4 = (size_t)Vg * C / 4;
+    MVS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, stream, partials, nparts, C, (double)Vg, gamma, beta, eps, momentum,
+               running_mean, running_var, stats, stats + C, stats + 2 * C, stats + 3 * C, G, 4 * C);
+    MVS_LAUNCH(bn_apply_relu_kernel, dim3(ew_grid(n4), G), dim3(256), 0, stream, x, (const float*)(stats + 2 * C),
+               (const float*)(stats + 3 * C), (const float*)nullptr, y, n4, C, relu, 4 * C);
+    return mvs_check_launch("bn_group_relu_fwd_parts");
+}
+
 extern "C" int mvs_bn_group_relu_bwd(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg,
                                      int C, float* ws, float* dx, float* dgamma, float* dbeta, hipStream_t stream) {
     MVS_REQUIRE(dy && x && stats && ws && dx, MVS_ERR_NULL, "bn_group_relu_bwd: null pointer argument");

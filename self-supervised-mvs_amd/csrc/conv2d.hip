@@ -23,6 +23,7 @@ struct Conv2dArgs {
     int os, py, px, YH, YW;             // output pixel of grid point (oy,ox) is (oy*os + py, ox*os + px) of a YH x YW map
     int act;                            // 1: LeakyReLU(slope) after the bias (jdacs-ms/models/modules.py:15-19)
     float slope;
+    float* partials;                    // STATS kernels: [tile][2][Cout] (sum, sum of squares of the workgroup's outputs)
 };
 
 template <int KS, int S>
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restric
     wp[idx] = v;
 }
 
-template <int KS, int S, int CC, int NB, bool PP = false>
+// STATS: the workgroup also writes the per-channel sum and sum of squares of its outputs as one row of a.partials -- BatchNorm's
+// statistics pass folded into the convolution that produces its input, like the 3-D kernels' epilogue (rows of an image are
+// consecutive: [N][tiles per image][2][Cout] is the grouped BatchNorm's partial layout).  Separate instantiations: the plain
+// kernels' code and register allocation do not change.
+template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
     static_assert(!PP || (KS == 3 && S == 1 && NB == 1), "pixel pairs: 3x3 stride 1, one column tile");
@@ -173,6 +178,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     }
     // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
     // (PP: column = p*8 + co, row = pixel pair: pixel 2 (4 g + r) + p of the row)
+    float st1[NB], st2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) st1[nb] = st2[nb] = 0.f;
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
@@ -189,8 +197,30 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
                     float v = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
                     if (a.act) v = v > 0.f ? v : v * a.slope;
                     o[co] = v;
+                    if (STATS) { st1[nb] += v; st2[nb] = fmaf(v, v, st2[nb]); }
                 }
             }
+        }
+    }
+    if constexpr (STATS) {
+        // 16 (wave, lane group) partial sums per column, summed in a fixed order; PP: columns c and c + 8 are the same channel
+        __shared__ float red[16 * NB * 16 * 2];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            red[((wave * 4 + g) * NB * 16 + nb * 16 + l15) * 2] = st1[nb];
+            red[((wave * 4 + g) * NB * 16 + nb * 16 + l15) * 2 + 1] = st2[nb];
+        }
+        __syncthreads();
+        const int ncol = PP ? 8 : NB * 16;
+        if (tid < 2 * ncol) {
+            const int stat = tid / ncol, col = tid % ncol;
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) {
+                t += red[(k * NB * 16 + col) * 2 + stat];
+                if (PP) t += red[(k * NB * 16 + col + 8) * 2 + stat];
+            }
+            const int co = PP ? col : nb0 * 16 + col;
+            if (co < a.Cout) a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] = t;
         }
     }
 }
@@ -395,14 +425,20 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
 
 template <int KS, int S, int CC>
 static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
+    if (a.partials) {
+        if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true>), grid, dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true>), grid, dim3(256), 0, st, a);
+        return;
+    }
     if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1>), grid, dim3(256), 0, st, a);
     else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2>), grid, dim3(256), 0, st, a);
 }
 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
-                        int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f) {
+                        int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
+                        float* partials = nullptr) {
     Conv2dArgs a = {};
-    a.act = act; a.slope = slope;
+    a.act = act; a.slope = slope; a.partials = partials;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
     a.os = 1; a.py = 0; a.px = 0; a.YH = a.Ho; a.YW = a.Wo;
@@ -415,7 +451,10 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
         MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
-        if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true>), gridp, dim3(256), 0, st, a);
+        if (partials) {
+            if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true, true>), gridp, dim3(256), 0, st, a);
+            else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true>), gridp, dim3(256), 0, st, a);
+        } else if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true>), gridp, dim3(256), 0, st, a);
         else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true>), gridp, dim3(256), 0, st, a);
         return mvs_check_launch("conv2d_igemm (pixel pairs)");
     }
@@ -449,6 +488,22 @@ extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias,
     if (rc) return rc;
     MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_fwd: null pointer argument");
     return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
+}
+
+// Forward without bias that also emits BatchNorm partial sums of its output: partials [rows][2][Cout], rows = mvs_conv2d_stat_rows
+// (one per workgroup tile, the tiles of image n are rows [n*T, (n+1)*T)) -- the layout mvs_bn_group_relu_fwd_parts reads with one
+// statistics group per image (or per run of images).  ConvBnReLU of the 2-D extractor in training (module.py:15-22).
+extern "C" int mvs_conv2d_stat_rows(int N, int H, int W, int ks, int stride) {
+    if (!c2_shape_ok(ks, stride) || N < 1 || H < 1 || W < 1) return -1;
+    const int Ho = stride == 1 ? H : (H - 1) / 2 + 1, Wo = stride == 1 ? W : (W - 1) / 2 + 1;
+    return N * mvs_cdiv(Ho, 8) * mvs_cdiv(Wo, 32);
+}
+extern "C" int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, float* partials, int N, int H, int W,
+                                    int Cin, int Cout, int ks, int stride, hipStream_t stream) {
+    int rc = c2_check("conv2d_fwd_stats", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && w && y && ws && partials, MVS_ERR_NULL, "conv2d_fwd_stats: null pointer argument");
+    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, partials);
 }
 
 // the same followed by LeakyReLU(negative_slope): the `conv` block of the feature pyramid (jdacs-ms/models/modules.py:15-19,

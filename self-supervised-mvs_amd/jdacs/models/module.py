@@ -39,7 +39,12 @@ class ConvBnReLU(nn.Module):
     # SURVEY 8(f)-3, first cut: the convolution itself through csrc/conv2d.hip instead of MIOpen.  Parity-tested (CPU
     # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
     hip_conv = os.environ.get("MVS_HIP_FEATURE", "0") == "1"
-    split_bwd = os.environ.get("MVS_SPLIT_CONV2D_BWD", "1") != "0"   # with ops.set_async_wgrad(True): weight gradient of the MIOpen conv on the side stream
+    # with ops.set_async_wgrad(True): weight gradient of the library's 2-D convolution on the side stream (Conv2dSplitBwdFn).
+    # OFF by default since the end of round 3: a GPU comparison of two equivalent FeatureNet paths that both ran their 2-D weight
+    # gradients on the side stream disagreed (conv0.conv.weight, 60 % relative L1) while the same comparison with synchronous
+    # weight gradients passes (tests/test_gpu_parity.py::test_featurenet_training_hip_forward_with_fused_statistics) -- an
+    # unexplained ordering problem of the library's weight-gradient call on a second stream; the gain was 0.03-0.05 ms.
+    split_bwd = os.environ.get("MVS_SPLIT_CONV2D_BWD", "0") == "1"
     # Inference (eval mode, no autograd): BatchNorm's running statistics folded into the convolution's weights and bias, ReLU in
     # the same csrc/conv2d.hip pass -- no separate normalisation pass over the activation (jdacs/eval.py:143 runs the model
     # in eval mode under no_grad).  MVS_FOLD_EVAL_BN=0 keeps convolution and BatchNorm apart.
@@ -62,12 +67,18 @@ class ConvBnReLU(nn.Module):
             return ops.conv2d_forward(x, w, b, self.conv.stride[0], negative_slope=0.0)
         if self.hip_conv:
             y = conv2d_maybe_hip(self.conv, x)
-        elif (ops._ASYNC_WGRAD and self.split_bwd and x.is_cuda and self.training and torch.is_grad_enabled() and self.conv.bias is None
-              and self.conv.groups == 1 and self.conv.dilation == (1, 1)):
+        elif ((ops._ASYNC_WGRAD and self.split_bwd or self.hip_fwd_train) and x.is_cuda and self.training and torch.is_grad_enabled()
+              and self.conv.bias is None and self.conv.groups == 1 and self.conv.dilation == (1, 1)):
             # opt-in side-stream weight gradients (ops.set_async_wgrad): the library convolution with its backward issued as two calls
-            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding,
-                                           self.hip_fwd_train and hip_conv2d_serves(self.conv, x)
-                                           and x.is_contiguous(memory_format=torch.channels_last))
+            hip_fwd = (self.hip_fwd_train and hip_conv2d_serves(self.conv, x) and x.is_contiguous(memory_format=torch.channels_last))
+            if hip_fwd and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64) and self.bn.momentum is not None:
+                # convolution + BatchNorm statistics in one launch, then finalize + apply: no statistics pass over the activation
+                y, parts = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True)
+                for _ in range(groups):
+                    count_batch(self.bn, self.training)
+                return ops.BnReLUFn.apply(y, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, True,
+                                          self.bn.eps, self.bn.momentum, groups, parts)
+            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, hip_fwd)
         else:
             y = self.conv(x)
         bn = self.bn

@@ -657,21 +657,23 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, hip_forward=False):
+    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False):
         """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
-        the library's two calls."""
+        the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm partial rows of y), the rows not differentiable."""
         if ctx.needs_input_grad[1]:
             _note_weight_use(weight)
-        if hip_forward:
-            y = conv2d_forward(x, weight, None, stride[0])
-        else:
-            y = torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
-        return y
+        if hip_forward and want_stats:
+            y, parts = conv2d_forward(x, weight, None, stride[0], want_stats=True)
+            ctx.mark_non_differentiable(parts)
+            return y, parts
+        if hip_forward:
+            return conv2d_forward(x, weight, None, stride[0])
+        return torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_unused_grad_of_the_partial_rows):
         x, weight = ctx.saved_tensors
         stride, padding = ctx.cfg
         bwd = torch.ops.aten.convolution_backward
@@ -681,7 +683,7 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
             gw = _maybe_on_side_stream(fn, weight, (x, gy))
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 def _maybe_on_side_stream(fn, weight, inputs):
@@ -726,7 +728,9 @@ class BnReLUFn(torch.autograd.Function):
     updated chunk after chunk, i.e. exactly what `groups` successive BatchNorm calls do."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, groups):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, groups, parts=None):
+        """parts [rows,2,C] (train mode): partial sums of x already written by the convolution that produced it
+        (conv2d_forward(want_stats=True)), rows of a statistics group consecutive -- no statistics pass over x."""
         lib = _lib_for(x)
         st = _stream(x)
         c = x.shape[1]
@@ -739,8 +743,14 @@ class BnReLUFn(torch.autograd.Function):
         stats = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
         ws = torch.empty(groups * 512 * 2 * c, dtype=torch.float32, device=dev)
         y = torch.empty_like(x, memory_format=fmt)
-        lib.call("mvs_bn_group_relu_fwd", _p(x), groups, vg, c, _p(gamma), _p(beta), float(eps), float(momentum),
-                 _p(running_mean), _p(running_var), int(training), 1, _p(ws), _p(stats), _p(y), st)
+        if parts is not None and training:
+            if parts.shape[0] % groups or tuple(parts.shape[1:]) != (2, c):
+                raise ValueError("BatchNorm partial rows %s do not split into %d groups of [rows,2,%d]" % (tuple(parts.shape), groups, c))
+            lib.call("mvs_bn_group_relu_fwd_parts", _p(x), _p(parts.contiguous()), parts.shape[0] // groups, groups, vg, c, _p(gamma),
+                     _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), 1, _p(stats), _p(y), st)
+        else:
+            lib.call("mvs_bn_group_relu_fwd", _p(x), groups, vg, c, _p(gamma), _p(beta), float(eps), float(momentum),
+                     _p(running_mean), _p(running_var), int(training), 1, _p(ws), _p(stats), _p(y), st)
         ctx.save_for_backward(x, stats)
         ctx.cfg = (training, vg, c, fmt, groups)
         return y
@@ -758,7 +768,7 @@ class BnReLUFn(torch.autograd.Function):
         dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
         lib.call("mvs_bn_group_relu_bwd", _p(gy), _p(x), _p(stats), 1, groups, vg, c, _p(ws), _p(dx), _p(dgb[0]),
                  _p(dgb[1]), _stream(x))
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 class ConvBias3dFn(torch.autograd.Function):
@@ -920,9 +930,10 @@ def _c2_ws(lib, op, n, h, w, cin, cout, ks, stride, like):
     return torch.empty(nfl, dtype=torch.float32, device=like.device)
 
 
-def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None):
+def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False):
     """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last);
-    negative_slope: LeakyReLU fused after the bias."""
+    negative_slope: LeakyReLU fused after the bias.  want_stats (no bias / activation): -> (y, partials [rows,2,Cout]), the
+    BatchNorm partial sums of y written by the convolution's epilogue, rows of image n consecutive (BnReLUFn's ``parts``)."""
     lib = _lib_for(x)
     x = as_cl2(x)
     n, cin, h, w = x.shape
@@ -932,6 +943,14 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None):
     ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
     ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x)
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=CL2)
+    if want_stats:
+        if bias is not None or negative_slope is not None:
+            raise ValueError("conv2d_forward: statistics are those of the plain convolution (no bias / activation)")
+        rows = lib.raw("mvs_conv2d_stat_rows", n, h, w, ks, stride)
+        parts = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous()), _p(y), _p(ws), _p(parts), n, h, w, cin, cout, ks, stride,
+                 _stream(x), tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+        return y, parts
     if negative_slope is not None:
         lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
                  n, h, w, cin, cout, ks, stride, float(negative_slope), _stream(x), tag="fwd2d_lrelu:%d>%d:k%d:s%d" % (cin, cout, ks, stride))

@@ -1334,3 +1334,32 @@ def test_conv3d_probability_layer_four_outputs_per_thread(emul_lib, cin, dims, b
             assert float((gx - xr.grad).abs().max()) < 3e-4, knob
     finally:
         emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (11, 37)), (8, 8, 3, 1, (9, 35)), (8, 16, 5, 2, (18, 70)), (16, 16, 3, 1, (9, 33)),
+                                                    (16, 32, 5, 2, (17, 41)), (32, 32, 3, 1, (10, 20))])
+def test_conv2d_forward_with_batchnorm_partial_sums(emul_lib, cin, cout, ks, stride, hw):
+    """mvs_conv2d_fwd_stats (the convolution of a training-mode ConvBnReLU, module.py:15-22, with BatchNorm's statistics pass folded
+    into its epilogue) + mvs_bn_group_relu_fwd_parts: the convolution equals the plain kernel bit for bit, the partial rows sum to
+    the per-image channel sums (ragged images: tiles overhang), and BatchNorm + ReLU from the rows equals BatchNorm + ReLU with its
+    own statistics pass, running statistics included (3 images = 3 statistics groups)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 5 + cout + ks)
+    n = 3
+    x = torch.randn(n, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
+    y0 = ops.conv2d_forward(x, w, None, stride)
+    y, parts = ops.conv2d_forward(x, w, None, stride, want_stats=True)
+    assert torch.equal(y, y0)
+    assert parts.shape[0] % n == 0 and tuple(parts.shape[1:]) == (2, cout)
+    per_img = parts.view(n, -1, 2, cout).sum(1)
+    assert torch.allclose(per_img[:, 0], y.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(per_img[:, 1], (y * y).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
+    gamma, beta = 0.5 + torch.rand(cout, generator=g), torch.randn(cout, generator=g) * 0.2
+    rm_a, rv_a, rm_b, rv_b = torch.zeros(cout), torch.ones(cout), torch.zeros(cout), torch.ones(cout)
+    za = ops.BnReLUFn.apply(y, gamma, beta, rm_a, rv_a, True, 1e-5, 0.1, n)
+    zb = ops.BnReLUFn.apply(y, gamma, beta, rm_b, rv_b, True, 1e-5, 0.1, n, parts)
+    assert float((za - zb).abs().max()) < 1e-5 * max(1.0, float(za.abs().max()))
+    assert torch.allclose(rm_a, rm_b, rtol=1e-5, atol=1e-6) and torch.allclose(rv_a, rv_b, rtol=1e-5, atol=1e-6)
+    ref = torch.cat([F.relu(F.batch_norm(y[i:i + 1], None, None, gamma, beta, True, 0.1, 1e-5)) for i in range(n)], 0)
+    assert float((zb - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))

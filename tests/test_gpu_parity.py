@@ -966,6 +966,41 @@ def test_featurenet_hip_convs_vs_stock(dev):
         assert rel_l1(p.grad, q.grad) < 3e-2, k
 
 
+def test_featurenet_training_hip_forward_with_fused_statistics(dev):
+    """Opt-in training path of the 2-D extractor (ConvBnReLU.hip_fwd_train): forward convolution through csrc/conv2d.hip with
+    BatchNorm's partial sums written by its epilogue (mvs_conv2d_fwd_stats + mvs_bn_group_relu_fwd_parts), backward through the
+    library -- against the default path (library convolution + BatchNorm kernels with their own statistics pass): outputs,
+    parameter gradients and running statistics, 3 views 128x160."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models import module as MM
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(4)
+    a = FeatureNet().to(dev).train()
+    b = copy.deepcopy(a).train()
+    x = torch.randn(3, 3, 128, 160, device=dev).contiguous(memory_format=torch.channels_last)
+    old_flag, old_async, old_fused = MM.ConvBnReLU.hip_fwd_train, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
+    try:
+        ops.set_async_wgrad(False)            # synchronous weight gradients: the comparison is about the kernels
+        MM.ConvBnReLU.hip_fwd_train = False
+        yb = b(x, 3)
+        yb.square().mean().backward()
+        torch.cuda.synchronize()
+        MM.ConvBnReLU.hip_fwd_train = True
+        ya = a(x, 3)
+        ya.square().mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        MM.ConvBnReLU.hip_fwd_train = old_flag
+        ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED = old_async, old_fused
+    assert float((ya - yb).abs().max()) < 2e-3 * max(1.0, float(yb.abs().max()))
+    bad = {k: round(rel_l1(p.grad, q.grad), 4) for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
+           if not rel_l1(p.grad, q.grad) < 3e-2}
+    badbuf = [k for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers())
+              if u.dtype.is_floating_point and not torch.allclose(u, v, rtol=1e-3, atol=1e-4)]
+    assert not bad and not badbuf, (bad, badbuf)
+
+
 def test_featurenet_eval_folded_batchnorm_vs_stock(dev):
     """Inference FeatureNet (eval mode, no_grad): BatchNorm folded into the csrc/conv2d.hip convolutions (ConvBnReLU.fold_eval,
     the default) vs the unfolded path (MIOpen convolution + BatchNorm kernel) and vs the oracle's stock modules, 3 views 128x160
