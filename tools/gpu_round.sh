@@ -566,3 +566,16 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), d['final_loss'])" gpurun_out/bench_hipfwd$f.json
   done
 fi
+if [ "$what" = "r4a" ]; then
+  # first session of round 4: what round 3 built last and could not time -- the 2-D extractor's forward convolution through
+  # conv2d.hip with BatchNorm statistics in its epilogue (MVS_HIP_FEATURE_FWD), configs 2 and 3; then the 2-D side-stream
+  # mismatch (MVS_SPLIT_CONV2D_BWD=1 under the side-stream mode) as a parity question, not a timing one
+  MVS_SKIP_HEAVY=1 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "featurenet" > gpurun_out/pytest_r4a.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" gpurun_out/pytest_r4a.log | tail -4
+  for cfg in 2 3; do for f in 0 1; do
+    MVS_HIP_FEATURE_FWD=$f timeout 300 python bench.py --config $cfg --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --time-all-kernels > "gpurun_out/bench_c${cfg}_hipfwd$f.json" 2> "gpurun_out/bench_c${cfg}_hipfwd$f.err"
+    echo "config $cfg MVS_HIP_FEATURE_FWD=$f exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c${cfg}_hipfwd$f.json"; grep -E "fwd2d|bn_group" "gpurun_out/bench_c${cfg}_hipfwd$f.err" | head -10
+  done; done
+fi
