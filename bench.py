@@ -278,6 +278,11 @@ def main():
     ap.add_argument("--pmc", type=int, default=1,
                     help="1 (default, N=1 only): after the timed region run tools/pmc_driver.py under `rocprofv3 --pmc` (separate "
                          "FETCH_SIZE and WRITE_SIZE passes) to fill roofline.traffic; 0 or no rocprofv3 on PATH: traffic = null")
+    ap.add_argument("--ab", type=str, default="",
+                    help="interleaved A/B timing after the timed region (never the headline): ';'-separated toggles, each "
+                         "'feature_fwd' (2-D extractor's forward through conv2d.hip + fused BatchNorm statistics) or "
+                         "'<tuning key>=<value>' (mvs_set_tuning, against the library default); 5 pairs of --steps steps each")
+    ap.add_argument("--ab-reps", type=int, default=5)
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check (tests, no GPU needed): start the ranks, all-reduce one number over gloo, print it, exit")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -510,6 +515,41 @@ def main():
         ms_other_mode = float(tm.item()) / args.steps * 1e3
         _ops.set_async_wgrad(async_wgrad)
 
+    ab = {}
+    if args.ab and not graph_mode:
+        from mvs_amd.jdacs.models.module import ConvBnReLU
+        for spec in filter(None, args.ab.split(";")):
+            if spec == "feature_fwd":
+                base = ConvBnReLU.hip_fwd_train
+                def setter(on, base=base):
+                    ConvBnReLU.hip_fwd_train = (not base) if on else base
+            else:
+                key, _, val = spec.partition("=")
+                dflt = _lib.DEFAULT_TUNING.get(key)
+                if dflt is None:
+                    raise SystemExit("bench.py --ab: give the library default of '%s' in _lib.DEFAULT_TUNING first" % key)
+                def setter(on, key=key, val=int(val), dflt=dflt):
+                    lib.call("mvs_set_tuning", key.encode(), val if on else dflt)
+            times = ([], [])
+            for _ in range(args.ab_reps):
+                for on in (0, 1):
+                    setter(on)
+                    for _ in range(3):
+                        step()
+                    barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    barrier()
+                    times[on].append((time.perf_counter() - t1) / args.steps * 1e3)
+            setter(0)
+            med = [sorted(t)[len(t) // 2] for t in times]
+            ab[spec] = {"default_ms": [round(t, 4) for t in times[0]], "toggled_ms": [round(t, 4) for t in times[1]],
+                        "median_default_ms": round(med[0], 4), "median_toggled_ms": round(med[1], 4)}
+            if rank == 0:
+                sys.stderr.write("A/B %s: default %.3f ms/step, toggled %.3f ms/step (medians of %d interleaved runs)\n"
+                                 % (spec, med[0], med[1], args.ab_reps))
+
     if rank == 0:
         summ = timer.summary()
         kernels = {}
@@ -570,6 +610,8 @@ def main():
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }
+        if ab:
+            res["ab"] = ab
         if not args.no_cpu_baseline and world == 1 and args.config == 2:   # rank 0 at N=1 only (bench contract)
             try:
                 res["cpu_baseline"] = cpu_baseline(state0, 1)

@@ -94,31 +94,41 @@ int mvs_homo_warp_bwd(const float* grad_warped, const float* src, const float* r
  * ws: workspace of mvs_conv3d_workspace_bytes(op,...) bytes, 16-byte aligned.
  * Forward epilogue (any subset): scale&&shift -> y*scale[c]+shift[c] (folded eval BatchNorm);
  * shift only -> y+shift[c] (bias of the prob layer, mvsnet.py:63); relu; + skip (added AFTER the
- * ReLU, mvsnet.py:70-72); stat_partials != NULL -> also writes [rows][2][Cout] partial sums
- * (sum, sum of squares) of the RAW conv output for train-mode BatchNorm, rows = mvs_conv3d_stat_rows. */
+ * ReLU, mvsnet.py:70-72); stat_slots != NULL -> per-channel (sum, sum of squares) of the RAW conv output are
+ * added (fp64 atomics) into row (workgroup mod nslots) of stat_slots [nslots][2][Cout] for train-mode BatchNorm
+ * (module.py:39); the caller zeroes the rows, nslots is a power of two (mvs_bn_slots(Cout)); consumer: mvs_bn_relu_fwd_slots.
+ * ws_packed = 1: ws already holds this op's weight image (mvs_conv3d_pack_weights[_batch] for the same op and shape). */
 enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
        MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
 long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int W, int Cin, int Cout, int stride);
-int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin, int Cout, int stride);
+/* Write the MFMA-fragment weight image of a forward / input-gradient op into ws ahead of time -- one launch for one op, or ONE
+ * launch for a whole list (ops[n], w[n], ws[n], shapes[n][7] = B, D, H, W, Cin, Cout, stride): the regulariser packs all of its
+ * layers once per training step instead of once in front of every convolution. */
+int mvs_conv3d_pack_weights(int op, const float* w, float* ws, int B, int D, int H, int W, int Cin, int Cout, int stride,
+                            hipStream_t stream);
+int mvs_conv3d_pack_weights_batch(int n, const int* ops, const float* const* w, float* const* ws, const int* shapes,
+                                  hipStream_t stream);
 int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin, int Cout,
                    int stride, const float* scale, const float* shift, const float* skip, int relu,
-                   float* stat_partials, hipStream_t stream);
-int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W, int Cin,
-                     int Cout, int stride, hipStream_t stream);
-/* Input gradients with a summand: gx = d conv / dx + add (add [B,D,H,W,Cin] like gx, or NULL).  A tensor with two consumers -- the
- * U-Net skip connections, jdacs/models/mvsnet.py:70-72, jdacs-ms/models/network.py:71-72 -- receives its second gradient
- * contribution in the epilogue of the kernel that computes the first, instead of autograd's separate add pass over both. */
-int mvs_conv3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
-                         int Cin, int Cout, int stride, hipStream_t stream);
-int mvs_convT3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
-                          int Cin, int Cout, int stride, hipStream_t stream);
+                   double* stat_slots, int nslots, int ws_packed, hipStream_t stream);
+/* Input gradients: gx = d conv / dx (+ add: [B,D,H,W,Cin] like gx, or NULL).  A tensor with two consumers -- the U-Net skip
+ * connections, jdacs/models/mvsnet.py:70-72, jdacs-ms/models/network.py:71-72 -- receives its second gradient contribution in the
+ * epilogue of the kernel that computes the first, instead of autograd's separate add pass over both.
+ * bn_raw != NULL (like gx): x came out of a BatchNorm+ReLU block, x = relu(BatchNorm(bn_raw)) (+ skip), and gx is that block's
+ * COMPLETE output gradient: the epilogue also adds the block's backward statistics (sum dyh, sum dyh*xhat per channel; dyh = gx where
+ * the ReLU was active) into bn_slots [nslots][2][Cin] (fp64), from bn_stats [4][Cin] = mean, invstd, scale, shift of the block
+ * (backward of module.py:35-42) -- no separate reduction pass over (gx, bn_raw); consumer: mvs_bn_relu_bwd_slots. */
+int mvs_conv3d_dgrad(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W, int Cin,
+                     int Cout, int stride, const float* bn_raw, const float* bn_stats, double* bn_slots, int nslots, int ws_packed,
+                     hipStream_t stream);
 int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
                      int Cout, int stride, hipStream_t stream);
 int mvs_convT3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W, int Cin,
                     int Cout, int stride, const float* scale, const float* shift, const float* skip, int relu,
-                    float* stat_partials, hipStream_t stream);
-int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W, int Cin,
-                      int Cout, int stride, hipStream_t stream);
+                    double* stat_slots, int nslots, int ws_packed, hipStream_t stream);
+int mvs_convT3d_dgrad(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W, int Cin,
+                      int Cout, int stride, const float* bn_raw, const float* bn_stats, double* bn_slots, int nslots, int ws_packed,
+                      hipStream_t stream);
 int mvs_convT3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
                       int Cout, int stride, hipStream_t stream);
 
@@ -135,39 +145,35 @@ int mvs_conv3d_bf16_fwd(const void* x_bf16, const float* w, void* y, void* ws, i
                         int out_is_f32, hipStream_t stream);
 int mvs_cast_f32_bf16(const float* x, void* y_bf16, long long n, hipStream_t stream);   /* n % 4 == 0 */
 
-/* ---- BatchNorm3d (+ReLU, + post-ReLU skip add) on channels-last [V][C], V = B*D*H*W ------------
- * Replace nn.BatchNorm3d + F.relu of ConvBnReLU3D (module.py:35-42) and of the deconv blocks
- * (mvsnet.py:48-61).  C in {4,8,16,32,64}. */
-int mvs_bn_reduce_blocks(void);   /* max rows mvs_bn_stats writes (1024) */
-int mvs_bn_stats(const float* x, long long V, int C, float* partials, int* nparts_out, hipStream_t stream);
-/* partials [nparts][2][C] -> mean, invstd (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale;
- * running stats (may be NULL) updated with `momentum` and the unbiased variance (PyTorch defaults). */
-int mvs_bn_finalize(const float* partials, int nparts, int C, long long count, const float* gamma, const float* beta,
-                    float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                    float* scale, float* shift, hipStream_t stream);
+/* ---- BatchNorm3d / BatchNorm2d (+ReLU, + post-ReLU skip add) on channels-last [V][C] -----------
+ * Replace nn.BatchNorm3d + F.relu of ConvBnReLU3D (module.py:35-42) and of the deconv blocks (mvsnet.py:48-61), and
+ * nn.BatchNorm2d + F.relu of the 2-D ConvBnReLU (module.py:15-22).  C in {4,8,16,32,64}.
+ * Train mode works on "statistic slots": nslots rows [2][C] of fp64 accumulators per statistics group, zeroed by the caller,
+ * into which the PRODUCER of the tensor adds per-workgroup sums -- a convolution epilogue (mvs_conv3d_fwd / mvs_convT3d_fwd /
+ * mvs_conv2d_fwd_stats; backward: mvs_conv3d_dgrad / mvs_convT3d_dgrad with bn_raw) or the stand-alone passes below -- and which
+ * the APPLY kernel finishes in the prologue of every workgroup (no finalize launch in between).
+ * G statistics groups of Vg contiguous rows each share the affine parameters; the running statistics are updated group after
+ * group == G successive BatchNorm calls: the N views of a sample go through the shared-weight feature extractor as one batch
+ * (jdacs/models/mvsnet.py:115) with the reference's per-view statistics.  slots [G][nslots][2][C]; stats [G][4][C] = mean, invstd
+ * (biased variance, eps), scale = gamma*invstd, shift = beta - mean*scale (written by the forward, read by the backward). */
+int mvs_bn_slots(int C);   /* recommended nslots (power of two; 16 KB of accumulators per group) */
+int mvs_bn_stats_slots(const float* x, int G, long long Vg, int C, double* slots, int nslots, hipStream_t stream);
+/* y = relu?(BatchNorm_train(x)) (+ skip); running_mean / running_var (both or neither NULL) updated with `momentum` and the
+ * unbiased variance (PyTorch defaults) */
+int mvs_bn_relu_fwd_slots(const float* x, const double* slots, int nslots, int G, long long Vg, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          const float* skip, int relu, float* stats, float* y, hipStream_t stream);
+/* backward statistics (sum dyh, sum dyh*xhat) of dy = grad w.r.t. relu?(bn(x)) into slots, when no input-gradient epilogue did */
+int mvs_bn_bwd_reduce_slots(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg, int C,
+                            double* slots, int nslots, hipStream_t stream);
+/* dx [G*Vg][C] = BatchNorm+ReLU backward of dy given the slots; dgamma [C], dbeta [C] (summed over the groups; may be NULL) */
+int mvs_bn_relu_bwd_slots(const float* dy, const float* x, const float* stats, const double* slots, int nslots, int relu, int G,
+                          long long Vg, int C, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
 int mvs_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, int C, float* scale, float* shift, hipStream_t stream);
 /* y = relu?(x*scale+shift) (+ skip) */
 int mvs_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, int relu, long long V,
                     int C, float* y, hipStream_t stream);
-/* dy = grad w.r.t. relu(bn(x)); ws >= (1024*2*C + 2*C) floats; outputs dx [V][C], dgamma [C], dbeta [C] */
-int mvs_bn_relu_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* scale,
-                    const float* shift, int relu, long long V, int C, float* ws, float* dx, float* dgamma,
-                    float* dbeta, hipStream_t stream);
-
-/* Grouped BatchNorm(+ReLU): G independent statistics groups of Vg contiguous rows each, shared affine parameters,
- * running statistics updated group after group == G successive nn.BatchNorm2d calls.  Lets the N views of a
- * sample go through the shared-weight feature extractor as one batch (jdacs/models/mvsnet.py:115) with the
- * reference's per-view statistics.  stats [G][4][C]; ws: fwd >= G*512*2*C floats, bwd >= G*512*2*C + G*2*C. */
-int mvs_bn_group_relu_fwd(const float* x, int G, long long Vg, int C, const float* gamma, const float* beta, float eps,
-                          float momentum, float* running_mean, float* running_var, int training, int relu, float* ws,
-                          float* stats, float* y, hipStream_t stream);
-/* train-mode mvs_bn_group_relu_fwd with the partial sums already computed (by mvs_conv2d_fwd_stats): partials [G][nparts][2][C] */
-int mvs_bn_group_relu_fwd_parts(const float* x, const float* partials, int nparts, int G, long long Vg, int C,
-                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                                float* running_var, int relu, float* stats, float* y, hipStream_t stream);
-int mvs_bn_group_relu_bwd(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg, int C,
-                          float* ws, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
 
 /* ---- K9/K10: softmax over depth + soft-argmin regression + photometric confidence --------------
  * Replace F.softmax(dim=1) + depth_regression + the pad/avg_pool3d/gather confidence:
@@ -218,12 +224,11 @@ int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int Cout, int ks, int stride, hipStream_t stream);
 /* conv2d + bias + LeakyReLU(negative_slope) in one pass: the `conv` block of the CVP feature pyramid
  * (jdacs-ms/models/modules.py:15-19, network.py:16-41; widths 3/16/32/64).  Channels: 1..32 or exactly 64. */
-/* conv2d forward (no bias) that also writes BatchNorm partial sums of its output: partials [rows][2][Cout] with
- * rows = mvs_conv2d_stat_rows (one per workgroup tile; image n owns rows [n*T, (n+1)*T)), read by mvs_bn_group_relu_fwd_parts.
+/* conv2d forward (no bias) that also adds BatchNorm's statistics of its output into slots [G][nslots][2][Cout] (fp64, zeroed by
+ * the caller): the N images are G statistics groups of N/G consecutive images; consumer: mvs_bn_relu_fwd_slots.
  * The convolution + statistics half of ConvBnReLU in training (jdacs/models/module.py:15-22). */
-int mvs_conv2d_stat_rows(int N, int H, int W, int ks, int stride);
-int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, float* partials, int N, int H, int W, int Cin,
-                         int Cout, int ks, int stride, hipStream_t stream);
+int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, double* slots, int nslots, int G, int N, int H,
+                         int W, int Cin, int Cout, int ks, int stride, hipStream_t stream);
 int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, float negative_slope, hipStream_t stream);
 int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,

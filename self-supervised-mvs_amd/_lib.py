@@ -33,31 +33,27 @@ SIGNATURES = {
     "mvs_homo_warp_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_homo_warp_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_conv3d_workspace_bytes": (_ll, [_i] * 8),
-    "mvs_conv3d_stat_rows": (_i, [_i] * 8),
-    "mvs_conv3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
-    "mvs_conv3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
-    "mvs_conv3d_dgrad_acc": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
-    "mvs_convT3d_dgrad_acc": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv3d_pack_weights": (_i, [_i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv3d_pack_weights_batch": (_i, [_i, C.POINTER(_i), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_i), _s]),
+    "mvs_conv3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _i, _i, _s]),
+    "mvs_conv3d_dgrad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _s]),
     "mvs_conv3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
-    "mvs_convT3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _s]),
-    "mvs_convT3d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_convT3d_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _i, _i, _s]),
+    "mvs_convT3d_dgrad": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _s]),
     "mvs_convT3d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
-    "mvs_bn_reduce_blocks": (_i, []),
-    "mvs_bn_stats": (_i, [_f, _ll, _i, _f, C.POINTER(_i), _s]),
-    "mvs_bn_finalize": (_i, [_f, _i, _i, _ll, _f, _f, _fl, _fl, _f, _f, _f, _f, _f, _f, _s]),
+    "mvs_bn_slots": (_i, [_i]),
+    "mvs_bn_stats_slots": (_i, [_f, _i, _ll, _i, _f, _i, _s]),
+    "mvs_bn_relu_fwd_slots": (_i, [_f, _f, _i, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _f, _i, _f, _f, _s]),
+    "mvs_bn_bwd_reduce_slots": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _i, _s]),
+    "mvs_bn_relu_bwd_slots": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _i, _f, _f, _f, _s]),
     "mvs_bn_eval_affine": (_i, [_f, _f, _f, _f, _fl, _i, _f, _f, _s]),
     "mvs_bn_relu_fwd": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _s]),
-    "mvs_bn_relu_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f, _f, _f, _s]),
-    "mvs_bn_group_relu_fwd": (_i, [_f, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _i, _i, _f, _f, _f, _s]),
-    "mvs_bn_group_relu_fwd_parts": (_i, [_f, _f, _i, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _i, _f, _f, _s]),
-    "mvs_bn_group_relu_bwd": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "mvs_conv2d_workspace_floats": (_ll, [_i] * 8),
     "mvs_conv2d_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_lrelu_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
-    "mvs_conv2d_stat_rows": (_i, [_i, _i, _i, _i, _i]),
-    "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),

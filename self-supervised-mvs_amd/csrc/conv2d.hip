@@ -23,7 +23,8 @@ struct Conv2dArgs {
     int os, py, px, YH, YW;             // output pixel of grid point (oy,ox) is (oy*os + py, ox*os + px) of a YH x YW map
     int act;                            // 1: LeakyReLU(slope) after the bias (jdacs-ms/models/modules.py:15-19)
     float slope;
-    float* partials;                    // STATS kernels: [tile][2][Cout] (sum, sum of squares of the workgroup's outputs)
+    double* slots;                      // STATS kernels: BatchNorm statistic slots [group][nslots][2][Cout] (fp64 atomics, bn.hip):
+    int nslots, imgs_per_group;         //   (sum, sum of squares) of the workgroup's outputs -> slot row (workgroup mod nslots) of image n's group
 };
 
 template <int KS, int S>
@@ -73,10 +74,9 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restric
     wp[idx] = v;
 }
 
-// STATS: the workgroup also writes the per-channel sum and sum of squares of its outputs as one row of a.partials -- BatchNorm's
-// statistics pass folded into the convolution that produces its input, like the 3-D kernels' epilogue (rows of an image are
-// consecutive: [N][tiles per image][2][Cout] is the grouped BatchNorm's partial layout).  Separate instantiations: the plain
-// kernels' code and register allocation do not change.
+// STATS: the workgroup also adds the per-channel sum and sum of squares of its outputs into a BatchNorm statistic slot row of its
+// image's statistics group -- BatchNorm's statistics pass folded into the convolution that produces its input, like the 3-D
+// kernels' epilogue.  Separate instantiations: the plain kernels' code and register allocation do not change.
 template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
                 if (PP) t += red[(k * NB * 16 + col + 8) * 2 + stat];
             }
             const int co = PP ? col : nb0 * 16 + col;
-            if (co < a.Cout) a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] = t;
+            if (co < a.Cout)
+                MVS_GLOBAL_ATOMIC_ADD_F64(a.slots + (((size_t)(n / a.imgs_per_group) * a.nslots + (blockIdx.x & (a.nslots - 1))) * 2 + stat) * a.Cout + co,
+                                          (double)t);
         }
     }
 }
@@ -425,7 +427,7 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
 
 template <int KS, int S, int CC>
 static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
-    if (a.partials) {
+    if (a.slots) {
         if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true>), grid, dim3(256), 0, st, a);
         else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true>), grid, dim3(256), 0, st, a);
         return;
@@ -436,9 +438,9 @@ static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
                         int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
-                        float* partials = nullptr) {
+                        double* slots = nullptr, int nslots = 0, int imgs_per_group = 1) {
     Conv2dArgs a = {};
-    a.act = act; a.slope = slope; a.partials = partials;
+    a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
     a.os = 1; a.py = 0; a.px = 0; a.YH = a.Ho; a.YW = a.Wo;
@@ -451,7 +453,7 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
         MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
-        if (partials) {
+        if (slots) {
             if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true, true>), gridp, dim3(256), 0, st, a);
             else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true>), gridp, dim3(256), 0, st, a);
         } else if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true>), gridp, dim3(256), 0, st, a);
@@ -490,20 +492,18 @@ extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias,
     return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
 }
 
-// Forward without bias that also emits BatchNorm partial sums of its output: partials [rows][2][Cout], rows = mvs_conv2d_stat_rows
-// (one per workgroup tile, the tiles of image n are rows [n*T, (n+1)*T)) -- the layout mvs_bn_group_relu_fwd_parts reads with one
-// statistics group per image (or per run of images).  ConvBnReLU of the 2-D extractor in training (module.py:15-22).
-extern "C" int mvs_conv2d_stat_rows(int N, int H, int W, int ks, int stride) {
-    if (!c2_shape_ok(ks, stride) || N < 1 || H < 1 || W < 1) return -1;
-    const int Ho = stride == 1 ? H : (H - 1) / 2 + 1, Wo = stride == 1 ? W : (W - 1) / 2 + 1;
-    return N * mvs_cdiv(Ho, 8) * mvs_cdiv(Wo, 32);
-}
-extern "C" int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, float* partials, int N, int H, int W,
-                                    int Cin, int Cout, int ks, int stride, hipStream_t stream) {
+// Forward without bias that also adds BatchNorm's statistics of its output into slots [G][nslots][2][Cout] (fp64, zeroed by the
+// caller; nslots a power of two, e.g. mvs_bn_slots(Cout)): the N images are G statistics groups of N/G consecutive images (the
+// views of a sample through the shared-weight extractor).  ConvBnReLU of the 2-D extractor in training (module.py:15-22);
+// consumer: mvs_bn_relu_fwd_slots.
+extern "C" int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, double* slots, int nslots, int G, int N,
+                                    int H, int W, int Cin, int Cout, int ks, int stride, hipStream_t stream) {
     int rc = c2_check("conv2d_fwd_stats", N, H, W, Cin, Cout, ks, stride);
     if (rc) return rc;
-    MVS_REQUIRE(x && w && y && ws && partials, MVS_ERR_NULL, "conv2d_fwd_stats: null pointer argument");
-    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, partials);
+    MVS_REQUIRE(x && w && y && ws && slots, MVS_ERR_NULL, "conv2d_fwd_stats: null pointer argument");
+    MVS_REQUIRE(G >= 1 && N % G == 0 && nslots >= 1 && nslots <= 256 && (nslots & (nslots - 1)) == 0, MVS_ERR_SHAPE,
+                "conv2d_fwd_stats: %d images do not split into %d groups, or bad slot count %d", N, G, nslots);
+    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, slots, nslots, N / G);
 }
 
 // the same followed by LeakyReLU(negative_slope): the `conv` block of the feature pyramid (jdacs-ms/models/modules.py:15-19,

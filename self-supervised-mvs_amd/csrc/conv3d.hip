@@ -15,9 +15,9 @@
 #include "mvs_rt.h"
 #include "conv_map.h"
 
-// tuning knob "cout1_d4": the Cout = 1 layer with four outputs per thread -- bit 0: the fp32 forward and input gradient
-// (measured, profiles/r03_run16_*: forward 0.089 -> 0.091 ms, 16 channels 0.331 -> 0.473, input gradient 0.083 -> 0.107: the
-// smaller LDS traffic does not pay for 1-2 waves per SIMD -- off), bit 1: the bf16 inference forward (0.426 -> 0.368 ms -- on)
+// tuning knob "cout1_d4", bit 1: the Cout = 1 layer of the bf16 inference path with four outputs per thread (conv3d_bf16.hip:
+// 0.426 -> 0.368 ms -- on).  The fp32 forms of the same idea (bit 0 in round 3) measured slower (profiles/r03_run16_*: forward
+// 0.089 -> 0.091 ms, 16 channels 0.331 -> 0.473, input gradient 0.083 -> 0.107) and were removed in round 4.
 int g_conv_cout1_d4 = 2;
 
 extern int g_conv_split, g_conv_small, g_conv_small_wgs, g_conv_tr2pw;
@@ -29,7 +29,12 @@ struct ConvArgs {
     const float* scale;     // [Cout] or null
     const float* shift;     // [Cout] or null (bias when scale == null)
     const float* skip;      // like y, or null (added after the ReLU)
-    float* partials;        // [numWG][2][Cout] or null
+    double* slots;          // BatchNorm statistic slots [nslots][2][Cout] (fp64 atomics, bn.hip) or null: per channel (sum y, sum y^2)
+                            // of the RAW output -- or, with bn_raw, (sum dyh, sum dyh*xhat) of the BatchNorm+ReLU block whose output
+                            // gradient this kernel writes (y = an input gradient incl. the `skip` summand)
+    int nslots;             // power of two
+    const float* bn_raw;    // like y: that block's raw (pre-BatchNorm) output, or null
+    const float* bn_stats;  // [4][Cout]: its mean, invstd, scale, shift
     int relu;
     int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout;
     int QD, QH, QW;         // coarse-grid extents
@@ -40,11 +45,8 @@ struct ConvArgs {
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                                int geom, int CC, int Cin, int Cout, int NB,
-                                                                int layout, int flip, int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void conv_pack_weights_item(const float* __restrict__ w, float* __restrict__ wp, int geom, int CC,
+                                                       int Cin, int Cout, int NB, int layout, int flip, int idx) {
     const int j = idx & 3, lane = (idx >> 2) & 63;
     const int nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
     const int co = nb * 16 + (lane & 15);
@@ -105,6 +107,32 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     wp[idx] = v;
 }
 
+
+
+// One launch packs the weight images of a whole list of layers (blockIdx.y = list entry): the regulariser packs the images of
+// its 10 forward and 10 input-gradient convolutions ONCE per training step (rounds 1-3: one 5-us launch in front of every
+// convolution, 19 per step -- profiles/r03_final_rocprofv3_kernel_stats.csv).  kind 0: implicit-GEMM image, kind 1: the
+// [tap][co] table of the Cin == 1 direct kernel (wt[t][co] = W[0][co][26 - t]; W is [1][C][3][3][3]).
+struct PackItem {
+    const float* w;
+    float* wp;
+    int kind, geom, CC, Cin, Cout, NB, layout, flip, total;
+};
+#define MVS_PACK_BATCH_MAX 24
+struct PackBatch {
+    PackItem it[MVS_PACK_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(PackBatch pb) {
+    const PackItem& p = pb.it[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    if (p.kind == 1) {
+        const int t = idx / p.Cout, c = idx % p.Cout;
+        p.wp[idx] = p.w[(size_t)c * 27 + (26 - t)];
+    } else {
+        conv_pack_weights_item(p.w, p.wp, p.geom, p.CC, p.Cin, p.Cout, p.NB, p.layout, p.flip, idx);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
@@ -179,10 +207,7 @@ __device__ __forceinline__ void stage_batched(float* __restrict__ lds, int tid, 
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM forward-style kernel (conv s1/s2, transposed s2; dgrads map onto these)
 // ------------------------------------------------------------------------------------------------
-// FS (fast staging, tuning knob "fs", not the default -- written after the Cout = 8 kernels gained 15 % from the same recipe,
-// not yet measured here): tiles whose halo lies inside the volume skip the six bounds compares and the zero fill per float4
-// and address the halo relative to one tile base pointer.
-template <int GEOM, int CC, int NB, bool FS = false>
+template <int GEOM, int CC, int NB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     using G = ConvGeom<GEOM>;
     constexpr int CCP = CC + 4;
@@ -246,8 +271,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     f32x4 acc[MB][NB];
     float st1[NB], st2[NB];
+    float bmu[NB], bis[NB], bsc[NB], bsh[NB];   // bn_raw: mean, invstd, scale, shift of the lane's output channel(s)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { st1[nb] = 0.f; st2[nb] = 0.f; }
+    for (int nb = 0; nb < NB; ++nb) {
+        st1[nb] = 0.f; st2[nb] = 0.f;
+        bmu[nb] = bis[nb] = bsc[nb] = bsh[nb] = 0.f;
+        if (a.bn_raw) {
+            const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
+            if (co < a.Cout) { bmu[nb] = a.bn_stats[co]; bis[nb] = a.bn_stats[a.Cout + co]; bsc[nb] = a.bn_stats[2 * a.Cout + co]; bsh[nb] = a.bn_stats[3 * a.Cout + co]; }
+        }
+    }
 
     const int nchunks = G::BASE == GEOM_TR2 ? 1 : a.Cin / CC;
     const int KSF = ksteps_for(27, CC);
@@ -262,16 +295,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (cls == 0) {
                 // ---- stage the input halo region (channels [chunk*CC, +CC)) into LDS ----
                 __syncthreads();
-                const int id0 = qd0 * G::IS - G::PAD, ih0 = qh0 * G::IS - G::PAD, iw0 = qw0 * G::IS - G::PAD;
-                if (FS && id0 >= 0 && id0 + G::RD <= a.Di && ih0 >= 0 && ih0 + G::RH <= a.Hi && iw0 >= 0 && iw0 + G::RW <= a.Wi) {
-                    const float* __restrict__ base = a.x + ((((size_t)b * a.Di + id0) * a.Hi + ih0) * a.Wi + iw0) * a.Cin + chunk * CC;
-                    stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
-                        const int vox = i / CQ, cq = i % CQ;
-                        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
-                        o = vox * CCP + 4 * cq;
-                        src = base + ((rd * a.Hi + rh) * a.Wi + rw) * a.Cin + 4 * cq;
-                    });
-                } else
                 stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
                     const int vox = i / CQ, cq = i % CQ;
                     const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
@@ -365,20 +388,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
                     if (co >= a.Cout) continue;
                     float v = acc[mb][nb][r];
-                    st1[nb] += v;
-                    st2[nb] += v * v;
+                    float sv1 = v, sv2 = v * v;
                     if (a.scale) v = v * a.scale[co] + a.shift[co];
                     else if (a.shift) v = v + a.shift[co];
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (a.skip) v += a.skip[obase + co];
+                    if (a.bn_raw) {
+                        // v is the complete output gradient of a BatchNorm+ReLU block at this voxel: its backward statistics
+                        const float rw = a.bn_raw[obase + co];
+                        sv1 = (rw * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
+                        sv2 = sv1 * ((rw - bmu[nb]) * bis[nb]);
+                    }
+                    st1[nb] += sv1;
+                    st2[nb] += sv2;
                     a.y[obase + co] = v;
                 }
             }
         }
     }
 
-    if (a.partials) {
-        // reduce the 4 lane groups of the wave, then the 4 waves, -> partials[block][2][Cout]
+    if (a.slots) {
+        // reduce the 4 lane groups of the wave, then the 4 waves, -> one slot row [2][Cout] (fp64 atomics)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             float s1 = st1[nb], s2 = st2[nb];
@@ -396,200 +426,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (nb0 * 16 + n < a.Cout) {
                 float s = 0.f;
                 for (int w = 0; w < 4; ++w) s += red[(w * NB * 16 + n) * 2 + stat];
-                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + nb0 * 16 + n] = s;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stride-1 implicit GEMM with PERSISTENT workgroups (round 3; layers with many tiles: conv0's input gradient, the 16->16 layers at
-// L1, CVP's full-resolution layers).  The one-tile-per-workgroup kernel above exposes every tile's halo staging (global -> registers
-// -> LDS, ~2 us of latency) to the MFMA pipe unless another resident workgroup happens to be in its k-loop, and the last round of a
-// launch runs half empty (1920 tiles on 768 slots).  Here a workgroup walks tiles t, t + G, t + 2G, ... in the XCD-aware brick order
-// and keeps the NEXT chunk's / tile's halo in flight in registers while the MFMAs of the current chunk run (the recipe of the
-// Cout = 8 kernels below: 15 % there).  Same arithmetic and the same k-order as conv_igemm_kernel<GEOM_S1>: bit-identical output,
-// one BatchNorm partial row per TILE (not per workgroup) so that the statistics buffer is the same.
-// ------------------------------------------------------------------------------------------------
-template <int CC, int NB>
-__global__ __launch_bounds__(256) MVS_MIN_WAVES_PER_SIMD((NB == 4 ? 2 : 3)) void conv_igemm_s1p_kernel(ConvArgs a, int xcd) {
-    using G = ConvGeom<GEOM_S1>;
-    constexpr int CCP = CC + 4, CQ = CC / 4, MB = G::MB;
-    constexpr int NR = G::RD * G::RH * G::RW;
-    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
-    __shared__ int tapoff[32];
-    __shared__ float red[4 * NB * 16 * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
-    const int vb = xcd ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    if (tid < 32) tapoff[tid] = tid < 27 ? (((tid / 9) * G::RH + (tid / 3) % 3) * G::RW + tid % 3) * CCP : 0;
-    int baseA[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int f = wave * MB + mb;
-        baseA[mb] = (((f / G::TQH) * G::RH + f % G::TQH) * G::RW + l15) * CCP;
-    }
-    auto tile_origin = [&](int t, int& b, int& qd0, int& qh0, int& qw0) {
-        int td, th, tw;
-        if (xcd) brick_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
-        else linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
-        qd0 = td * G::TQD; qh0 = th * G::TQH; qw0 = tw * G::TQW;
-    };
-    // halo tile -> registers (all loads issued back to back; zero outside the volume), registers -> LDS; the offset of item k relative
-    // to the tile's origin voxel does not depend on the tile; interior tiles skip the per-item bounds checks
-    constexpr int XIT = (NR * CQ + 255) / 256;
-    float4 xv[XIT];
-    // (the offsets are recomputed per chunk: a dozen integer operations per item against 11 registers held across the MFMA loop)
-    auto rel_of = [&](int i) {
-        const int vox = i / CQ, cq = i % CQ;
-        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
-        return (((rd - 1) * a.Hi + (rh - 1)) * a.Wi + (rw - 1)) * a.Cin + 4 * cq;
-    };
-    auto load_chunk = [&](int b, int qd0, int qh0, int qw0, int chunk) {
-        const float* __restrict__ base = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.Cin + chunk * CC;
-        const bool interior = qd0 >= 1 && qd0 + G::TQD + 1 <= a.Di && qh0 >= 1 && qh0 + G::TQH + 1 <= a.Hi &&
-                              qw0 >= 1 && qw0 + G::TQW + 1 <= a.Wi;
-        if (interior) {
-#pragma unroll
-            for (int k = 0; k < XIT; ++k)
-                if (tid + 256 * k < NR * CQ) xv[k] = *reinterpret_cast<const float4*>(base + rel_of(tid + 256 * k));
-        } else {
-#pragma unroll
-            for (int k = 0; k < XIT; ++k) {
-                const int i = tid + 256 * k;
-                xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < NR * CQ) {
-                    const int vox = i / CQ;
-                    const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
-                    const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-                    if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                        xv[k] = *reinterpret_cast<const float4*>(base + rel_of(i));
-                }
-            }
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int k = 0; k < XIT; ++k) {
-            const int i = tid + 256 * k;
-            if (i < NR * CQ) *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = xv[k];
-        }
-    };
-    const int nchunks = a.Cin / CC;
-    const int KS = ksteps_for(27, CC);
-    int b, qd0, qh0, qw0;
-    if (vb < ntiles) {
-        tile_origin(vb, b, qd0, qh0, qw0);
-        load_chunk(b, qd0, qh0, qw0, 0);
-    }
-    for (int t = vb; t < ntiles; t += gridDim.x) {
-        tile_origin(t, b, qd0, qh0, qw0);
-        f32x4 acc[MB][NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            __syncthreads();                                   // the previous chunk's / tile's reads of the LDS image are done
-            store_chunk();
-            __syncthreads();
-            if (chunk + 1 < nchunks) load_chunk(b, qd0, qh0, qw0, chunk + 1);      // in flight while this chunk's MFMAs run
-            else if (t + (int)gridDim.x < ntiles) {
-                int b2, d2, h2, w2;
-                tile_origin(t + gridDim.x, b2, d2, h2, w2);
-                load_chunk(b2, d2, h2, w2, 0);
-            }
-            const int kk0 = chunk * KS;
-            constexpr int PD = 2;                              // weight fragments PD k-steps ahead (see conv_igemm_kernel)
-            float4 bq[PD][NB], af[MB];
-            auto load_b = [&](int ks, float4 (&dst)[NB]) {
-                const int kc = ks < KS ? ks : KS - 1;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    dst[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(kk0 + kc) * a.nb_total + nb) * 64 + lane) * 4);
-            };
-            auto load_a = [&](int ks, float4 (&dst)[MB]) {
-                const int kc = ks < KS ? ks : KS - 1;
-                const int kflat = 16 * kc + 4 * g;
-                const int aoff = tapoff[kflat / CC] + kflat % CC;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) dst[mb] = *reinterpret_cast<const float4*>(&tile[baseA[mb] + aoff]);
-            };
-#pragma unroll
-            for (int u = 0; u < PD; ++u) load_b(u, bq[u]);
-            load_a(0, af);
-            for (int ks0 = 0; ks0 < KS; ks0 += PD) {
-#pragma unroll
-                for (int u = 0; u < PD; ++u) {
-                    const int ks = ks0 + u;
-                    if (ks < KS) {
-                        float4 an[MB];
-                        load_a(ks + 1, an);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) {
-                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
-                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bq[u][nb].y, acc[mb][nb]);
-                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bq[u][nb].z, acc[mb][nb]);
-                                acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bq[u][nb].w, acc[mb][nb]);
-                            }
-                        load_b(ks + PD, bq[u]);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) af[mb] = an[mb];
-                    }
-                }
-            }
-        }
-        // ---- epilogue: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
-        float st1[NB], st2[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { st1[nb] = 0.f; st2[nb] = 0.f; }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int f = wave * MB + mb;
-            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
-            if (qd >= a.QD || qh >= a.QH) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qw = qw0 + 4 * g + r;
-                if (qw >= a.QW) continue;
-                const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int co = nb * 16 + l15;
-                    if (co >= a.Cout) continue;
-                    float v = acc[mb][nb][r];
-                    st1[nb] += v;
-                    st2[nb] += v * v;
-                    if (a.scale) v = v * a.scale[co] + a.shift[co];
-                    else if (a.shift) v = v + a.shift[co];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.skip) v += a.skip[obase + co];
-                    a.y[obase + co] = v;
-                }
-            }
-        }
-        if (a.partials) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float s1 = st1[nb], s2 = st2[nb];
-                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-                if (lane < 16) {
-                    red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
-                    red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
-                }
-            }
-            __syncthreads();
-            if (tid < 2 * NB * 16) {
-                const int stat = tid / (NB * 16), n = tid % (NB * 16);
-                if (n < a.Cout) {
-                    float sm = 0.f;
-                    for (int w = 0; w < 4; ++w) sm += red[(w * NB * 16 + n) * 2 + stat];
-                    a.partials[((size_t)t * 2 + stat) * a.Cout + n] = sm;
-                }
+                MVS_GLOBAL_ATOMIC_ADD_F64(a.slots + ((size_t)(blockIdx.x & (a.nslots - 1)) * 2 + stat) * a.Cout + nb0 * 16 + n, (double)s);
             }
         }
     }
@@ -601,93 +438,62 @@ __global__ __launch_bounds__(256) MVS_MIN_WAVES_PER_SIMD((NB == 4 ? 2 : 3)) void
 // ------------------------------------------------------------------------------------------------
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                        float* __restrict__ y, int B, int D, int H, int W) {
+                                                        float* __restrict__ y, int B, int D, int H, int W,
+                                                        const float* __restrict__ bn_raw, const float* __restrict__ bn_stats,
+                                                        double* __restrict__ slots, int nslots) {
     __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+    __shared__ float red[4 * 2 * COUT];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = wt[i];
     __syncthreads();
     const size_t total = (size_t)B * D * H * W;
     const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= total) return;
-    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
+    const bool live = v < total;
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-    for (int t = 0; t < 27; ++t) {
-        const int dd = d_ + t / 9 - 1, hh = h_ + (t / 3) % 3 - 1, ww = w_ + t % 3 - 1;
-        if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-        const float xv = x[v + ((long long)(t / 9 - 1) * H + ((t / 3) % 3 - 1)) * W + (t % 3 - 1)];
+    if (live) {
+        const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
+        for (int t = 0; t < 27; ++t) {
+            const int dd = d_ + t / 9 - 1, hh = h_ + (t / 3) % 3 - 1, ww = w_ + t % 3 - 1;
+            if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const float xv = x[v + ((long long)(t / 9 - 1) * H + ((t / 3) % 3 - 1)) * W + (t % 3 - 1)];
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xv, ws[t * COUT + c], acc[c]);
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xv, ws[t * COUT + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4)
+            *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
     }
+    if (slots) {
+        // y is the complete output gradient of the BatchNorm+ReLU block in front of this layer (bn_raw = that block's raw
+        // output): its backward statistics (sum dyh, sum dyh*xhat) per channel -> wave sums -> workgroup sums -> one slot row
+        float sv[2 * COUT];
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4)
-        *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-}
-
-// The same with a column of FOUR depth slices per thread (knob "cout1_d4"): each of the 6 x 9 input values under the column is
-// loaded once and feeds up to three outputs; the 27 taps are unrolled, the bounds tests are three small per-axis tables instead of
-// six compares per tap, and the weights are read at compile-time offsets of a kernel-argument pointer (scalar loads, SGPR operands
-// of the FMAs) instead of two LDS reads per tap.
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_cin1_d4_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                           float* __restrict__ y, int B, int D, int H, int W) {
-    const int D4 = (D + 3) / 4;
-    const size_t total = (size_t)B * D4 * H * W;
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= total) return;
-    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), dq = (int)((v / ((size_t)W * H)) % D4), b = (int)(v / ((size_t)W * H * D4));
-    const int d0 = 4 * dq;
-    // per-axis clamped coordinates and validity of the 6 / 3 / 3 input positions
-    int dc[6], hc[3], wc[3];
-    bool vd[6], vh[3], vw[3];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { const int d = d0 + i - 1; vd[i] = d >= 0 && d < D; dc[i] = min(max(d, 0), D - 1) * H * W; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int h = h_ + i - 1, w = w_ + i - 1;
-        vh[i] = h >= 0 && h < H; hc[i] = min(max(h, 0), H - 1) * W;
-        vw[i] = w >= 0 && w < W; wc[i] = min(max(w, 0), W - 1);
-    }
-    const float* __restrict__ xb = x + (size_t)b * D * H * W;
-    float acc[4][COUT];
-#pragma unroll
-    for (int pd = 0; pd < 4; ++pd)
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[pd][c] = 0.f;
-#pragma unroll
-    for (int khw = 0; khw < 9; ++khw) {
-        const int kh = khw / 3, kw = khw % 3;
-        const bool vhw = vh[kh] && vw[kw];
-        const int col = hc[kh] + wc[kw];
-#pragma unroll
-        for (int din = 0; din < 6; ++din) {
-            float xv = xb[dc[din] + col];
-            xv = (vhw && vd[din]) ? xv : 0.f;
-#pragma unroll
-            for (int pd = 0; pd < 4; ++pd) {
-                const int kd = din - pd;
-                if (kd < 0 || kd > 2) continue;
-                const int t = (kd * 3 + kh) * 3 + kw;
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[pd][c] = fmaf(xv, wt[t * COUT + c], acc[pd][c]);
+        for (int c = 0; c < COUT; ++c) {
+            float d1 = 0.f, d2 = 0.f;
+            if (live) {
+                const float rw = bn_raw[v * COUT + c];
+                d1 = (rw * bn_stats[2 * COUT + c] + bn_stats[3 * COUT + c] > 0.f) ? acc[c] : 0.f;
+                d2 = d1 * ((rw - bn_stats[c]) * bn_stats[COUT + c]);
             }
+            sv[c] = d1;
+            sv[COUT + c] = d2;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 2 * COUT; ++k) {
+            float t = sv[k];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) t += __shfl_xor(t, m);
+            if (lane == 0) red[wave * 2 * COUT + k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            const int k = threadIdx.x;
+            const float t = (red[k] + red[2 * COUT + k]) + (red[4 * COUT + k] + red[6 * COUT + k]);
+            MVS_GLOBAL_ATOMIC_ADD_F64(slots + (size_t)(blockIdx.x & (nslots - 1)) * 2 * COUT + k, (double)t);
         }
     }
-#pragma unroll
-    for (int pd = 0; pd < 4; ++pd) {
-        if (d0 + pd >= D) continue;
-        float* __restrict__ o = y + ((((size_t)b * D + d0 + pd) * H + h_) * W + w_) * COUT;
-#pragma unroll
-        for (int c = 0; c < COUT; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[pd][c], acc[pd][c + 1], acc[pd][c + 2], acc[pd][c + 3]);
-    }
-}
-
-// wt[t][co] = W[0][co][2-kd][2-kh][2-kw]   (W is [1][Cin][3][3][3], OIK with O == 1)
-__global__ void conv_cin1_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 27 * C) return;
-    const int t = i / C, c = i % C;
-    wt[i] = w[(size_t)c * 27 + (26 - t)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -931,107 +737,6 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     }
 }
 
-// The same layer with FOUR outputs per thread (a column of 4 depth slices): the kernel above is LDS-bandwidth bound -- every output
-// reads its 27 x CIN inputs and the 27 x CIN weights from LDS (108 ds_read_b128 per output at CIN = 8: 0.086 ms of LDS time for the
-// 3.9 M voxels of MVSNet's probability layer, measured 0.095).  A thread that owns outputs d .. d+3 of one (h, w) reads each of the 6
-// input slices under a (kh, kw) offset once and each weight once per four outputs: 40 reads per output instead of 108 (measured: no
-// gain, see the knob).  The halo is
-// kept as one plane per channel quad ([cq][voxel] float4), so the 16 lanes along W read consecutive 16-byte words: no padding, no
-// bank conflicts.  Tile 4 x 8 x 16 outputs, 128 threads, halo 6 x 10 x 18.  Knob "cout1_d4" (1 = this form).
-template <int CIN>
-__global__ __launch_bounds__(128) void conv_cout1_d4_kernel(ConvArgs a, const float* __restrict__ w) {
-    constexpr int TD = 4, TH = 8, TW = 16, RD = TD + 2, RH = TH + 2, RW = TW + 2, NR = RD * RH * RW, CQ = CIN / 4;
-    __shared__ float4 tile[CQ * NR];      // [cq][voxel]
-    __shared__ float4 wl[27 * CQ];        // [tap][cq]
-    const int tid = threadIdx.x;
-    int t = blockIdx.x;
-    const int tw = t % a.ntw; t /= a.ntw;
-    const int th = t % a.nth; t /= a.nth;
-    const int td = t % a.ntd; t /= a.ntd;
-    const int b = t;
-    const int qd0 = td * TD, qh0 = th * TH, qw0 = tw * TW;
-    if (tid < 27 * CQ) {
-        const int tap = tid / CQ, cq = tid % CQ;   // W[0][ci][tap]
-        wl[tid] = make_float4(w[(size_t)(4 * cq) * 27 + tap], w[(size_t)(4 * cq + 1) * 27 + tap], w[(size_t)(4 * cq + 2) * 27 + tap],
-                              w[(size_t)(4 * cq + 3) * 27 + tap]);
-    }
-    // halo: all loads of a batch first, then the LDS writes (zero outside the volume)
-    constexpr int NITEMS = NR * CQ, NIT = (NITEMS + 127) / 128, BATCH = NIT < 12 ? NIT : 12;
-#pragma unroll
-    for (int k0 = 0; k0 < NIT; k0 += BATCH) {
-        float4 v[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int i = tid + 128 * (k0 + k);
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + k < NIT && i < NITEMS) {
-                const int vox = i / CQ, cq = i % CQ;
-                const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
-                const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-                if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                    v[k] = *reinterpret_cast<const float4*>(a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * CIN + 4 * cq);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int i = tid + 128 * (k0 + k);
-            if (k0 + k < NIT && i < NITEMS) tile[(i % CQ) * NR + i / CQ] = v[k];
-        }
-    }
-    __syncthreads();
-    const int pw = tid % TW, ph = tid / TW;
-    float acc[TD];
-#pragma unroll
-    for (int pd = 0; pd < TD; ++pd) acc[pd] = 0.f;
-    // NOT unrolled over (kh, kw) and the channel-quad pairs: fully unrolled, hipcc hoists all 54 x CQ tile reads to the top and
-    // runs out of registers (256 VGPRs + scratch); one iteration = 12 reads + 6 weight reads + 96 FMAs
-#pragma unroll 1
-    for (int khw = 0; khw < 9; ++khw) {
-        const int kh = khw / 3, kw = khw % 3;
-        const int col = (ph + kh) * RW + pw + kw;
-#pragma unroll 1
-        for (int cq0 = 0; cq0 < CQ; cq0 += 2) {
-            float4 wv[3][2];
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) wv[kd][c] = wl[((kd * 3 + kh) * 3 + kw) * CQ + cq0 + c];
-            float4 xv[RD][2];
-#pragma unroll
-            for (int din = 0; din < RD; ++din)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) xv[din][c] = tile[(cq0 + c) * NR + din * RH * RW + col];
-#pragma unroll
-            for (int din = 0; din < RD; ++din)
-#pragma unroll
-                for (int pd = 0; pd < TD; ++pd) {
-                    const int kd = din - pd;
-                    if (kd < 0 || kd > 2) continue;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        acc[pd] = fmaf(xv[din][c].x, wv[kd][c].x, acc[pd]); acc[pd] = fmaf(xv[din][c].y, wv[kd][c].y, acc[pd]);
-                        acc[pd] = fmaf(xv[din][c].z, wv[kd][c].z, acc[pd]); acc[pd] = fmaf(xv[din][c].w, wv[kd][c].w, acc[pd]);
-                    }
-                }
-        }
-    }
-    const int qh = qh0 + ph, qw = qw0 + pw;
-    if (qh < a.QH && qw < a.QW) {
-#pragma unroll
-        for (int pd = 0; pd < TD; ++pd) {
-            const int qd = qd0 + pd;
-            if (qd >= a.QD) continue;
-            const size_t o = (((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw;
-            float v = acc[pd];
-            if (a.scale) v = v * a.scale[0] + a.shift[0];
-            else if (a.shift) v = v + a.shift[0];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.skip) v += a.skip[o];
-            a.y[o] = v;
-        }
-    }
-}
-
 // dW[tap][cx] = sum_pos X[pos + tap - 1][cx] * g[pos]   (CG == 1, stride 1): thread = one (tap, cx) output
 // (two for CX == 16), persistent over tiles; X halo tile and g tile in LDS.  Partial image per workgroup
 // in the generic layout [group][27][CX][1] so conv_wgrad_reduce_kernel finishes it.
@@ -1194,135 +899,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_cg1_mfma_kernel(WgradArgs a) {
 // weight of channel (l&3)+4h broadcast to all blocks; D: lane holds channel (l&3)+4h of the 4 positions
 // 4*(l>>2)+r.  One ds_read_b128 per lane feeds the A operands of 4 consecutive ci (8 MFMAs per set).
 // ------------------------------------------------------------------------------------------------
-template <int CC, int NV>
-__global__ __launch_bounds__(256) void conv_c8_fwd_kernel(ConvArgs a, const float* __restrict__ w, int wlayout, int flip) {
-    constexpr int TQD = 4, TQH = 4 * NV, TQW = 16;
-    constexpr int RD = TQD + 2, RH = TQH + 2, RW = TQW + 2;
-    constexpr int CCP = CC + 4, CQ = CC / 4, NR = RD * RH * RW;
-    __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
-    __shared__ __attribute__((aligned(16))) float wl[27 * CQ * 2 * 4 * 4];   // [tap][cq][h][j][kk]
-    __shared__ float red[4 * 8 * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int t = blockIdx.x;
-    const int tw = t % a.ntw; t /= a.ntw;
-    const int th = t % a.nth; t /= a.nth;
-    const int td = t % a.ntd; t /= a.ntd;
-    const int b = t;
-    const int qd0 = td * TQD, qh0 = th * TQH, qw0 = tw * TQW;
-    int baseA[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int row = (wave * NV + v) * 4 + (lane >> 4);      // row of the TQD x TQH plane of rows
-        baseA[v] = (((row / TQH) * RH + row % TQH) * RW + (lane & 15)) * CCP;
-    }
-    f32x4 acc[NV][2];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) { acc[v][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[v][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    const int nchunks = a.Cin / CC;
-    constexpr int XIT = (NR * CQ + 255) / 256;          // float4 of the input halo tile per thread
-    constexpr int WIT = (27 * CQ * 32 + 255) / 256;     // weight floats per thread
-    float4 xv[XIT];
-    int xo[XIT];
-    float wv[WIT];
-    auto load_chunk = [&](int chunk) {
-        stage_load<XIT>(xv, xo, tid, NR * CQ, [&](int i, const float*& src, int& o) {
-            const int vox = i / CQ, cq = i % CQ;
-            const int rw = vox % RW, rh = (vox / RW) % RH, rd = vox / (RW * RH);
-            const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-            o = vox * CCP + 4 * cq;
-            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.Cin + chunk * CC + 4 * cq;
-        });
-#pragma unroll
-        for (int k = 0; k < WIT; ++k) {
-            const int i = tid + 256 * k;
-            float v = 0.f;
-            if (i < 27 * CQ * 32) {
-                const int kk = i & 3, j = (i >> 2) & 3, h = (i >> 4) & 1, cq = (i >> 5) % CQ, tap = (i >> 5) / CQ;
-                const int co = j + 4 * h, ci = chunk * CC + 4 * cq + kk;
-                const int kidx = flip ? 26 - tap : tap;
-                if (co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
-            }
-            wv[k] = v;
-        }
-    };
-    load_chunk(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();                                   // previous chunk's MFMAs have read the LDS image
-        stage_store<XIT>(tile, xv, xo);
-#pragma unroll
-        for (int k = 0; k < WIT; ++k) { const int i = tid + 256 * k; if (i < 27 * CQ * 32) wl[i] = wv[k]; }
-        __syncthreads();
-        if (chunk + 1 < nchunks) load_chunk(chunk + 1);    // in flight while this chunk's MFMAs run
-        for (int tap = 0; tap < 27; ++tap) {
-            const int toff = (((tap / 9) * RH + (tap / 3) % 3) * RW + tap % 3) * CCP;
-#pragma unroll
-            for (int cq = 0; cq < CQ; ++cq) {
-                const float4 b0 = *reinterpret_cast<const float4*>(&wl[((tap * CQ + cq) * 2 + 0) * 16 + (lane & 3) * 4]);
-                const float4 b1 = *reinterpret_cast<const float4*>(&wl[((tap * CQ + cq) * 2 + 1) * 16 + (lane & 3) * 4]);
-                float4 av[NV];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) av[v] = *reinterpret_cast<const float4*>(&tile[baseA[v] + toff + 4 * cq]);
-                // (measured: this v-outer order is 8 % faster than k-outer, profiles/r01_run10_kernels.log)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    acc[v][0] = MVS_MFMA_4x4x1(av[v].x, b0.x, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].x, b1.x, acc[v][1]);
-                    acc[v][0] = MVS_MFMA_4x4x1(av[v].y, b0.y, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].y, b1.y, acc[v][1]);
-                    acc[v][0] = MVS_MFMA_4x4x1(av[v].z, b0.z, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].z, b1.z, acc[v][1]);
-                    acc[v][0] = MVS_MFMA_4x4x1(av[v].w, b0.w, acc[v][0]); acc[v][1] = MVS_MFMA_4x4x1(av[v].w, b1.w, acc[v][1]);
-                }
-            }
-        }
-    }
-    // epilogue: lane (block bl = lane>>2, j = lane&3) holds channel j+4h of positions 4*bl + r of its set
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    const int bl = lane >> 2, j = lane & 3;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int row = (wave * NV + v) * 4 + (bl >> 2);
-        const int qd = qd0 + row / TQH, qh = qh0 + row % TQH;
-        if (qd >= a.QD || qh >= a.QH) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qw = qw0 + 4 * (bl & 3) + r;
-            if (qw >= a.QW) continue;
-            const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int co = j + 4 * h;
-                if (co >= a.Cout) continue;
-                float val = acc[v][h][r];
-                s1[h] += val;
-                s2[h] += val * val;
-                if (a.scale) val = val * a.scale[co] + a.shift[co];
-                else if (a.shift) val = val + a.shift[co];
-                if (a.relu) val = fmaxf(val, 0.f);
-                if (a.skip) val += a.skip[obase + co];
-                a.y[obase + co] = val;
-            }
-        }
-    }
-    if (a.partials) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float x1 = s1[h], x2 = s2[h];
-#pragma unroll
-            for (int m = 4; m < 64; m <<= 1) { x1 += __shfl_xor(x1, m); x2 += __shfl_xor(x2, m); }
-            if (lane < 4) { red[(wave * 8 + lane + 4 * h) * 2] = x1; red[(wave * 8 + lane + 4 * h) * 2 + 1] = x2; }
-        }
-        __syncthreads();
-        if (tid < 16) {
-            const int stat = tid >> 3, co = tid & 7;
-            if (co < a.Cout) {
-                float sm = 0.f;
-                for (int wv = 0; wv < 4; ++wv) sm += red[(wv * 8 + co) * 2 + stat];
-                a.partials[((size_t)blockIdx.x * 2 + stat) * a.Cout + co] = sm;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Cout == 8 forward, second form: the WEIGHTS are the broadcast operand and never touch LDS.
 // v_mfma_f32_4x4x1_16b_f32 has a block-broadcast control on its A operand (cbsz = 4, abid = k: all 16 blocks
@@ -1433,6 +1009,11 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
         if (k < CC && co < a.Cout) v = wlayout == WL_OIK ? w[((size_t)co * a.Cin + ci) * 27 + kidx] : w[((size_t)ci * a.Cout + co) * 27 + kidx];
         wl[i] = v;
     }
+    // BatchNorm statistics of the raw output: per-lane sums over ALL tiles of this persistent workgroup, one butterfly and one
+    // slot row per workgroup at the end (rounds 1-3: one butterfly and one partial row per tile)
+    float s1[8], s2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     for (int t = vb; t < ntiles; t += gridDim.x) {
     tile_origin(t, b, qd0, qh0, qw0);
     f32x4 acc[2][2];
@@ -1484,7 +1065,6 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
     // epilogue: the lane owns position (qd0 + wave, qh0 + lane>>4, qw0 + lane&15) and channels 4h + r
     const int qd = qd0 + wave, qh = qh0 + (lane >> 4), qw = qw0 + (lane & 15);
     const bool inside = qd < a.QD && qh < a.QH && qw < a.QW;
-    float s1[8], s2[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float o[4];
@@ -1493,8 +1073,8 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
             const int co = 4 * h + r;
             float val = acc[0][h][r] + acc[1][h][r];
             if (!inside || co >= a.Cout) val = 0.f;
-            s1[co] = val;
-            s2[co] = val * val;
+            s1[co] += val;
+            s2[co] += val * val;
             if (co < a.Cout) {
                 if (a.scale) val = val * a.scale[co] + a.shift[co];
                 else if (a.shift) val = val + a.shift[co];
@@ -1518,7 +1098,8 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
             }
         }
     }
-    if (a.partials) {
+    }   // tile loop
+    if (a.slots) {
         // 16 per-lane values -> wave sums by a halving butterfly: after the step with mask m a lane keeps the
         // half of its values selected by its bit m, so the exchange count is 8+4+2+1 (+2 full steps) instead of 16*6
         float v[16];
@@ -1552,11 +1133,10 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
         if (tid < 16) {
             const int stat = tid >> 3, co = tid & 7;
             if (co < a.Cout)
-                a.partials[((size_t)t * 2 + stat) * a.Cout + co] =
-                    red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+                MVS_GLOBAL_ATOMIC_ADD_F64(a.slots + ((size_t)(blockIdx.x & (a.nslots - 1)) * 2 + stat) * a.Cout + co,
+                                          (double)(red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid]));
         }
     }
-    }   // tile loop
 }
 
 
@@ -1775,27 +1355,16 @@ static size_t packed_floats(int geom, int cin, int cout) {
     return (size_t)total_ksteps(geom, cin, cc) * nb * 256;
 }
 
-int g_conv_split = 1;
+int g_conv_split = 1;       // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
 int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv with Cout == 8 as W-parity-merged GEMMs (GEOM_TR2_PW)
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
-int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1 = Cout==8 stride-1 layers use the 4x4x1 MFMA kernels, +2 = forward with the weights as the broadcast operand, +4 = weight gradient with g as the broadcast operand
-int g_conv_persist = 0;  // tuning knob "conv_persist": 0 = never (default: measured SLOWER than five small workgroups per CU, profiles/r03_run8_*), 1 = stride-1 layers with many tiles run the persistent implicit-GEMM kernel (next tile's halo in flight during the MFMAs), n > 1 = with exactly n workgroups (tests)
-int g_conv_fs = 0;      // tuning knob "fs": fast halo staging of interior tiles in the generic implicit-GEMM kernels (unmeasured)
-int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward   // tuning knob "conv_split" (mvs_set_tuning): 0 keeps all Cout tiles in one workgroup
+int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
+int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
 template <int GEOM, int CC>
 static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
     dim3 grid(nblocks, a.nb_total / NB), block(256);
-    if (g_conv_fs) {
-        switch (NB) {
-            case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1, true>), grid, block, 0, st, a); break;
-            case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2, true>), grid, block, 0, st, a); break;
-            case 4: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 4, true>), grid, block, 0, st, a); break;
-            default: mvs_set_error("conv igemm: Cout tile count %d unsupported", NB); return MVS_ERR_UNSUPPORTED;
-        }
-        return mvs_check_launch("conv_igemm_fs");
-    }
     switch (NB) {
         case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1>), grid, block, 0, st, a); break;
         case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2>), grid, block, 0, st, a); break;
@@ -1805,10 +1374,9 @@ static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t s
     return mvs_check_launch("conv_igemm");
 }
 
-// Which tiling the generic kernel runs with (shared by run_igemm and mvs_conv3d_stat_rows: the BatchNorm partial-sum buffer has
-// exactly one row per workgroup tile).  Small volumes (deep U-Net levels) have too few tiles to fill 256 CUs: first one 16-wide
-// Cout tile per workgroup, and if that still leaves fewer than ~1.5 workgroups per CU, quarter-size tiles (knob "conv_small":
-// 0 never, 1 auto, 2 always).
+// Which tiling the generic kernel runs with.  Small volumes (deep U-Net levels) have too few tiles to fill 256 CUs: first one
+// 16-wide Cout tile per workgroup, and if that still leaves fewer than ~1.5 workgroups per CU, quarter-size tiles (knob
+// "conv_small": 0 never, 1 auto, 2 always).
 static void igemm_tiling(int geom, int B, int QD, int QH, int QW, int cout, int& kgeom, int& NB, int& nblocks) {
     const int nb_total = mvs_cdiv(cout, 16) == 3 ? 4 : mvs_cdiv(cout, 16);
     nblocks = B * mvs_cdiv(QD, geom_tqd(geom)) * mvs_cdiv(QH, geom_tqh(geom)) * mvs_cdiv(QW, 16);
@@ -1826,51 +1394,145 @@ static void igemm_tiling(int geom, int B, int QD, int QH, int QW, int cout, int&
 }
 
 struct Epilogue {
-    const float* scale; const float* shift; const float* skip; int relu; float* partials;
+    const float* scale; const float* shift; const float* skip; int relu;
+    double* slots; int nslots;                       // BatchNorm statistic slots (see ConvArgs)
+    const float* bn_raw; const float* bn_stats;      // backward statistics of the block whose output gradient is written
 };
 
-// in: [B,Di,Hi,Wi,cin] ; out: [B,Do,Ho,Wo,cout] ; coarse grid: S1/S2 -> output dims, TR2 -> input dims
-static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, int flip, float* out, float* ws,
-                     int B, int Di, int Hi, int Wi, int cin, int cout, const Epilogue& ep, hipStream_t st) {
+// One convolution-shaped op as the implicit-GEMM kernels see it: in [B,Di,Hi,Wi,cin] -> out [B,Do,Ho,Wo,cout];
+// coarse grid: S1/S2 -> output dims, TR2 -> input dims; weights read with (wlayout, flip) from the parameter tensor.
+struct IgemmPlan {
+    int geom, wlayout, flip, B, Di, Hi, Wi, cin, cout;
+    bool cin1;                                        // Cout == 1 stride-1 input gradient: the direct Cin == 1 kernel
+};
+enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
+       MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
+
+static int check_stride(int stride, int D, int H, int W, const char* what) {
+    MVS_REQUIRE(stride == 1 || stride == 2, MVS_ERR_UNSUPPORTED, "%s: stride must be 1 or 2, got %d", what, stride);
+    MVS_REQUIRE(D > 0 && H > 0 && W > 0, MVS_ERR_SHAPE, "%s: bad spatial shape %dx%dx%d", what, D, H, W);
+    return MVS_OK;
+}
+
+// (D,H,W) are always the spatial dims of the forward op's INPUT x; Cin / Cout those of the forward op.
+static int plan_for(int op, int B, int D, int H, int W, int Cin, int Cout, int stride, IgemmPlan& p, const char* what) {
+    int rc = check_stride(stride, D, H, W, what);
+    if (rc) return rc;
+    // the kernels index voxels with 32-bit ints inside a tile's neighbourhood and size_t beyond; the element counts themselves
+    // must fit the int arithmetic of the tile maps
+    MVS_REQUIRE(B > 0 && (long long)B * D * H * W * 8 < (1LL << 40), MVS_ERR_SHAPE, "%s: volume %dx%dx%dx%d too large", what, B, D, H, W);
+    p = {};
+    p.B = B; p.cin1 = false;
+    switch (op) {
+        case MVS_OP_CONV_FWD:
+            p.geom = stride == 2 ? GEOM_S2 : GEOM_S1; p.wlayout = WL_OIK; p.flip = 0;
+            p.Di = D; p.Hi = H; p.Wi = W; p.cin = Cin; p.cout = Cout;
+            return MVS_OK;
+        case MVS_OP_CONV_DGRAD:
+            p.cin = Cout; p.cout = Cin; p.wlayout = WL_IOK;
+            if (stride == 1) {
+                p.geom = GEOM_S1; p.flip = 1; p.Di = D; p.Hi = H; p.Wi = W;
+                p.cin1 = Cout == 1;
+            } else {
+                MVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MVS_ERR_SHAPE, "%s stride 2: D,H,W must be even", what);
+                p.geom = GEOM_TR2; p.flip = 0; p.Di = D / 2; p.Hi = H / 2; p.Wi = W / 2;
+            }
+            return MVS_OK;
+        case MVS_OP_CONVT_FWD:
+            p.wlayout = WL_IOK; p.Di = D; p.Hi = H; p.Wi = W; p.cin = Cin; p.cout = Cout;
+            if (stride == 1) { p.geom = GEOM_S1; p.flip = 1; } else { p.geom = GEOM_TR2; p.flip = 0; }
+            return MVS_OK;
+        case MVS_OP_CONVT_DGRAD:
+            p.wlayout = WL_OIK; p.flip = 0; p.cin = Cout; p.cout = Cin;
+            if (stride == 1) { p.geom = GEOM_S1; p.Di = D; p.Hi = H; p.Wi = W; }
+            else { p.geom = GEOM_S2; p.Di = 2 * D; p.Hi = 2 * H; p.Wi = 2 * W; }
+            return MVS_OK;
+        default:
+            mvs_set_error("%s: op %d has no weight image", what, op);
+            return MVS_ERR_UNSUPPORTED;
+    }
+}
+
+static void plan_grid(const IgemmPlan& p, int& QD, int& QH, int& QW) {
+    if (p.geom == GEOM_S2) { QD = (p.Di - 1) / 2 + 1; QH = (p.Hi - 1) / 2 + 1; QW = (p.Wi - 1) / 2 + 1; }
+    else { QD = p.Di; QH = p.Hi; QW = p.Wi; }
+}
+static bool plan_is_c8(const IgemmPlan& p, const Epilogue* ep) {
+    return (g_conv_c8 & 3) && p.geom == GEOM_S1 && p.cout == 8 && (p.cin == 8 || p.cin == 16 || p.cin == 32) && !(ep && ep->bn_raw);
+}
+static bool plan_is_cout1(const IgemmPlan& p, const Epilogue* ep) {
+    return p.geom == GEOM_S1 && p.cout == 1 && p.wlayout == WL_OIK && !p.flip && (p.cin == 8 || p.cin == 16) &&
+           !(ep && (ep->slots || ep->bn_raw));
+}
+
+// What mvs_conv3d_pack_weights has to write for this op (kind -1: nothing -- the kernel reads the parameter tensor itself).
+static int plan_pack(const IgemmPlan& p, const float* w, float* ws, PackItem& it) {
+    it = {};
+    it.w = w; it.wp = ws; it.kind = -1;
+    if (p.cin1) {
+        MVS_REQUIRE(p.cout == 8 || p.cout == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", p.cout);
+        it.kind = 1; it.Cout = p.cout; it.total = 27 * p.cout;
+        return MVS_OK;
+    }
+    MVS_REQUIRE(p.cin == 8 || p.cin == 16 || p.cin == 32 || p.cin == 64, MVS_ERR_UNSUPPORTED,
+                "conv igemm: input channels must be 8/16/32/64, got %d", p.cin);
+    MVS_REQUIRE(p.cout >= 1 && p.cout <= 64, MVS_ERR_UNSUPPORTED, "conv igemm: output channels must be <= 64, got %d", p.cout);
+    MVS_REQUIRE(!(p.geom == GEOM_TR2 && p.cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
+    // (an op served by the Cout == 8 / Cout == 1 kernels needs no image -- unless its epilogue carries backward statistics, which
+    //  only the generic kernel implements; the image is cheap, so it is written whenever the generic kernel COULD run)
+    int QD, QH, QW, kgeom, NB, nblocks;
+    plan_grid(p, QD, QH, QW);
+    igemm_tiling(p.geom, p.B, QD, QH, QW, p.cout, kgeom, NB, nblocks);
+    const int cc = pick_cc(p.geom, p.cin);
+    const int nb_total = mvs_cdiv(p.cout, 16) == 3 ? 4 : mvs_cdiv(p.cout, 16);
+    const int pgeom = (kgeom == GEOM_TR2 && cc == 16 && p.cout == 8 && g_conv_tr2pw) ? GEOM_TR2_PW : p.geom;
+    it.kind = 0; it.geom = pgeom; it.CC = cc; it.Cin = p.cin; it.Cout = p.cout; it.NB = nb_total; it.layout = p.wlayout; it.flip = p.flip;
+    it.total = (int)((size_t)total_ksteps(pgeom, p.cin, cc) * nb_total * 256);
+    return MVS_OK;
+}
+
+static int launch_pack(const PackItem* items, int n, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += MVS_PACK_BATCH_MAX) {
+        PackBatch pb = {};
+        int m = 0, maxtotal = 0;
+        for (int i = i0; i < n && m < MVS_PACK_BATCH_MAX; ++i) {
+            if (items[i].kind < 0) continue;
+            pb.it[m++] = items[i];
+            if (items[i].total > maxtotal) maxtotal = items[i].total;
+        }
+        if (m == 0) continue;
+        MVS_LAUNCH(conv_pack_batch_kernel, dim3(mvs_cdiv(maxtotal, 256), m), dim3(256), 0, st, pb);
+    }
+    return mvs_check_launch("conv_pack_weights");
+}
+
+static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, float* out, float* ws, const Epilogue& ep,
+                     int ws_packed, hipStream_t st) {
     MVS_REQUIRE(in && wsrc && out && ws, MVS_ERR_NULL, "conv: null pointer argument");
-    MVS_REQUIRE(cin == 8 || cin == 16 || cin == 32 || cin == 64, MVS_ERR_UNSUPPORTED,
-                "conv igemm: input channels must be 8/16/32/64, got %d", cin);
-    MVS_REQUIRE(cout >= 1 && cout <= 64, MVS_ERR_UNSUPPORTED, "conv igemm: output channels must be <= 64, got %d", cout);
-    MVS_REQUIRE(!(geom == GEOM_TR2 && cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
+    MVS_REQUIRE(!ep.slots || (ep.nslots >= 1 && ep.nslots <= 256 && (ep.nslots & (ep.nslots - 1)) == 0), MVS_ERR_SHAPE,
+                "conv: statistic slot count must be a power of two <= 256, got %d", ep.nslots);
+    MVS_REQUIRE(!ep.bn_raw || (ep.bn_stats && ep.slots), MVS_ERR_NULL, "conv: bn_raw needs bn_stats and slots");
+    const int geom = p.geom, B = p.B, cin = p.cin, cout = p.cout;
     ConvArgs a = {};
-    a.x = in; a.y = out; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = cin; a.Cout = cout;
-    a.scale = ep.scale; a.shift = ep.shift; a.skip = ep.skip; a.relu = ep.relu; a.partials = ep.partials;
-    if (geom == GEOM_S1) { a.Do = Di; a.Ho = Hi; a.Wo = Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
-    else if (geom == GEOM_S2) {
-        a.Do = (Di - 1) / 2 + 1; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1;
-        a.QD = a.Do; a.QH = a.Ho; a.QW = a.Wo;
-    } else { a.Do = 2 * Di; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.QD = Di; a.QH = Hi; a.QW = Wi; }
+    a.x = in; a.y = out; a.B = B; a.Di = p.Di; a.Hi = p.Hi; a.Wi = p.Wi; a.Cin = cin; a.Cout = cout;
+    a.scale = ep.scale; a.shift = ep.shift; a.skip = ep.skip; a.relu = ep.relu;
+    a.slots = ep.slots; a.nslots = ep.nslots; a.bn_raw = ep.bn_raw; a.bn_stats = ep.bn_stats;
+    plan_grid(p, a.QD, a.QH, a.QW);
+    if (geom == GEOM_S1) { a.Do = p.Di; a.Ho = p.Hi; a.Wo = p.Wi; }
+    else if (geom == GEOM_S2) { a.Do = a.QD; a.Ho = a.QH; a.Wo = a.QW; }
+    else { a.Do = 2 * p.Di; a.Ho = 2 * p.Hi; a.Wo = 2 * p.Wi; }
     a.ntd = mvs_cdiv(a.QD, geom_tqd(geom)); a.nth = mvs_cdiv(a.QH, geom_tqh(geom)); a.ntw = mvs_cdiv(a.QW, 16);
-    if ((g_conv_c8 & 2) && geom == GEOM_S1 && cout == 8 && (cin == 8 || cin == 16 || cin == 32)) {
-        // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions
+    if (plan_is_c8(p, &ep)) {
+        // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions (reads the parameter tensor itself)
         const int ntl = B * a.ntd * a.nth * a.ntw;
         const int nbc = ntl < 512 ? ntl : 512;            // 80 KB of LDS -> 2 resident workgroups per CU
-        if (cin == 32) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 2>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
-        else if (cin == 16) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
-        else MVS_LAUNCH((conv_c8_fwd_bc_kernel<8, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, wlayout, flip, g_conv_xcd);
+        if (cin == 32) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 2>), dim3(nbc), dim3(256), 0, st, a, wsrc, p.wlayout, p.flip, g_conv_xcd);
+        else if (cin == 16) MVS_LAUNCH((conv_c8_fwd_bc_kernel<16, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, p.wlayout, p.flip, g_conv_xcd);
+        else MVS_LAUNCH((conv_c8_fwd_bc_kernel<8, 1>), dim3(nbc), dim3(256), 0, st, a, wsrc, p.wlayout, p.flip, g_conv_xcd);
         return mvs_check_launch("conv_c8_fwd_bc");
     }
-    if (g_conv_c8 && geom == GEOM_S1 && cout == 8 && cin % 8 == 0) {
-        // 4x4x1 MFMA path, tile 4 x 8 x 16 positions
-        a.nth = mvs_cdiv(a.QH, 8);
-        const int nb8 = B * a.ntd * a.nth * a.ntw;
-        MVS_LAUNCH((conv_c8_fwd_kernel<8, 2>), dim3(nb8), dim3(256), 0, st, a, wsrc, wlayout, flip);
-        return mvs_check_launch("conv_c8_fwd");
-    }
     int nblocks = B * a.ntd * a.nth * a.ntw;
-    if (geom == GEOM_S1 && cout == 1 && wlayout == WL_OIK && !flip && !ep.partials && (cin == 8 || cin == 16)) {
-        if (g_conv_cout1_d4 & 1) {   // four outputs per thread, tile 4 x 8 x 16
-            a.nth = mvs_cdiv(a.QH, 8);
-            const int nb4 = B * a.ntd * a.nth * a.ntw;
-            if (cin == 8) MVS_LAUNCH((conv_cout1_d4_kernel<8>), dim3(nb4), dim3(128), 0, st, a, wsrc);
-            else MVS_LAUNCH((conv_cout1_d4_kernel<16>), dim3(nb4), dim3(128), 0, st, a, wsrc);
-            return mvs_check_launch("conv_cout1_d4");
-        }
+    if (plan_is_cout1(p, &ep)) {
         if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         return mvs_check_launch("conv_cout1");
@@ -1880,27 +1542,18 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     a.nb_total = mvs_cdiv(cout, 16) == 3 ? 4 : mvs_cdiv(cout, 16);
     igemm_tiling(geom, B, a.QD, a.QH, a.QW, cout, kgeom, NB, nblocks);
     a.ntd = mvs_cdiv(a.QD, geom_tqd(kgeom)); a.nth = mvs_cdiv(a.QH, geom_tqh(kgeom));
-    // pack weights into ws
-    {
-        const int pgeom = (kgeom == GEOM_TR2 && cc == 16 && cout == 8 && g_conv_tr2pw) ? GEOM_TR2_PW : geom;
-        const int total = (int)((size_t)total_ksteps(pgeom, cin, cc) * a.nb_total * 256);
-        MVS_LAUNCH(conv_pack_weights_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, wsrc, ws, pgeom, cc, cin, cout,
-                   a.nb_total, wlayout, flip, total);
+    if (!ws_packed) {
+        PackItem it;
+        int rc = plan_pack(p, wsrc, ws, it);
+        if (rc) return rc;
+        rc = launch_pack(&it, 1, st);
+        if (rc) return rc;
+    } else {
+        MVS_REQUIRE(cin == 8 || cin == 16 || cin == 32 || cin == 64, MVS_ERR_UNSUPPORTED, "conv igemm: input channels must be 8/16/32/64, got %d", cin);
+        MVS_REQUIRE(cout >= 1 && cout <= 64, MVS_ERR_UNSUPPORTED, "conv igemm: output channels must be <= 64, got %d", cout);
+        MVS_REQUIRE(!(geom == GEOM_TR2 && cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
     }
     a.wp = ws;
-    if (kgeom == GEOM_S1 && g_conv_persist && NB == a.nb_total && !g_conv_fs) {
-        // persistent workgroups when every slot gets >= 2 tiles: 3 workgroups per CU (52 KB of LDS with 16-channel chunks; the
-        // register allocation is held to 3 waves per SIMD), 2 for the 64-wide layers (register budget)
-        const int slots = g_conv_persist > 1 ? g_conv_persist : 256 * (NB == 4 ? 2 : 3);   // > 1: that many workgroups (tests)
-        if (nblocks >= 2 * slots && (NB == 1 || NB == 2 || NB == 4)) {
-            dim3 pgrid(slots), block(256);
-#define MVS_S1P(CCV, NBV) MVS_LAUNCH((conv_igemm_s1p_kernel<CCV, NBV>), pgrid, block, 0, st, a, g_conv_xcd)
-            if (cc == 16) { if (NB == 1) MVS_S1P(16, 1); else if (NB == 2) MVS_S1P(16, 2); else MVS_S1P(16, 4); }
-            else { if (NB == 1) MVS_S1P(8, 1); else if (NB == 2) MVS_S1P(8, 2); else MVS_S1P(8, 4); }
-#undef MVS_S1P
-            return mvs_check_launch("conv_igemm_s1p");
-        }
-    }
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);
@@ -1918,16 +1571,29 @@ static int run_igemm(int geom, const float* in, const float* wsrc, int wlayout, 
     return launch_igemm_nb<GEOM_TR2, 64>(a, NB, nblocks, st);
 }
 
-// rows of the BatchNorm partial-sum buffer of a forward call: one per workgroup tile of the tiling the call will use
-static int igemm_blocks(int geom, int B, int Di, int Hi, int Wi, int cout = 16, bool generic = false) {
-    int QD = Di, QH = Hi, QW = Wi;
-    if (geom == GEOM_S2) { QD = (Di - 1) / 2 + 1; QH = (Hi - 1) / 2 + 1; QW = (Wi - 1) / 2 + 1; }
-    if (generic) {
-        int kgeom, NB, nblocks;
-        igemm_tiling(geom, B, QD, QH, QW, cout, kgeom, NB, nblocks);
-        return nblocks;
+// input gradient of the Cout == 1 layer (direct kernel over the [tap][co] table in ws)
+static int run_cin1(const IgemmPlan& p, const float* gy, const float* w, float* gx, float* ws, const Epilogue& ep, int ws_packed,
+                    hipStream_t st) {
+    MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv3d_dgrad: null pointer argument");
+    MVS_REQUIRE(!ep.skip, MVS_ERR_UNSUPPORTED, "conv3d_dgrad: the Cout = 1 input gradient takes no summand");
+    MVS_REQUIRE(!ep.bn_raw || (ep.bn_stats && ep.slots), MVS_ERR_NULL, "conv3d_dgrad: bn_raw needs bn_stats and slots");
+    MVS_REQUIRE(!ep.slots || (ep.bn_raw && ep.nslots >= 1 && ep.nslots <= 256 && (ep.nslots & (ep.nslots - 1)) == 0), MVS_ERR_SHAPE,
+                "conv3d_dgrad: bad statistic slots");
+    const int C = p.cout;
+    if (!ws_packed) {
+        PackItem it;
+        int rc = plan_pack(p, w, ws, it);
+        if (rc) return rc;
+        rc = launch_pack(&it, 1, st);
+        if (rc) return rc;
+    } else {
+        MVS_REQUIRE(C == 8 || C == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", C);
     }
-    return B * mvs_cdiv(QD, geom_tqd(geom)) * mvs_cdiv(QH, geom_tqh(geom)) * mvs_cdiv(QW, 16);
+    const size_t total = (size_t)p.B * p.Di * p.Hi * p.Wi;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (C == 8) MVS_LAUNCH((conv_cin1_kernel<8>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    else MVS_LAUNCH((conv_cin1_kernel<16>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    return mvs_check_launch("conv_cin1");
 }
 
 static const int WGRAD_MAX_GROUPS = 768;
@@ -1996,17 +1662,8 @@ static int wgrad_finish(float* ws, int nparts, int CX, int CG, float* gw, hipStr
     return mvs_check_launch("conv_wgrad_reduce");
 }
 
-static int check_stride(int stride, int D, int H, int W, const char* what) {
-    MVS_REQUIRE(stride == 1 || stride == 2, MVS_ERR_UNSUPPORTED, "%s: stride must be 1 or 2, got %d", what, stride);
-    MVS_REQUIRE(D > 0 && H > 0 && W > 0, MVS_ERR_SHAPE, "%s: bad spatial shape %dx%dx%d", what, D, H, W);
-    return MVS_OK;
-}
-
 // ---- C ABI ---------------------------------------------------------------------------------------
 // (D,H,W) are always the spatial dims of the forward op's INPUT x.
-enum { MVS_OP_CONV_FWD = 0, MVS_OP_CONV_DGRAD = 1, MVS_OP_CONV_WGRAD = 2,
-       MVS_OP_CONVT_FWD = 3, MVS_OP_CONVT_DGRAD = 4, MVS_OP_CONVT_WGRAD = 5 };
-
 extern "C" long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int W, int Cin, int Cout, int stride) {
     (void)B; (void)D; (void)H; (void)W;
     size_t fl = 0;
@@ -2022,73 +1679,72 @@ extern "C" long long mvs_conv3d_workspace_bytes(int op, int B, int D, int H, int
     return (long long)(fl * sizeof(float) + 256);
 }
 
-// rows of the [rows][2][Cout] BatchNorm partial-sum buffer a forward call writes
-extern "C" int mvs_conv3d_stat_rows(int op, int B, int D, int H, int W, int Cin, int Cout, int stride) {
-    if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && (g_conv_c8 & 2) && Cout == 8 &&
-        (Cin == 8 || Cin == 16 || Cin == 32))
-        return igemm_blocks(GEOM_S1, B, D, H, W);                        // conv_c8_fwd_bc_kernel tiling
-    if ((op == MVS_OP_CONV_FWD || op == MVS_OP_CONVT_FWD) && stride == 1 && g_conv_c8 && Cout == 8 && Cin % 8 == 0)
-        return B * mvs_cdiv(D, 4) * mvs_cdiv(H, 8) * mvs_cdiv(W, 16);   // conv_c8_fwd_kernel tiling
-    if (op == MVS_OP_CONV_FWD) return igemm_blocks(stride == 2 ? GEOM_S2 : GEOM_S1, B, D, H, W, Cout, true);
-    if (op == MVS_OP_CONVT_FWD) return igemm_blocks(stride == 2 ? GEOM_TR2 : GEOM_S1, B, D, H, W, Cout, true);
-    return -1;
+// Write into ws (>= mvs_conv3d_workspace_bytes) what the kernels of `op` (a forward or input-gradient op) derive from the
+// parameter tensor w; a later call of that op with the same shape and ws_packed = 1 skips its own packing launch.
+extern "C" int mvs_conv3d_pack_weights(int op, const float* w, float* ws, int B, int D, int H, int W, int Cin, int Cout, int stride,
+                                       hipStream_t stream) {
+    MVS_REQUIRE(w && ws, MVS_ERR_NULL, "conv3d_pack_weights: null pointer argument");
+    IgemmPlan p;
+    int rc = plan_for(op, B, D, H, W, Cin, Cout, stride, p, "conv3d_pack_weights");
+    if (rc) return rc;
+    PackItem it;
+    rc = plan_pack(p, w, ws, it);
+    if (rc) return rc;
+    return launch_pack(&it, 1, stream);
+}
+
+// The same for n ops in ONE launch: ops[n], w[n], ws[n], shapes[n][7] = (B, D, H, W, Cin, Cout, stride) of each op.
+extern "C" int mvs_conv3d_pack_weights_batch(int n, const int* ops, const float* const* w, float* const* ws, const int* shapes,
+                                             hipStream_t stream) {
+    MVS_REQUIRE(ops && w && ws && shapes, MVS_ERR_NULL, "conv3d_pack_weights_batch: null pointer argument");
+    MVS_REQUIRE(n >= 0 && n <= 1024, MVS_ERR_SHAPE, "conv3d_pack_weights_batch: bad count %d", n);
+    PackItem items[64];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int m = n - i0 < 64 ? n - i0 : 64;
+        for (int i = 0; i < m; ++i) {
+            const int* sh = shapes + (size_t)(i0 + i) * 7;
+            MVS_REQUIRE(w[i0 + i] && ws[i0 + i], MVS_ERR_NULL, "conv3d_pack_weights_batch: null pointer in entry %d", i0 + i);
+            IgemmPlan p;
+            int rc = plan_for(ops[i0 + i], sh[0], sh[1], sh[2], sh[3], sh[4], sh[5], sh[6], p, "conv3d_pack_weights_batch");
+            if (rc) return rc;
+            rc = plan_pack(p, w[i0 + i], ws[i0 + i], items[i]);
+            if (rc) return rc;
+        }
+        int rc = launch_pack(items, m, stream);
+        if (rc) return rc;
+    }
+    return MVS_OK;
 }
 
 // y = conv3d(x, w[Cout][Cin][3][3][3], stride, pad 1) then optional epilogue:
-//   scale&&shift: y*scale[c]+shift[c] ; only shift: y+shift[c] (bias) ; relu ; + skip ; stat partials of raw y
+//   scale&&shift: y*scale[c]+shift[c] ; only shift: y+shift[c] (bias) ; relu ; + skip ;
+//   stat_slots [nslots][2][Cout] fp64: per-channel (sum, sum of squares) of the RAW y added into slot (workgroup mod nslots)
 extern "C" int mvs_conv3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W,
                               int Cin, int Cout, int stride, const float* scale, const float* shift,
-                              const float* skip, int relu, float* stat_partials, hipStream_t stream) {
-    int rc = check_stride(stride, D, H, W, "conv3d_fwd");
+                              const float* skip, int relu, double* stat_slots, int nslots, int ws_packed, hipStream_t stream) {
+    IgemmPlan p;
+    int rc = plan_for(MVS_OP_CONV_FWD, B, D, H, W, Cin, Cout, stride, p, "conv3d_fwd");
     if (rc) return rc;
-    Epilogue ep = {scale, shift, skip, relu, stat_partials};
-    return run_igemm(stride == 2 ? GEOM_S2 : GEOM_S1, x, w, WL_OIK, 0, y, ws, B, D, H, W, Cin, Cout, ep, stream);
+    Epilogue ep = {scale, shift, skip, relu, stat_slots, nslots, nullptr, nullptr};
+    return run_igemm(p, x, w, y, ws, ep, ws_packed, stream);
 }
 
-// gx[B,D,H,W,Cin] = d conv3d / dx applied to gy[B,Do,Ho,Wo,Cout]
-extern "C" int mvs_conv3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W,
-                                int Cin, int Cout, int stride, hipStream_t stream) {
-    int rc = check_stride(stride, D, H, W, "conv3d_dgrad");
+// gx[B,D,H,W,Cin] = d conv3d / dx applied to gy[B,Do,Ho,Wo,Cout]  (+ add, like gx, or NULL: the second gradient contribution of a
+// tensor with two consumers -- the U-Net's skip connections, mvsnet.py:70-72 -- summed in the epilogue).
+// bn_raw (like gx, or NULL): x = relu(BatchNorm(bn_raw)) (+ skip) came out of a BatchNorm+ReLU block and gx is that block's COMPLETE
+// output gradient; the epilogue then also adds the block's backward statistics (sum dyh, sum dyh*xhat per channel, dyh = gx where
+// the ReLU was active) into bn_slots [nslots][2][Cin] (fp64), using bn_stats [4][Cin] = the block's mean, invstd, scale, shift
+// (module.py:35-42 backward): no separate reduction pass over (gx, raw).
+extern "C" int mvs_conv3d_dgrad(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
+                                int Cin, int Cout, int stride, const float* bn_raw, const float* bn_stats, double* bn_slots,
+                                int nslots, int ws_packed, hipStream_t stream) {
+    IgemmPlan p;
+    int rc = plan_for(MVS_OP_CONV_DGRAD, B, D, H, W, Cin, Cout, stride, p, "conv3d_dgrad");
     if (rc) return rc;
-    Epilogue ep = {nullptr, nullptr, nullptr, 0, nullptr};
-    if (stride == 1) {
-        if (Cout == 1) {
-            MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv3d_dgrad: null pointer argument");
-            MVS_REQUIRE(Cin == 8 || Cin == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", Cin);
-            MVS_LAUNCH(conv_cin1_pack_kernel, dim3(mvs_cdiv(27 * Cin, 256)), dim3(256), 0, stream, w, ws, Cin);
-            if (g_conv_cout1_d4 & 1) {
-                const size_t total4 = (size_t)B * ((D + 3) / 4) * H * W;
-                dim3 grid4((unsigned)((total4 + 255) / 256));
-                if (Cin == 8) MVS_LAUNCH((conv_cin1_d4_kernel<8>), grid4, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
-                else MVS_LAUNCH((conv_cin1_d4_kernel<16>), grid4, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
-                return mvs_check_launch("conv_cin1_d4");
-            }
-            const size_t total = (size_t)B * D * H * W;
-            dim3 grid((unsigned)((total + 255) / 256));
-            if (Cin == 8) MVS_LAUNCH((conv_cin1_kernel<8>), grid, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
-            else MVS_LAUNCH((conv_cin1_kernel<16>), grid, dim3(256), 0, stream, gy, (const float*)ws, gx, B, D, H, W);
-            return mvs_check_launch("conv_cin1");
-        }
-        return run_igemm(GEOM_S1, gy, w, WL_IOK, 1, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
-    }
-    MVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MVS_ERR_SHAPE, "conv3d_dgrad stride 2: D,H,W must be even");
-    return run_igemm(GEOM_TR2, gy, w, WL_IOK, 0, gx, ws, B, D / 2, H / 2, W / 2, Cout, Cin, ep, stream);
-}
-
-// The same with `add` [B,D,H,W,Cin] (or NULL) summed into the result in the epilogue: gx = d conv3d / dx + add.  A tensor with two
-// consumers (the U-Net's skip connections, mvsnet.py:70-72) gets its second gradient contribution without a separate pass over it.
-extern "C" int mvs_conv3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H, int W,
-                                    int Cin, int Cout, int stride, hipStream_t stream) {
-    if (!add || (stride == 1 && Cout == 1)) {
-        MVS_REQUIRE(!add, MVS_ERR_UNSUPPORTED, "conv3d_dgrad_acc: the Cout = 1 input gradient takes no summand");
-        return mvs_conv3d_dgrad(gy, w, gx, ws, B, D, H, W, Cin, Cout, stride, stream);
-    }
-    int rc = check_stride(stride, D, H, W, "conv3d_dgrad_acc");
-    if (rc) return rc;
-    Epilogue ep = {nullptr, nullptr, add, 0, nullptr};
-    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_IOK, 1, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
-    MVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, MVS_ERR_SHAPE, "conv3d_dgrad_acc stride 2: D,H,W must be even");
-    return run_igemm(GEOM_TR2, gy, w, WL_IOK, 0, gx, ws, B, D / 2, H / 2, W / 2, Cout, Cin, ep, stream);
+    Epilogue ep = {nullptr, nullptr, add, 0, bn_slots, nslots, bn_raw, bn_stats};
+    MVS_REQUIRE(!bn_slots || bn_raw, MVS_ERR_NULL, "conv3d_dgrad: bn_slots without bn_raw");
+    if (p.cin1) return run_cin1(p, gy, w, gx, ws, ep, ws_packed, stream);
+    return run_igemm(p, gy, w, gx, ws, ep, ws_packed, stream);
 }
 
 // gw[Cout][Cin][27] = d conv3d / dw
@@ -2099,34 +1755,27 @@ extern "C" int mvs_conv3d_wgrad(const float* x, const float* gy, float* gw, floa
     return run_wgrad(stride == 2 ? GEOM_S2 : GEOM_S1, x, gy, gw, ws, B, D, H, W, Cin, Cout, stream);
 }
 
-// y = conv_transpose3d(x, w[Cin][Cout][3][3][3], stride, pad 1, output_padding stride-1)
+// y = conv_transpose3d(x, w[Cin][Cout][3][3][3], stride, pad 1, output_padding stride-1); epilogue like mvs_conv3d_fwd
 extern "C" int mvs_convT3d_fwd(const float* x, const float* w, float* y, float* ws, int B, int D, int H, int W,
                                int Cin, int Cout, int stride, const float* scale, const float* shift,
-                               const float* skip, int relu, float* stat_partials, hipStream_t stream) {
-    int rc = check_stride(stride, D, H, W, "convT3d_fwd");
+                               const float* skip, int relu, double* stat_slots, int nslots, int ws_packed, hipStream_t stream) {
+    IgemmPlan p;
+    int rc = plan_for(MVS_OP_CONVT_FWD, B, D, H, W, Cin, Cout, stride, p, "convT3d_fwd");
     if (rc) return rc;
-    Epilogue ep = {scale, shift, skip, relu, stat_partials};
-    if (stride == 1) return run_igemm(GEOM_S1, x, w, WL_IOK, 1, y, ws, B, D, H, W, Cin, Cout, ep, stream);
-    return run_igemm(GEOM_TR2, x, w, WL_IOK, 0, y, ws, B, D, H, W, Cin, Cout, ep, stream);
+    Epilogue ep = {scale, shift, skip, relu, stat_slots, nslots, nullptr, nullptr};
+    return run_igemm(p, x, w, y, ws, ep, ws_packed, stream);
 }
 
-// gx[B,D,H,W,Cin] from gy[B,sD,sH,sW,Cout]
-extern "C" int mvs_convT3d_dgrad(const float* gy, const float* w, float* gx, float* ws, int B, int D, int H, int W,
-                                 int Cin, int Cout, int stride, hipStream_t stream) {
-    int rc = check_stride(stride, D, H, W, "convT3d_dgrad");
+// gx[B,D,H,W,Cin] from gy[B,sD,sH,sW,Cout]; add / bn_raw / bn_stats / bn_slots as in mvs_conv3d_dgrad
+extern "C" int mvs_convT3d_dgrad(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H,
+                                 int W, int Cin, int Cout, int stride, const float* bn_raw, const float* bn_stats, double* bn_slots,
+                                 int nslots, int ws_packed, hipStream_t stream) {
+    IgemmPlan p;
+    int rc = plan_for(MVS_OP_CONVT_DGRAD, B, D, H, W, Cin, Cout, stride, p, "convT3d_dgrad");
     if (rc) return rc;
-    Epilogue ep = {nullptr, nullptr, nullptr, 0, nullptr};
-    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_OIK, 0, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
-    return run_igemm(GEOM_S2, gy, w, WL_OIK, 0, gx, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, ep, stream);
-}
-
-extern "C" int mvs_convT3d_dgrad_acc(const float* gy, const float* w, const float* add, float* gx, float* ws, int B, int D, int H,
-                                     int W, int Cin, int Cout, int stride, hipStream_t stream) {
-    int rc = check_stride(stride, D, H, W, "convT3d_dgrad_acc");
-    if (rc) return rc;
-    Epilogue ep = {nullptr, nullptr, add, 0, nullptr};
-    if (stride == 1) return run_igemm(GEOM_S1, gy, w, WL_OIK, 0, gx, ws, B, D, H, W, Cout, Cin, ep, stream);
-    return run_igemm(GEOM_S2, gy, w, WL_OIK, 0, gx, ws, B, 2 * D, 2 * H, 2 * W, Cout, Cin, ep, stream);
+    MVS_REQUIRE(!bn_slots || bn_raw, MVS_ERR_NULL, "convT3d_dgrad: bn_slots without bn_raw");
+    Epilogue ep = {nullptr, nullptr, add, 0, bn_slots, nslots, bn_raw, bn_stats};
+    return run_igemm(p, gy, w, gx, ws, ep, ws_packed, stream);
 }
 
 // gw[Cin][Cout][27]

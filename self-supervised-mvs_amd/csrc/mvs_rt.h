@@ -83,6 +83,11 @@ static __device__ __forceinline__ void mvs_dma4(float* lds_dst, const float* gba
     ((void)__hip_atomic_fetch_add((mvs_lds_float*)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) \
     ((void)__hip_atomic_fetch_add((mvs_global_float*)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+// fp64 accumulation slots of the BatchNorm statistics (global_atomic_add_f64, no return value): the order in which workgroups
+// arrive changes the sum by ~1e-16 relative, far below the fp32 values derived from it
+typedef __attribute__((address_space(1))) double mvs_global_double;
+#define MVS_GLOBAL_ATOMIC_ADD_F64(ptr, v) \
+    ((void)__hip_atomic_fetch_add((mvs_global_double*)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 #endif
 
 #define MVS_WAVE 64

@@ -73,11 +73,11 @@ class ConvBnReLU(nn.Module):
             hip_fwd = (self.hip_fwd_train and hip_conv2d_serves(self.conv, x) and x.is_contiguous(memory_format=torch.channels_last))
             if hip_fwd and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64) and self.bn.momentum is not None:
                 # convolution + BatchNorm statistics in one launch, then finalize + apply: no statistics pass over the activation
-                y, parts = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True)
+                y, slots = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True, groups)
                 for _ in range(groups):
                     count_batch(self.bn, self.training)
                 return ops.BnReLUFn.apply(y, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, True,
-                                          self.bn.eps, self.bn.momentum, groups, parts)
+                                          self.bn.eps, self.bn.momentum, groups, slots)
             y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, hip_fwd)
         else:
             y = self.conv(x)

@@ -119,7 +119,7 @@ class MVSNet(nn.Module):
             self.refine_network = RefineNet()
 
     def forward(self, imgs, proj_matrices, depth_values):
-        with batched_bn_counters():
+        with batched_bn_counters(), ops.slot_scope():
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):

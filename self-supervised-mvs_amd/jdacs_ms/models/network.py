@@ -96,6 +96,10 @@ class CVPMVSNet(nn.Module):
         self.align_corners = align_corners
 
     def forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max):
+        with ops.slot_scope():   # one zero-filled arena for the BatchNorm statistic slots of all three regulariser passes
+            return self._forward(ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max)
+
+    def _forward(self, ref_img, src_imgs, ref_in, src_in, ref_ex, src_ex, depth_min, depth_max):
         a = self.args
         depth_est_list = []
         # feature pyramids (stock PyTorch)

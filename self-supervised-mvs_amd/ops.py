@@ -219,11 +219,15 @@ class HomoWarp(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # 3-D convolution family + BatchNorm (K3-K8)
 # ------------------------------------------------------------------------------------------------
-def _ws(lib, op, b, d, h, w, cin, cout, stride, like):
+def _ws_floats(lib, op, b, d, h, w, cin, cout, stride):
     nbytes = lib.raw("mvs_conv3d_workspace_bytes", op, b, d, h, w, cin, cout, stride)
     if nbytes < 0:
         raise ValueError("mvs_conv3d_workspace_bytes: bad op %d" % op)
-    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=like.device)
+    return (nbytes + 15) // 16 * 4        # floats, a multiple of 16 bytes
+
+
+def _ws(lib, op, b, d, h, w, cin, cout, stride, like):
+    return torch.empty(_ws_floats(lib, op, b, d, h, w, cin, cout, stride), dtype=torch.float32, device=like.device)
 
 
 def _ctag(kind, cin, cout, stride, b, d, h, w):
@@ -238,9 +242,65 @@ def _out_dims(d, h, w, stride, transposed):
     return ((d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
 
 
+# ---- BatchNorm statistic slots (csrc/bn.hip) ----------------------------------------------------------------------------
+# A train-mode BatchNorm needs, per statistics group, `nslots` zeroed rows [2][C] of fp64 accumulators for its forward
+# statistics and the same again for its backward statistics.  Inside a `slot_scope()` (MVSNet / CVPMVSNet.forward open one)
+# every layer cuts its rows out of ONE zero-filled arena -- one fill launch per model forward instead of one per layer; the
+# backward rows are cut at forward time too and stay zero until the layer's backward uses them (a second backward through the
+# same graph gets fresh rows).  The arena is allocated inside the scope, so a captured hipGraph re-zeroes it on every replay.
+# Outside a scope each request is its own torch.zeros.
+import threading
+
+_SLOT_TLS = threading.local()
+_ARENA_DOUBLES = 1 << 18          # 2 MB
+
+
+class slot_scope:
+    def __enter__(self):
+        st = getattr(_SLOT_TLS, "state", None)
+        if st is None:
+            st = _SLOT_TLS.state = {"depth": 0, "arenas": {}}
+        st["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        st = _SLOT_TLS.state
+        st["depth"] -= 1
+        if st["depth"] == 0:
+            st["arenas"].clear()
+        return False
+
+
+def bn_nslots(lib, c: int) -> int:
+    n = lib.raw("mvs_bn_slots", c)
+    if n <= 0:
+        raise ValueError("mvs_amd BatchNorm kernels serve 4/8/16/32/64 channels, got %d" % c)
+    return n
+
+
+def stat_slots(like: torch.Tensor, groups: int, nslots: int, c: int, pieces: int = 1):
+    """`pieces` zero-filled fp64 tensors [groups, nslots, 2, c] on like's device."""
+    n = groups * nslots * 2 * c
+    st = getattr(_SLOT_TLS, "state", None)
+    if st is None or st["depth"] == 0:
+        z = torch.zeros(pieces * n, dtype=torch.float64, device=like.device)
+        return [z[i * n:(i + 1) * n].view(groups, nslots, 2, c) for i in range(pieces)]
+    out = []
+    key = (like.device.type, like.device.index)
+    for _ in range(pieces):
+        ent = st["arenas"].get(key)
+        if ent is None or ent[1] + n > ent[0].numel():
+            ent = st["arenas"][key] = [torch.zeros(max(_ARENA_DOUBLES, n), dtype=torch.float64, device=like.device), 0]
+        out.append(ent[0][ent[1]:ent[1] + n].view(groups, nslots, 2, c))
+        ent[1] += n
+    return out
+
+
 def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None, skip=None, relu=False,
-                   want_stats=False):
-    """Raw C-ABI call.  x [B,Cin,D,H,W] (channels_last_3d).  Returns (y, stat_partials|None)."""
+                   want_stats=False, slots=None, packed_ws=None):
+    """Raw C-ABI call.  x [B,Cin,D,H,W] (channels_last_3d).  Returns (y, slots|None).  slots (or want_stats: allocated here):
+    zeroed fp64 [nslots, 2, Cout] that receives the BatchNorm statistics (sum, sum of squares per channel) of the raw output,
+    spread over nslots rows; packed_ws: this op's weight image, already written (pack_conv3d_weights)."""
     lib = _lib_for(x)
     x = as_cl3(x)
     b, cin, d, h, w = x.shape
@@ -251,19 +311,41 @@ def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None
     op = OP_CONVT_FWD if transposed else OP_CONV_FWD
     od, oh, ow = _out_dims(d, h, w, stride, transposed)
     y = empty_cl3(b, cout, od, oh, ow, x)
-    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
-    parts = None
-    if want_stats:
-        rows = lib.raw("mvs_conv3d_stat_rows", op, b, d, h, w, cin, cout, stride)
-        parts = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x) if packed_ws is None else packed_ws
+    nslots = 0
+    if slots is None and want_stats:
+        slots = stat_slots(x, 1, bn_nslots(lib, cout) if cout in (4, 8, 16, 32, 64) else 8, cout, 1)[0][0]
+    if slots is not None:
+        if slots.dtype != torch.float64 or slots.shape[-1] != cout or slots.shape[-2] != 2 or not slots.is_contiguous():
+            raise ValueError("statistic slots must be contiguous float64 [.., nslots, 2, %d], got %s %s" % (cout, slots.dtype, tuple(slots.shape)))
+        nslots = slots.shape[-3]
     if skip is not None:
         skip = as_cl3(skip)
         if skip.shape != y.shape:
             raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(y.shape)))
     lib.call("mvs_convT3d_fwd" if transposed else "mvs_conv3d_fwd", _p(x), _p(wt), _p(y), _p(ws), b, d, h, w, cin,
-             cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(parts), _stream(x),
+             cout, stride, _p(scale), _p(shift), _p(skip), int(relu), _p(slots), nslots, int(packed_ws is not None), _stream(x),
              tag=_ctag("fwdT" if transposed else "fwd", cin, cout, stride, b, d, h, w))
-    return y, parts
+    return y, slots
+
+
+def pack_conv3d_weights(items, like):
+    """items: list of (op, weight, (B, D, H, W, Cin, Cout, stride)) -- forward / input-gradient ops with the FORWARD op's shape.
+    ONE launch writes all their weight images; returns the list of workspace tensors (views of one buffer) to hand to
+    conv3d_forward / conv3d_dgrad as ``packed_ws``."""
+    lib = _lib_for(like)
+    n = len(items)
+    sizes = [_ws_floats(lib, op, *shape) for op, _, shape in items]
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=like.device)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(buf[off:off + sz])
+        off += sz
+    ws_ = [wt.contiguous() for _, wt, _ in items]
+    ops_arr = (C.c_int * n)(*[op for op, _, _ in items])
+    shp_arr = (C.c_int * (7 * n))(*[int(v) for _, _, shape in items for v in shape])
+    lib.call("mvs_conv3d_pack_weights_batch", n, ops_arr, _ptr_array(ws_), _ptr_array(views), shp_arr, _stream(like))
+    return views
 
 
 def conv3d_forward_bf16(x, weight, stride=1, transposed=False, scale=None, shift=None, skip=None, relu=False, out_f32=False):
@@ -305,9 +387,11 @@ def conv_bn_relu3d_eval_bf16(x, weight, gamma, beta, running_mean, running_var, 
     return conv3d_forward_bf16(x, weight, stride, transposed, scale=scale, shift=shift, skip=skip, relu=True)
 
 
-def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False, add=None):
+def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False, add=None, bn=None, packed_ws=None):
     """Input gradient of conv3d / conv_transpose3d; ``add`` (same shape as the result, channels_last_3d) is summed into it in the
-    kernel's epilogue (the second gradient contribution of a tensor with two consumers: the U-Net skips)."""
+    kernel's epilogue (the second gradient contribution of a tensor with two consumers: the U-Net skips).  ``bn`` = (raw, stats,
+    slots): the result is the COMPLETE output gradient of the BatchNorm+ReLU block whose raw output is ``raw`` (stats [4,C]); its
+    backward statistics are added into the zeroed fp64 ``slots`` [.., nslots, 2, C] by the same epilogue."""
     lib = _lib_for(gy)
     gy = as_cl3(gy)
     b, cin, d, h, w = in_shape
@@ -315,17 +399,23 @@ def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False, add=None):
     cout = wt.shape[1] if transposed else wt.shape[0]
     op = OP_CONVT_DGRAD if transposed else OP_CONV_DGRAD
     gx = empty_cl3(b, cin, d, h, w, gy)
-    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, gy)
+    ws = _ws(lib, op, b, d, h, w, cin, cout, stride, gy) if packed_ws is None else packed_ws
     tag = _ctag("dgradT" if transposed else "dgrad", cin, cout, stride, b, d, h, w)
-    if add is None:
-        lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(gx), _p(ws), b, d, h, w,
-                 cin, cout, stride, _stream(gy), tag=tag)
-    else:
+    if add is not None:
         add = as_cl3(add)
         if tuple(add.shape) != tuple(in_shape):
             raise ValueError("conv3d_dgrad: summand shape %s != input shape %s" % (tuple(add.shape), tuple(in_shape)))
-        lib.call("mvs_convT3d_dgrad_acc" if transposed else "mvs_conv3d_dgrad_acc", _p(gy), _p(wt), _p(add), _p(gx), _p(ws), b, d, h,
-                 w, cin, cout, stride, _stream(gy), tag=tag)
+    raw = stats = slots = None
+    nslots = 0
+    if bn is not None:
+        raw, stats, slots = bn
+        raw = as_cl3(raw)
+        if tuple(raw.shape) != tuple(in_shape) or tuple(stats.shape) != (4, cin) or slots.dtype != torch.float64 or \
+                slots.shape[-1] != cin or slots.shape[-2] != 2:
+            raise ValueError("conv3d_dgrad: BatchNorm operands do not match the input shape %s" % (tuple(in_shape),))
+        nslots = slots.shape[-3]
+    lib.call("mvs_convT3d_dgrad" if transposed else "mvs_conv3d_dgrad", _p(gy), _p(wt), _p(add), _p(gx), _p(ws), b, d, h, w,
+             cin, cout, stride, _p(raw), _p(stats), _p(slots), nslots, int(packed_ws is not None), _stream(gy), tag=tag)
     return gx
 
 
@@ -451,10 +541,40 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     return gw
 
 
+def bn_relu_fwd_slots(x, slots, gamma, beta, running_mean, running_var, eps, momentum, skip=None, relu=True, groups=1):
+    """y = relu(BatchNorm_train(x)) (+ skip) from the statistic slots of x (written by the kernel that produced x); -> (y, stats
+    [groups, 4, C]: mean, invstd, scale, shift).  x channels-last [B,C,...]; the groups are equal chunks of the batch."""
+    lib = _lib_for(x)
+    c = x.shape[1]
+    vg = x.numel() // c // groups
+    stats = torch.empty((groups, 4, c), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x, memory_format=CL2 if x.dim() == 4 else CL3)
+    lib.call("mvs_bn_relu_fwd_slots", _p(x), _p(slots), slots.shape[-3], groups, vg, c, _p(gamma), _p(beta), float(eps),
+             float(momentum), _p(running_mean), _p(running_var), _p(skip), int(relu), _p(stats), _p(y), _stream(x))
+    return y, stats
+
+
+def bn_relu_bwd_slots(gy, x, stats, slots, have_stats, relu=True, groups=1):
+    """BatchNorm(+ReLU) backward: (dx, dgamma, dbeta).  have_stats: the slots already hold (sum dyh, sum dyh*xhat) -- an
+    input-gradient epilogue wrote them (conv3d_dgrad(bn=...)); otherwise one reduction pass over (gy, x) fills them first."""
+    lib = _lib_for(x)
+    c = x.shape[1]
+    vg = x.numel() // c // groups
+    st = _stream(x)
+    if not have_stats:
+        lib.call("mvs_bn_bwd_reduce_slots", _p(gy), _p(x), _p(stats), int(relu), groups, vg, c, _p(slots), slots.shape[-3], st)
+    dx = torch.empty_like(x, memory_format=CL2 if x.dim() == 4 else CL3)
+    dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    lib.call("mvs_bn_relu_bwd_slots", _p(gy), _p(x), _p(stats), _p(slots), slots.shape[-3], int(relu), groups, vg, c, _p(dx),
+             _p(dgb[0]), _p(dgb[1]), st)
+    return dx, dgb[0], dgb[1]
+
+
 class ConvBnReLU3dFn(torch.autograd.Function):
     """conv3d | conv_transpose3d (bias-free, k3 p1) -> BatchNorm3d -> ReLU (-> + skip, after the ReLU).
 
-    Train: batch statistics (partials from the conv epilogue), running stats updated in place.
+    Train: batch statistics (slots filled by the conv epilogue, finished in the apply kernel's prologue), running stats
+    updated in place.
     Eval : BatchNorm folded into the conv epilogue (no gradient support -- the reference only
     evaluates under no_grad, jdacs/eval.py:143)."""
 
@@ -476,19 +596,14 @@ class ConvBnReLU3dFn(torch.autograd.Function):
             return y
         if ctx.needs_input_grad[1]:
             _note_weight_use(weight)
-        raw, parts = conv3d_forward(x, weight, stride, transposed, want_stats=True)
-        b, _, od, oh, ow = raw.shape
-        count = b * od * oh * ow
-        stats = torch.empty((4, cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        lib.call("mvs_bn_finalize", _p(parts), parts.shape[0], cout, count, _p(gamma), _p(beta), float(eps),
-                 float(momentum), _p(running_mean), _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                 _p(stats[3]), st)
-        y = torch.empty_like(raw, memory_format=CL3)
+        slots_f, slots_b = stat_slots(x, 1, bn_nslots(lib, cout), cout, 2)
+        raw, _ = conv3d_forward(x, weight, stride, transposed, slots=slots_f)
         skip_c = None if skip is None else as_cl3(skip)
-        lib.call("mvs_bn_relu_fwd", _p(raw), _p(stats[2]), _p(stats[3]), _p(skip_c), 1, count, cout, _p(y), st)
-        ctx.save_for_backward(x, weight, raw, stats)
-        ctx.cfg = (stride, transposed, skip is not None, count, cout)
+        y, stats = bn_relu_fwd_slots(raw, slots_f, gamma, beta, running_mean, running_var, eps, momentum, skip_c)
+        ctx.save_for_backward(x, weight, raw, stats, slots_b)
+        ctx.cfg = (stride, transposed, skip is not None, cout)
         ctx.eval_mode = False
+        ctx.slots_used = False
         return y
 
     @staticmethod
@@ -496,29 +611,30 @@ class ConvBnReLU3dFn(torch.autograd.Function):
         if ctx.eval_mode:
             raise NotImplementedError("mvs_amd: backward through eval-mode (folded) BatchNorm is not supported; "
                                       "call .train() for training or use torch.no_grad() for inference")
-        x, weight, raw, stats = ctx.saved_tensors
-        stride, transposed, has_skip, count, cout = ctx.cfg
-        lib = _lib_for(x)
-        st = _stream(x)
+        x, weight, raw, stats, slots_b = ctx.saved_tensors
+        stride, transposed, has_skip, cout = ctx.cfg
         gy = as_cl3(gy)
-        ws = torch.empty(1024 * 2 * cout + 2 * cout, dtype=torch.float32, device=x.device)
-        draw = torch.empty_like(raw, memory_format=CL3)
-        dgb = torch.empty((2, cout), dtype=torch.float32, device=x.device)
-        lib.call("mvs_bn_relu_bwd", _p(gy), _p(raw), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, count,
-                 cout, _p(ws), _p(draw), _p(dgb[0]), _p(dgb[1]), st)
+        if ctx.slots_used:                       # a second backward through the same graph: fresh accumulators
+            slots_b = torch.zeros_like(slots_b)
+        ctx.slots_used = True
+        draw, dgamma, dbeta = bn_relu_bwd_slots(gy, raw, stats[0], slots_b, False)
         gx = conv3d_dgrad(draw, weight, tuple(x.shape), stride, transposed) if ctx.needs_input_grad[0] else None
         gw = _wgrad_maybe_async(x, draw, weight, stride, transposed) if ctx.needs_input_grad[1] else None
         gskip = gy if has_skip else None
-        return gx, gw, dgb[0], dgb[1], None, None, gskip, None, None, None, None, None
+        return gx, gw, dgamma, dbeta, None, None, gskip, None, None, None, None, None
 
 
 # ---- the whole regulariser as ONE autograd node ----------------------------------------------------------------------------
 # jdacs/models/mvsnet.py:37-74 and jdacs-ms/models/network.py:44-74 are short straight-line programs of ConvBnReLU3D /
 # Deconv+BN+ReLU blocks with skips added after the ReLU, closed by the bias-only `prob` convolution.  Running one program
-# through ONE torch.autograd.Function (the same kernels as the per-layer Functions above, launched in the same order) buys what the
-# per-layer graph cannot give:
+# through ONE torch.autograd.Function buys what the per-layer graph cannot give:
 #  * the second gradient contribution of a skip source is summed in the EPILOGUE of the input-gradient kernel of its other
 #    consumer (conv3d_dgrad(add=...)) instead of autograd's out-of-place add (three passes over the 126 MB level-0 tensor);
+#  * round 4: the BatchNorm BACKWARD statistics of a block are summed in the epilogue of the input-gradient kernel that writes the
+#    block's complete output gradient (conv3d_dgrad(bn=...)): no reduction pass over (dy, raw) -- and all BatchNorm statistics,
+#    forward and backward, are finished in the prologue of the kernel that applies them (csrc/bn.hip): a block costs conv + apply
+#    forward and apply + dgrad backward, where rounds 1-3 ran conv, finalize, apply / reduce, finalize, apply, dgrad;
+#  * round 4: the MFMA weight images of all forward and input-gradient convolutions are packed by ONE launch per step;
 #  * weight gradients run on a side HIP stream BY DEFAULT: they are handed to autograd only after the side stream has been joined,
 #    at the end of this node's backward, so DataParallel / DDP hooks (which fire when a gradient is RETURNED) can never observe an
 #    unfinished one -- the per-layer form had to leave that off (see _wgrad_maybe_async);
@@ -536,31 +652,50 @@ class UNetRegulariserFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, prog, *params):
         lib = _lib_for(x)
-        st = _stream(x)
         x = as_cl3(x)
-        dev = x.device
         n = len(prog)
-        ys, raws, statss = [], [], []
+        need = ctx.needs_input_grad          # [x, prog, *params]
+        wp, bp = params[5 * n], params[5 * n + 1]
+        # ---- shapes of every block's input, then ONE launch packs all weight images (forward + input gradient) ----
+        shapes, in_shape = [], {-1: tuple(x.shape)}
+        for i, (transposed, stride, src, skip, eps, momentum) in enumerate(prog):
+            w = params[5 * i]
+            b, cin, d, h, wd = in_shape[src]
+            cout = w.shape[1] if transposed else w.shape[0]
+            shapes.append((b, d, h, wd, cin, cout, stride))
+            in_shape[i] = (b, cout) + _out_dims(d, h, wd, stride, transposed)
+        bq, cq, dq, hq, wq = in_shape[n - 1]
+        pshape = (bq, dq, hq, wq, cq, wp.shape[0], 1)
+        any_grad = any(need)
+        items = [(OP_CONVT_FWD if prog[i][0] else OP_CONV_FWD, params[5 * i], shapes[i]) for i in range(n)]
+        dg_index = {}
+        if any_grad:
+            for i in range(n):
+                if prog[i][2] >= 0 or need[0]:
+                    dg_index[i] = len(items)
+                    items.append((OP_CONVT_DGRAD if prog[i][0] else OP_CONV_DGRAD, params[5 * i], shapes[i]))
+            dg_index[n] = len(items)
+            items.append((OP_CONV_DGRAD, wp, pshape))
+        packed = pack_conv3d_weights(items, x)
+        ys, raws, statss, slots_b = [], [], [], []
         for i, (transposed, stride, src, skip, eps, momentum) in enumerate(prog):
             w, gamma, beta, rmean, rvar = params[5 * i:5 * i + 5]
             xin = x if src < 0 else ys[src]
-            cout = w.shape[1] if transposed else w.shape[0]
-            raw, parts = conv3d_forward(xin, w, stride, transposed, want_stats=True)
-            b, _, od, oh, ow = raw.shape
-            count = b * od * oh * ow
-            stats = torch.empty((4, cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-            lib.call("mvs_bn_finalize", _p(parts), parts.shape[0], cout, count, _p(gamma), _p(beta), float(eps), float(momentum),
-                     _p(rmean), _p(rvar), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), st)
-            y = torch.empty_like(raw, memory_format=CL3)
-            lib.call("mvs_bn_relu_fwd", _p(raw), _p(stats[2]), _p(stats[3]), _p(ys[skip] if skip >= 0 else None), 1, count, cout,
-                     _p(y), st)
+            cout = shapes[i][5]
+            sf, sb = stat_slots(x, 1, bn_nslots(lib, cout), cout, 2)
+            raw, _ = conv3d_forward(xin, w, stride, transposed, slots=sf, packed_ws=packed[i])
+            y, stats = bn_relu_fwd_slots(raw, sf, gamma, beta, rmean, rvar, eps, momentum, ys[skip] if skip >= 0 else None)
             ys.append(y)
             raws.append(raw)
-            statss.append(stats)
-        wp, bp = params[5 * n], params[5 * n + 1]
+            statss.append(stats[0])
+            slots_b.append(sb)
         logits, _ = conv3d_forward(ys[-1], wp, 1, False, shift=bp.contiguous())
         ctx.prog = prog
-        ctx.save_for_backward(x, wp, *[params[5 * i] for i in range(n)], *ys, *raws, *statss)
+        ctx.shapes = shapes
+        ctx.dg_index = dg_index
+        ctx.npacked = len(packed)
+        ctx.slots_used = False
+        ctx.save_for_backward(x, wp, *[params[5 * i] for i in range(n)], *ys, *raws, *statss, *slots_b, *packed)
         return logits
 
     @staticmethod
@@ -569,13 +704,17 @@ class UNetRegulariserFn(torch.autograd.Function):
         n = len(prog)
         sv = ctx.saved_tensors
         x, wp = sv[0], sv[1]
-        ws_, ys, raws, statss = sv[2:2 + n], sv[2 + n:2 + 2 * n], sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n]
+        ws_, ys, raws, statss, slots_b = (sv[2 + k * n:2 + (k + 1) * n] for k in range(5))
+        packed = sv[2 + 5 * n:]
+        dg_index = ctx.dg_index
         lib = _lib_for(x)
-        st = _stream(x)
         dev = x.device
         need = ctx.needs_input_grad          # [x, prog, *params]
         main = torch.cuda.current_stream(dev) if x.is_cuda else None
         side_used = [False]
+        if ctx.slots_used:                   # a second backward through the same graph: fresh accumulators
+            slots_b = [torch.zeros_like(t) for t in slots_b]
+        ctx.slots_used = True
 
         def wgrad(xin, gout, weight, stride, transposed, wanted):
             """weight gradient, on the side stream when allowed (joined before this node returns)"""
@@ -602,12 +741,28 @@ class UNetRegulariserFn(torch.autograd.Function):
             side_used[0] = True
             return gw
 
+        # the consumer that contributes LAST to a block's output gradient (blocks run last to first; within a block the skip
+        # contribution precedes the input gradient): if it does so through its input gradient, that kernel's epilogue also sums the
+        # block's BatchNorm backward statistics
+        last = [n] * n                                   # n = the prob layer (only block n-1 feeds it)
+        for i in range(n):
+            for j in (prog[i][2], prog[i][3]):
+                if j >= 0:
+                    last[j] = min(last[j], i)
+
+        def bn_of(j, i):
+            """BatchNorm operands for the input-gradient kernel of consumer i writing block j's gradient, if it completes it"""
+            return (raws[j], statss[j], slots_b[j]) if (last[j] == i and (i == n or prog[i][2] == j)) else None
+
         grads = [None] * (5 * n + 2)
         g = [None] * n                                   # gradient w.r.t. block outputs, summed over their consumers
+        have = [False] * n                               # backward statistics of block j already in slots_b[j]
         gx = None
         # ---- prob layer ----
         gy = as_cl3(glogits)
-        g[n - 1] = conv3d_dgrad(gy, wp, tuple(ys[-1].shape), 1, False)
+        bn = bn_of(n - 1, n) if last[n - 1] == n else None
+        g[n - 1] = conv3d_dgrad(gy, wp, tuple(ys[-1].shape), 1, False, bn=bn, packed_ws=packed[dg_index[n]])
+        have[n - 1] = bn is not None
         grads[5 * n] = wgrad(ys[-1], gy, wp, 1, False, need[2 + 5 * n])
         if need[2 + 5 * n + 1]:
             grads[5 * n + 1] = gy.sum().reshape(1) if gy.shape[1] == 1 else gy.sum(dim=(0, 2, 3, 4))
@@ -616,22 +771,17 @@ class UNetRegulariserFn(torch.autograd.Function):
             transposed, stride, src, skip, eps, momentum = prog[i]
             gy = g[i]
             g[i] = None
-            raw, stats, w = raws[i], statss[i], ws_[i]
-            cout = raw.shape[1]
-            count = raw.numel() // cout
-            wsb = torch.empty(1024 * 2 * cout + 2 * cout, dtype=torch.float32, device=dev)
-            draw = torch.empty_like(raw, memory_format=CL3)
-            dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
-            lib.call("mvs_bn_relu_bwd", _p(gy), _p(raw), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), 1, count, cout,
-                     _p(wsb), _p(draw), _p(dgb[0]), _p(dgb[1]), st)
-            grads[5 * i + 1], grads[5 * i + 2] = dgb[0], dgb[1]
+            raw, w = raws[i], ws_[i]
+            draw, grads[5 * i + 1], grads[5 * i + 2] = bn_relu_bwd_slots(gy, raw, statss[i], slots_b[i], have[i])
             if skip >= 0:                                # y = relu(bn(raw)) + y_skip: the skip source receives gy as it is
                 g[skip] = gy if g[skip] is None else g[skip] + gy
             xin = x if src < 0 else ys[src]
             if src >= 0:
-                g[src] = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=g[src])
+                bn = bn_of(src, i)
+                g[src] = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=g[src], bn=bn, packed_ws=packed[dg_index[i]])
+                have[src] = bn is not None
             elif need[0]:
-                gx = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=gx)
+                gx = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=gx, packed_ws=packed[dg_index[i]])
             grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
         if side_used[0]:
             main.wait_stream(_SIDE_STREAMS[dev.index])   # every weight gradient is complete before autograd sees it
@@ -657,23 +807,24 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False):
+    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False, groups=1):
         """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
-        the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm partial rows of y), the rows not differentiable."""
+        the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm statistic slots of y for `groups` equal batch
+        chunks), the slots not differentiable."""
         if ctx.needs_input_grad[1]:
             _note_weight_use(weight)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
         if hip_forward and want_stats:
-            y, parts = conv2d_forward(x, weight, None, stride[0], want_stats=True)
-            ctx.mark_non_differentiable(parts)
-            return y, parts
+            y, slots = conv2d_forward(x, weight, None, stride[0], want_stats=True, groups=groups)
+            ctx.mark_non_differentiable(slots)
+            return y, slots
         if hip_forward:
             return conv2d_forward(x, weight, None, stride[0])
         return torch.ops.aten.convolution(x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1)
 
     @staticmethod
-    def backward(ctx, gy, *_unused_grad_of_the_partial_rows):
+    def backward(ctx, gy, *_unused_grad_of_the_slots):
         x, weight = ctx.saved_tensors
         stride, padding = ctx.cfg
         bwd = torch.ops.aten.convolution_backward
@@ -683,7 +834,7 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
             gw = _maybe_on_side_stream(fn, weight, (x, gy))
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None
 
 
 def _maybe_on_side_stream(fn, weight, inputs):
@@ -719,18 +870,18 @@ def _maybe_on_side_stream(fn, weight, inputs):
 
 class BnReLUFn(torch.autograd.Function):
     """BatchNorm (+ReLU) over the channel dim of a channels-last tensor [B,C,H,W] / [B,C,D,H,W] with the same
-    HIP kernels as the 3-D regulariser (statistics partials -> fp64 finalize -> one apply pass; two-pass
-    backward).  Used by the 2-D ConvBnReLU blocks of the feature extractors (jdacs/models/module.py:15-22),
-    where MIOpen's BatchNorm kernels take ~40 us per call at B=1 with 8-32 channels.
+    HIP kernels as the 3-D regulariser (statistic slots -> ONE apply pass that finishes them in its prologue; backward: one
+    reduction pass + one apply pass).  Used by the 2-D ConvBnReLU blocks of the feature extractors
+    (jdacs/models/module.py:15-22), where MIOpen's BatchNorm kernels take ~40 us per call at B=1 with 8-32 channels.
 
     ``groups`` > 1: the batch holds `groups` equal chunks (the N views of a sample pushed through the
     shared-weight extractor as one batch); statistics are taken per chunk and the running statistics are
     updated chunk after chunk, i.e. exactly what `groups` successive BatchNorm calls do."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, groups, parts=None):
-        """parts [rows,2,C] (train mode): partial sums of x already written by the convolution that produced it
-        (conv2d_forward(want_stats=True)), rows of a statistics group consecutive -- no statistics pass over x."""
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, eps, momentum, groups, slots=None):
+        """slots [groups, nslots, 2, C] fp64 (train mode): statistics of x already summed by the convolution that produced it
+        (conv2d_forward(want_stats=True)) -- no statistics pass over x."""
         lib = _lib_for(x)
         st = _stream(x)
         c = x.shape[1]
@@ -739,36 +890,40 @@ class BnReLUFn(torch.autograd.Function):
         fmt = CL2 if x.dim() == 4 else CL3
         x = x.contiguous(memory_format=fmt)
         vg = x.numel() // c // groups
-        dev = x.device
-        stats = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        ws = torch.empty(groups * 512 * 2 * c, dtype=torch.float32, device=dev)
-        y = torch.empty_like(x, memory_format=fmt)
-        if parts is not None and training:
-            if parts.shape[0] % groups or tuple(parts.shape[1:]) != (2, c):
-                raise ValueError("BatchNorm partial rows %s do not split into %d groups of [rows,2,%d]" % (tuple(parts.shape), groups, c))
-            lib.call("mvs_bn_group_relu_fwd_parts", _p(x), _p(parts.contiguous()), parts.shape[0] // groups, groups, vg, c, _p(gamma),
-                     _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), 1, _p(stats), _p(y), st)
+        ctx.cfg = (training, c, fmt, groups)
+        if not training:
+            scale = torch.empty(c, dtype=torch.float32, device=x.device)
+            shift = torch.empty_like(scale)
+            lib.call("mvs_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), c, _p(scale), _p(shift), st)
+            y = torch.empty_like(x, memory_format=fmt)
+            lib.call("mvs_bn_relu_fwd", _p(x), _p(scale), _p(shift), None, 1, x.numel() // c, c, _p(y), st)
+            return y
+        nslots = bn_nslots(lib, c)
+        if slots is not None:
+            if slots.dtype != torch.float64 or tuple(slots.shape[0:1] + slots.shape[2:]) != (groups, 2, c) or not slots.is_contiguous():
+                raise ValueError("BatchNorm statistic slots %s %s do not match %d groups of [nslots,2,%d] float64"
+                                 % (slots.dtype, tuple(slots.shape), groups, c))
+            (slots_b,) = stat_slots(x, groups, nslots, c, 1)
         else:
-            lib.call("mvs_bn_group_relu_fwd", _p(x), groups, vg, c, _p(gamma), _p(beta), float(eps), float(momentum),
-                     _p(running_mean), _p(running_var), int(training), 1, _p(ws), _p(stats), _p(y), st)
-        ctx.save_for_backward(x, stats)
-        ctx.cfg = (training, vg, c, fmt, groups)
+            slots, slots_b = stat_slots(x, groups, nslots, c, 2)
+            lib.call("mvs_bn_stats_slots", _p(x), groups, vg, c, _p(slots), slots.shape[1], st)
+        y, stats = bn_relu_fwd_slots(x, slots, gamma, beta, running_mean, running_var, eps, momentum, None, True, groups)
+        ctx.save_for_backward(x, stats, slots_b)
+        ctx.slots_used = False
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, stats = ctx.saved_tensors
-        training, vg, c, fmt, groups = ctx.cfg
+        training, c, fmt, groups = ctx.cfg
         if not training:
             raise NotImplementedError("mvs_amd: backward through eval-mode BatchNorm is not supported")
-        lib = _lib_for(x)
+        x, stats, slots_b = ctx.saved_tensors
         gy = gy.contiguous(memory_format=fmt)
-        ws = torch.empty(groups * 512 * 2 * c + groups * 2 * c, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x, memory_format=fmt)
-        dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        lib.call("mvs_bn_group_relu_bwd", _p(gy), _p(x), _p(stats), 1, groups, vg, c, _p(ws), _p(dx), _p(dgb[0]),
-                 _p(dgb[1]), _stream(x))
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+        if ctx.slots_used:
+            slots_b = torch.zeros_like(slots_b)
+        ctx.slots_used = True
+        dx, dgamma, dbeta = bn_relu_bwd_slots(gy, x, stats, slots_b, False, True, groups)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class ConvBias3dFn(torch.autograd.Function):
@@ -930,10 +1085,11 @@ def _c2_ws(lib, op, n, h, w, cin, cout, ks, stride, like):
     return torch.empty(nfl, dtype=torch.float32, device=like.device)
 
 
-def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False):
+def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1):
     """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last);
-    negative_slope: LeakyReLU fused after the bias.  want_stats (no bias / activation): -> (y, partials [rows,2,Cout]), the
-    BatchNorm partial sums of y written by the convolution's epilogue, rows of image n consecutive (BnReLUFn's ``parts``)."""
+    negative_slope: LeakyReLU fused after the bias.  want_stats (no bias / activation): -> (y, slots [groups,nslots,2,Cout] fp64),
+    the BatchNorm statistics of y summed by the convolution's epilogue, the N images being `groups` equal chunks (BnReLUFn's
+    ``slots``)."""
     lib = _lib_for(x)
     x = as_cl2(x)
     n, cin, h, w = x.shape
@@ -946,11 +1102,12 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
     if want_stats:
         if bias is not None or negative_slope is not None:
             raise ValueError("conv2d_forward: statistics are those of the plain convolution (no bias / activation)")
-        rows = lib.raw("mvs_conv2d_stat_rows", n, h, w, ks, stride)
-        parts = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
-        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous()), _p(y), _p(ws), _p(parts), n, h, w, cin, cout, ks, stride,
-                 _stream(x), tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
-        return y, parts
+        if n % groups:
+            raise ValueError("conv2d_forward: %d images do not split into %d statistics groups" % (n, groups))
+        (slots,) = stat_slots(x, groups, bn_nslots(lib, cout), cout, 1)
+        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous()), _p(y), _p(ws), _p(slots), slots.shape[1], groups, n, h, w,
+                 cin, cout, ks, stride, _stream(x), tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+        return y, slots
     if negative_slope is not None:
         lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
                  n, h, w, cin, cout, ks, stride, float(negative_slope), _stream(x), tag="fwd2d_lrelu:%d>%d:k%d:s%d" % (cin, cout, ks, stride))

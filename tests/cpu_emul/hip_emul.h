@@ -251,6 +251,17 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define MVS_WAIT_VMCNT(n) ((void)0)
 #define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
+static inline void emul_atomic_add_f64(double* addr, double v) {
+    unsigned long long* p = (unsigned long long*)addr;
+    unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED), nw;
+    double f;
+    do {
+        memcpy(&f, &old, 8);
+        f += v;
+        memcpy(&nw, &f, 8);
+    } while (!__atomic_compare_exchange_n(p, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+#define MVS_GLOBAL_ATOMIC_ADD_F64(ptr, v) emul_atomic_add_f64((ptr), (v))
 #define MVS_NT_STORE4(ptr, o) (*reinterpret_cast<float4*>(ptr) = (o))
 #define MVS_RCP(x) (1.0f / (x))
 static inline int emul_f2i(float x) { return x != x ? 0 : (x >= 2147483647.0f ? 2147483647 : (x <= -2147483648.0f ? (-2147483647 - 1) : (int)x)); }

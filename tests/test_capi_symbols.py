@@ -69,10 +69,16 @@ def test_error_convention_of_every_entry_point():
     null_calls = [
         ("mvs_plane_sweep_variance_fwd", (None, None, None, None, None, 0, 1, 3, 32, 8, 8, 8, 0, 0, None, None)),
         ("mvs_homo_warp_fwd", (None, None, None, None, 0, 1, 8, 4, 8, 8, 0, None, None)),
-        ("mvs_conv3d_fwd", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None, None, None, 0, None, None)),
-        ("mvs_conv3d_dgrad", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None)),
+        ("mvs_conv3d_fwd", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None, None, None, 0, None, 0, 0, None)),
+        ("mvs_conv3d_dgrad", (None, None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None, None, None, 0, 0, None)),
+        ("mvs_convT3d_dgrad", (None, None, None, None, None, 1, 4, 4, 8, 16, 8, 2, None, None, None, 0, 0, None)),
         ("mvs_conv3d_wgrad", (None, None, None, None, 1, 8, 8, 16, 8, 8, 1, None)),
-        ("mvs_convT3d_fwd", (None, None, None, None, 1, 4, 4, 8, 16, 8, 2, None, None, None, 0, None, None)),
+        ("mvs_convT3d_fwd", (None, None, None, None, 1, 4, 4, 8, 16, 8, 2, None, None, None, 0, None, 0, 0, None)),
+        ("mvs_conv3d_pack_weights", (0, None, None, 1, 8, 8, 16, 8, 8, 1, None)),
+        ("mvs_bn_stats_slots", (None, 1, 64, 8, None, 16, None)),
+        ("mvs_bn_relu_fwd_slots", (None, None, 16, 1, 64, 8, None, None, 1e-5, 0.1, None, None, None, 1, None, None, None)),
+        ("mvs_bn_bwd_reduce_slots", (None, None, None, 1, 1, 64, 8, None, 16, None)),
+        ("mvs_bn_relu_bwd_slots", (None, None, None, None, 16, 1, 1, 64, 8, None, None, None, None)),
         ("mvs_bn_relu_fwd", (None, None, None, None, 1, 64, 8, None, None)),
         ("mvs_softargmin_conf_bwd", (None, None, None, 0, None, None, None, 1, 4, 2, 2, None, None)),
         ("mvs_unsup_loss_fwd", (None, None, None, None, None, 1, 4, 8, 8, 1.0, None, None, None)),
@@ -88,7 +94,7 @@ def test_error_convention_of_every_entry_point():
     assert lib.raw("mvs_unsup_loss_workspace_floats", 1, 4, 2, 8) == -1
     assert lib.raw("mvs_depth_hypo_workspace_doubles", 0, 8, 8) == -1
     assert lib.raw("mvs_unsup_loss_workspace_floats", 2, 4, 16, 20) == 4 * 2 * 320 * 4 + (4 * 4 + 2) * 3 + 64 + 2 * 2 * 14 * 18 * 9
-    assert lib.raw("mvs_conv3d_stat_rows", 0, 1, 192, 128, 160, 32, 8, 1) == 15360
+    assert [lib.raw("mvs_bn_slots", c) for c in (4, 8, 16, 32, 64, 12)] == [128, 128, 64, 32, 16, -1]
     # unknown tuning key
     with pytest.raises(ValueError, match="unknown key"):
         lib.call("mvs_set_tuning", b"zz_no_such_knob", 1)

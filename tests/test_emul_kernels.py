@@ -258,7 +258,7 @@ def test_conv3d_family(emul_lib, conv_tiles, cin, cout, stride, transposed, dims
     y, parts = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
     assert y.shape == yr.shape
     assert float((y - yr).abs().max()) < 2e-4
-    s = parts.sum(0)
+    s = parts.sum(0).float()
     assert torch.allclose(s[0], yr.detach().sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
     assert torch.allclose(s[1], (yr.detach() ** 2).sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
     gy = torch.randn(yr.shape, generator=g)
@@ -544,7 +544,7 @@ def test_conv_multi_cout_tiles_per_workgroup(emul_lib):
                   else F.conv3d(x, w, stride=stride, padding=1))
             y, parts = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
             assert float((y - yr).abs().max()) < 2e-4
-            assert torch.allclose(parts.sum(0)[0], yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
+            assert torch.allclose(parts.sum(0)[0].float(), yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
     finally:
         emul_lib.call("mvs_set_tuning", b"conv_split", 1)
 
@@ -634,7 +634,7 @@ def test_conv_c8_broadcast_operand_forward(emul_lib, cin, dims, xcd):
     try:
         y, parts = ops.conv3d_forward(x, w, 1, False, want_stats=True)
         assert float((y - yr).abs().max()) < 2e-4
-        s = parts.sum(0)
+        s = parts.sum(0).float()
         assert torch.allclose(s[0], yr.sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
         assert torch.allclose(s[1], (yr ** 2).sum(dim=(0, 2, 3, 4)), atol=1e-2, rtol=1e-4)
         scale = torch.rand(8, generator=g) + 0.5
@@ -877,32 +877,6 @@ def test_plane_sweep_fwd_quad_shared_projection(emul_lib, ns, hw, dl):
     assert float((outs[1] - exp).abs().max()) < 2e-4
 
 
-@pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="1.5 minutes of emulation for a non-default variant; set MVS_EMUL_FULL=1")
-@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 16, 1, False, (9, 9, 33)), (8, 16, 2, False, (10, 16, 40)),
-                                                             (16, 8, 2, True, (5, 5, 20))])
-def test_conv3d_fast_staging_variant(emul_lib, cin, cout, stride, transposed, dims):
-    """Generic implicit-GEMM kernels with the fast halo staging of interior tiles (tuning knob "fs", not the default): volumes
-    large enough to have interior tiles next to boundary ones; forward + input gradient, bit-identical to the default."""
-    from mvs_amd import ops
-    g = torch.Generator().manual_seed(cin + cout + stride)
-    x = torch.randn(1, cin, *dims, generator=g)
-    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
-    w = torch.randn(wshape, generator=g) * 0.2
-    y0, _ = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
-    gy = torch.randn(y0.shape, generator=g)
-    can_dgrad = not (stride == 2 and not transposed and any(s % 2 for s in dims))
-    gx0 = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed) if can_dgrad else None
-    emul_lib.call("mvs_set_tuning", b"fs", 1)
-    try:
-        y1, _ = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
-        gx1 = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed) if can_dgrad else None
-    finally:
-        emul_lib.call("mvs_set_tuning", b"fs", 0)
-    assert torch.equal(y0, y1)
-    if can_dgrad:
-        assert torch.equal(gx0, gx1)
-
-
 # ---- bf16-storage inference path (BASELINE configs[4]) -------------------------------------------------------------------
 BF16_CONV_CASES = [(32, 8, 1, False, (5, 6, 20)), (32, 8, 1, False, (7, 3, 33)), (16, 16, 1, False, (4, 5, 18)), (64, 64, 1, False, (3, 4, 17)), (8, 1, 1, False, (6, 5, 19)), (16, 1, 1, False, (5, 9, 18)),
                    (8, 16, 2, False, (6, 8, 34)), (32, 64, 2, False, (4, 6, 18)), (64, 32, 2, True, (2, 3, 9)), (16, 8, 2, True, (3, 4, 17)), (16, 8, 2, True, (5, 5, 9))]
@@ -1135,43 +1109,14 @@ def test_fusion_chain_on_files_vs_oracle(emul_lib, tmp_path):
 _full = pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="a non-default kernel: 30 s of emulation per case; set MVS_EMUL_FULL=1")
 
 
-@pytest.mark.parametrize("cin,cout,dims,slots", [(16, 16, (5, 6, 19), 3), pytest.param(8, 32, (3, 5, 33), 2, marks=_full),
-                                                 pytest.param(32, 64, (5, 3, 9), 1, marks=_full)])
-def test_conv3d_persistent_stride1_kernel(emul_lib, cin, cout, dims, slots):
-    """The persistent stride-1 implicit-GEMM kernel (knob conv_persist; not the default: measured slower): a handful of workgroups
-    walking several ragged tiles each (boundary tiles, the next tile's halo held in registers across the k-loop, one BatchNorm partial
-    row per TILE), forward and input gradient, one and several channel chunks / Cout tiles: BIT-IDENTICAL to the one-tile-per-workgroup
-    kernel (same k-order), and equal to ATen within fp32 rounding."""
-    from mvs_amd import ops
-    g = torch.Generator().manual_seed(cin + cout)
-    x = torch.randn(1, cin, *dims, generator=g)
-    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2
-    gy = torch.randn(1, cout, *dims, generator=g)
-    outs = {}
-    slots = slots + 1                      # knob values > 1 = that many workgroups
-    emul_lib.call("mvs_set_tuning", b"conv_small", 0)
-    try:
-        for mode in (0, slots):
-            emul_lib.call("mvs_set_tuning", b"conv_persist", mode)
-            y, parts = ops.conv3d_forward(x, w, 1, False, want_stats=True)
-            gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), 1, False)
-            outs[mode] = (y, parts, gx)
-    finally:
-        emul_lib.call("mvs_set_tuning", b"conv_persist", 0)
-        emul_lib.call("mvs_set_tuning", b"conv_small", 1)
-    for a, b_ in zip(outs[0], outs[slots]):
-        assert torch.equal(a, b_)
-    xr = x.clone().requires_grad_(True)
-    yr = F.conv3d(xr, w, padding=1)
-    yr.backward(gy)
-    assert float((outs[slots][0] - yr).abs().max()) < 2e-4
-    assert float((outs[slots][2] - xr.grad).abs().max()) < 5e-4
+def _close(a, b, tol=2e-5):
+    return float((a - b).abs().max()) <= tol * max(1e-3, float(b.abs().max()))
 
 
 def test_fused_regulariser_node_on_a_small_program(emul_lib):
     """The one-node regulariser (ops.UNetRegulariserFn) on a three-block U-Net small enough for the default CPU suite -- stride-1
     conv, stride-2 conv, stride-2 transposed conv with the skip added after its ReLU, bias-only prob layer -- against the per-layer
-    autograd graph built from the same modules: logits, input gradient, parameter gradients, BatchNorm buffers bit-identical."""
+    autograd graph built from the same modules: logits and BatchNorm buffers bit-identical, input / parameter gradients to fp32 rounding."""
     from mvs_amd import nn3d, ops
     torch.manual_seed(5)
 
@@ -1193,9 +1138,11 @@ def test_fused_regulariser_node_on_a_small_program(emul_lib):
             y = m[3](m[2](m[1](y0), skip=y0))
         y.backward(gout)
         res[fused] = (y.detach(), x.grad, [p.grad for p in m.parameters()], [b.clone() for b in m.buffers()])
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # forward: the same kernels in the same order -> bit-identical; backward: the fused node sums the BatchNorm backward statistics
+    # in the input-gradient epilogues (per tile) where the per-layer graph runs a reduction pass (per stride): fp32 rounding apart
+    assert torch.equal(res[True][0], res[False][0]) and _close(res[True][1], res[False][1])
     for a, b in zip(res[True][2], res[False][2]):
-        assert torch.equal(a, b)
+        assert _close(a, b)
     for a, b in zip(res[True][3], res[False][3]):
         assert torch.equal(a, b)
 
@@ -1204,8 +1151,9 @@ def test_fused_regulariser_node_on_a_small_program(emul_lib):
 def test_fused_regulariser_node_equals_per_layer_graph(emul_lib):
     """ops.UNetRegulariserFn (the whole regulariser as one autograd node: skip gradients summed in the dgrad epilogue through
     mvs_conv3d_dgrad_acc / mvs_convT3d_dgrad_acc, one node on the tape) vs the per-layer graph on the CVP regulariser (stride-1 and
-    stride-2 transposed blocks with skips, shared code with MVSNet's): logits, input gradient, EVERY parameter gradient and the
-    BatchNorm buffers bit-identical; a frozen parameter gets no gradient.  (The goldens run through the fused node by default:
+    stride-2 transposed blocks with skips, shared code with MVSNet's): logits and the BatchNorm buffers bit-identical, input gradient
+    and EVERY parameter gradient equal to fp32 rounding (the BatchNorm backward statistics are summed per tile in the input-gradient
+    epilogues here, per stride by a reduction pass there); a frozen parameter gets no gradient.  (The goldens run through the fused node by default:
     test_costregnet_golden / test_costregnet_cvp_golden here with MVS_EMUL_FULL=1, and on the GPU.)"""
     from mvs_amd import ops
     from mvs_amd.jdacs_ms.models.network import CostRegNet
@@ -1227,12 +1175,12 @@ def test_fused_regulariser_node_equals_per_layer_graph(emul_lib):
         finally:
             ops.FUSED_REGULARISER = old
         res[fused] = (y.detach(), x.grad, {k: p.grad for k, p in net.named_parameters()}, {k: v.clone() for k, v in net.state_dict().items()})
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][0], res[False][0]) and _close(res[True][1], res[False][1])
     for k in res[True][2]:
         a, b = res[True][2][k], res[False][2][k]
         assert (a is None) == (b is None), k
         if a is not None:
-            assert torch.equal(a, b), k
+            assert _close(a, b), k
     assert res[True][2]["conv2.bn.bias"] is None
     for k in res[True][3]:
         assert torch.equal(res[True][3][k], res[False][3][k]), k
@@ -1298,49 +1246,11 @@ def test_conv2d_folded_batchnorm_relu_eval(emul_lib, cin, cout, ks, stride, hw):
     assert float(got.min()) >= 0.0
 
 
-@pytest.mark.parametrize("cin,dims,b", [(8, (4, 8, 16), 1), (8, (5, 11, 19), 2), (16, (6, 9, 17), 1), (16, (3, 2, 5), 2)])
-def test_conv3d_probability_layer_four_outputs_per_thread(emul_lib, cin, dims, b):
-    """Knob cout1_d4: the Cout = 1 layer (mvsnet.py:63 / network.py:65: Conv3d(C, 1, 3, padding 1) with bias) with a column of four
-    depth slices per thread and the halo as one plane per channel quad -- ragged sizes (tiles overhang in all three dimensions, a
-    volume thinner than one tile), bias, skip and ReLU epilogues -- against ATen and against the one-output-per-thread kernel."""
-    from mvs_amd import ops
-    g = torch.Generator().manual_seed(cin + sum(dims))
-    x = torch.randn(b, cin, *dims, generator=g)
-    w = torch.randn(1, cin, 3, 3, 3, generator=g) * 0.2
-    bias = torch.randn(1, generator=g)
-    skip = torch.randn(b, 1, *dims, generator=g)
-    exp = F.conv3d(x, w, bias, padding=1)
-    outs = {}
-    try:
-        for knob in (0, 1):
-            emul_lib.call("mvs_set_tuning", b"cout1_d4", knob)      # bit 0: the fp32 kernels
-            y, _ = ops.conv3d_forward(x, w, 1, False, shift=bias)
-            y2, _ = ops.conv3d_forward(x, w, 1, False, shift=bias, skip=skip, relu=True)
-            outs[knob] = (y, y2)
-    finally:
-        emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)
-    for knob in (0, 1):
-        assert float((outs[knob][0] - exp).abs().max()) < 2e-4, knob
-        assert float((outs[knob][1] - (F.relu(exp) + skip)).abs().max()) < 2e-4, knob
-    assert float((outs[1][0] - outs[0][0]).abs().max()) < 2e-5      # same products, another summation order
-    # the layer's input gradient (1 -> C channels), same knob
-    gy = torch.randn(b, 1, *dims, generator=g)
-    xr = x.clone().requires_grad_(True)
-    F.conv3d(xr, w, None, padding=1).backward(gy)
-    try:
-        for knob in (0, 1):
-            emul_lib.call("mvs_set_tuning", b"cout1_d4", knob)
-            gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), 1, False)
-            assert float((gx - xr.grad).abs().max()) < 3e-4, knob
-    finally:
-        emul_lib.call("mvs_set_tuning", b"cout1_d4", 2)
-
-
 @pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (11, 37)), (8, 8, 3, 1, (9, 35)), (8, 16, 5, 2, (12, 66)), (16, 16, 3, 1, (9, 33)),
                                                     (16, 32, 5, 2, (11, 35)), (32, 32, 3, 1, (6, 18))])
 def test_conv2d_forward_with_batchnorm_partial_sums(emul_lib, cin, cout, ks, stride, hw):
     """mvs_conv2d_fwd_stats (the convolution of a training-mode ConvBnReLU, module.py:15-22, with BatchNorm's statistics pass folded
-    into its epilogue) + mvs_bn_group_relu_fwd_parts: the convolution equals the plain kernel bit for bit, the partial rows sum to
+    into its epilogue) + mvs_bn_relu_fwd_slots: the convolution equals the plain kernel bit for bit, the slot rows sum to
     the per-image channel sums (ragged images: tiles overhang), and BatchNorm + ReLU from the rows equals BatchNorm + ReLU with its
     own statistics pass, running statistics included (3 images = 3 statistics groups)."""
     from mvs_amd import ops
@@ -1349,10 +1259,10 @@ def test_conv2d_forward_with_batchnorm_partial_sums(emul_lib, cin, cout, ks, str
     x = torch.randn(n, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, ks, ks, generator=g) * 0.2
     y0 = ops.conv2d_forward(x, w, None, stride)
-    y, parts = ops.conv2d_forward(x, w, None, stride, want_stats=True)
+    y, parts = ops.conv2d_forward(x, w, None, stride, want_stats=True, groups=n)
     assert torch.equal(y, y0)
-    assert parts.shape[0] % n == 0 and tuple(parts.shape[1:]) == (2, cout)
-    per_img = parts.view(n, -1, 2, cout).sum(1)
+    assert parts.dtype == torch.float64 and parts.shape[0] == n and tuple(parts.shape[2:]) == (2, cout)
+    per_img = parts.sum(1).float()
     assert torch.allclose(per_img[:, 0], y.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
     assert torch.allclose(per_img[:, 1], (y * y).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
     gamma, beta = 0.5 + torch.rand(cout, generator=g), torch.randn(cout, generator=g) * 0.2

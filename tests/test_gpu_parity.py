@@ -401,7 +401,7 @@ def test_conv3d_family_vs_torch(dev, conv_tiles, cin, cout, stride, transposed, 
           else F.conv3d(xr, wr, stride=stride, padding=1))
     y, parts = ops.conv3d_forward(x.to(dev), w.to(dev), stride, transposed, want_stats=True)
     assert float((y.cpu() - yr).abs().max()) < 3e-4
-    s = parts.sum(0).cpu()
+    s = parts.sum(0).float().cpu()
     assert torch.allclose(s[0], yr.detach().sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
     assert torch.allclose(s[1], (yr.detach() ** 2).sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
     gy = torch.randn(yr.shape, generator=g)
@@ -433,7 +433,7 @@ def test_conv_cout8_forms_and_tile_orders(dev, cin, dims, k8, xcd):
     try:
         y, parts = ops.conv3d_forward(x.to(dev), w.to(dev), 1, False, want_stats=True)
         assert float((y.cpu() - yr).abs().max()) < 3e-4
-        s = parts.sum(0).cpu()
+        s = parts.sum(0).float().cpu()
         assert torch.allclose(s[0], yr.sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
         assert torch.allclose(s[1], (yr ** 2).sum(dim=(0, 2, 3, 4)), atol=5e-2, rtol=1e-4)
         scale = torch.rand(8, generator=g) + 0.5

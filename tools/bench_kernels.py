@@ -64,9 +64,10 @@ def main():
                                                                             bound), flush=True)
 
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
+    skip_sweep = bool(os.environ.get("MVS_BENCH_SKIP_SWEEP"))
     with torch.no_grad():
-        for variant, label in ((0, "direct"), (2, "cached4"), (3, "cached8"), (6, "cached8, quad-shared projection"), (3, "cached8"),
-                               (6, "cached8, quad-shared projection"), (4, "cached16")):
+        for variant, label in (((3, "cached8"),) if skip_sweep else ((0, "direct"), (2, "cached4"), (3, "cached8"), (6, "cached8, quad-shared projection"), (3, "cached8"),
+                               (6, "cached8, quad-shared projection"), (4, "cached16"))):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
         lib.call("mvs_set_tuning", b"dslab", 0)
@@ -114,13 +115,14 @@ def main():
                                                                                    ", 1 wave/SIMD (3-4 views)" if pf == 2 else "") if variant == 0
                                              else "round-1 view pairs + LDS atomics", ", dslab %d" % dslab if dslab else "", label),
                 lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
-        lib.call("mvs_set_tuning", b"sweep_bwd", _lib.DEFAULT_TUNING.get("sweep_bwd", 2))
+        lib.call("mvs_set_tuning", b"sweep_bwd", _lib.DEFAULT_TUNING.get("sweep_bwd", 0))
         lib.call("mvs_set_tuning", b"bwd_dslab", 0)
         lib.call("mvs_set_tuning", b"bwd_gd", 2)
         lib.call("mvs_set_tuning", b"bwd_pf", 0)
 
-    sweep_bwd_case(NS, "")
-    sweep_bwd_case(4, "")
+    if not skip_sweep:
+        sweep_bwd_case(NS, "")
+        sweep_bwd_case(4, "")
     if os.environ.get('MVS_BENCH_BWD_ONLY'):
         return
     # conv0 family
@@ -129,47 +131,51 @@ def main():
     with torch.no_grad():
         y0, _ = ops.conv3d_forward(var, w0, 1, False)
         gy0 = torch.randn_like(y0)
-        for k8, xcd, label in ((0, 1, "16x16x4 padded"), (1, 0, "4x4x1, linear tile order"), (1, 1, "4x4x1, XCD bricks"),
-                               (7, 0, "4x4x1 broadcast operand, linear"), (7, 1, "4x4x1 broadcast operand, XCD bricks")):
+        for k8, xcd, label in ((0, 1, "16x16x4 padded"), (7, 0, "4x4x1 broadcast operand, linear"), (7, 1, "4x4x1 broadcast operand, XCD bricks")):
             lib.call("mvs_set_tuning", b"k8", k8)
             lib.call("mvs_set_tuning", b"xcd", xcd)
-            if not (k8 == 1 and xcd == 0):   # the first-form forward has no tile-order switch
-                add("conv0 fwd 32>8 [%s]" % label, lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
+            add("conv0 fwd 32>8 [%s]" % label, lambda: ops.conv3d_forward(var, w0, 1, False, want_stats=True), "mfma", fl0)
             add("conv0 wgrad [%s]" % label, lambda: ops.conv3d_wgrad(var, gy0, tuple(w0.shape), 1, False), "mfma", fl0)
         lib.call("mvs_set_tuning", b"k8", _lib.DEFAULT_TUNING["k8"])
         lib.call("mvs_set_tuning", b"xcd", _lib.DEFAULT_TUNING["xcd"])
         add("conv0 dgrad", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
-        lib.call("mvs_set_tuning", b"fs", 1)     # fast halo staging of interior tiles in the generic kernels (not the default)
-        add("conv0 dgrad [fast staging]", lambda: ops.conv3d_dgrad(gy0, w0, tuple(var.shape), 1, False), "mfma", fl0)
-        lib.call("mvs_set_tuning", b"fs", 0)
         # L0 8-channel layers
         w1 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
         add("conv1 fwd 8>16 s2", lambda: ops.conv3d_forward(y0, w1, 2, False, want_stats=True), "mfma", 2 * 27 * 8 * 16 * vox / 8)
         y1, _ = ops.conv3d_forward(y0, w1, 2, False)
         gy1 = torch.randn_like(y1)
         add("conv1 dgrad (TR2 16>8)", lambda: ops.conv3d_dgrad(gy1, w1, tuple(y0.shape), 2, False), "mfma", 2 * 27 * 8 * 16 * vox / 8)
+        # the same with the skip summand and the BatchNorm backward statistics of conv0's block in the epilogue (round 4)
+        st0 = torch.stack([y0.mean(dim=(0, 2, 3, 4)), 1.0 / y0.std(dim=(0, 2, 3, 4)), torch.ones(8, device=dev), torch.zeros(8, device=dev)]).contiguous()
+        sl0 = torch.zeros((128, 2, 8), dtype=torch.float64, device=dev)
+        add("conv1 dgrad + add", lambda: ops.conv3d_dgrad(gy1, w1, tuple(y0.shape), 2, False, add=gy0), "hbm", 3 * 8 * vox * 4)
+        add("conv1 dgrad + add + bn stats", lambda: ops.conv3d_dgrad(gy1, w1, tuple(y0.shape), 2, False, add=gy0, bn=(y0, st0, sl0)),
+            "hbm", 4 * 8 * vox * 4)
         add("conv1 wgrad", lambda: ops.conv3d_wgrad(y0, gy1, tuple(w1.shape), 2, False), "mfma", 2 * 27 * 8 * 16 * vox / 8)
         wp = (torch.randn(1, 8, 3, 3, 3, generator=g) * 0.05).to(dev)
         bp = torch.zeros(1, device=dev)
         add("prob fwd 8>1", lambda: ops.conv3d_forward(y0, wp, 1, False, shift=bp), "hbm", 9 * vox * 4)
         gp = torch.randn(1, 1, D, H, W, device=dev)
         add("prob dgrad 1>8", lambda: ops.conv3d_dgrad(gp, wp, tuple(y0.shape), 1, False), "hbm", 9 * vox * 4)
+        add("prob dgrad 1>8 + bn stats", lambda: ops.conv3d_dgrad(gp, wp, tuple(y0.shape), 1, False, bn=(y0, st0, sl0)), "hbm", 17 * vox * 4)
         add("prob wgrad", lambda: ops.conv3d_wgrad(y0, gp, tuple(wp.shape), 1, False), "hbm", 9 * vox * 4)
         # L1 16>16
         x2 = torch.randn(1, 16, D // 2, H // 2, W // 2, device=dev).contiguous(memory_format=torch.channels_last_3d)
         w2 = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
         fl2 = 2 * 27 * 16 * 16 * vox / 8
         add("conv2 fwd 16>16 @L1", lambda: ops.conv3d_forward(x2, w2, 1, False, want_stats=True), "mfma", fl2)
-        lib.call("mvs_set_tuning", b"fs", 1)
-        add("conv2 fwd 16>16 @L1 [fast staging]", lambda: ops.conv3d_forward(x2, w2, 1, False, want_stats=True), "mfma", fl2)
-        lib.call("mvs_set_tuning", b"fs", 0)
         add("conv2 wgrad", lambda: ops.conv3d_wgrad(x2, x2, tuple(w2.shape), 1, False), "mfma", fl2)
-        # BN passes on the L0 activation
-        sc = torch.ones(8, device=dev)
-        sh = torch.zeros(8, device=dev)
-        yb = torch.empty_like(y0)
-        add("bn_relu_fwd L0 (8ch)", lambda: lib.call("mvs_bn_relu_fwd", y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, vox, 8,
-                                                     yb.data_ptr(), None), "hbm", 2 * 8 * vox * 4)
+        # BatchNorm passes on the L0 activation (statistic slots: finished in the apply kernels' prologues)
+        gam, bet = torch.ones(8, device=dev), torch.zeros(8, device=dev)
+        _, slf = ops.conv3d_forward(var, w0, 1, False, want_stats=True)
+        add("bn_relu_fwd_slots L0 (8ch)", lambda: ops.bn_relu_fwd_slots(y0, slf, gam, bet, None, None, 1e-5, 0.1), "hbm", 2 * 8 * vox * 4)
+        add("bn_relu_fwd_slots L0 + skip", lambda: ops.bn_relu_fwd_slots(y0, slf, gam, bet, None, None, 1e-5, 0.1, skip=gy0), "hbm", 3 * 8 * vox * 4)
+        add("bn bwd reduce + apply L0", lambda: ops.bn_relu_bwd_slots(gy0, y0, st0, torch.zeros_like(sl0), False), "hbm", 5 * 8 * vox * 4)
+        add("bn bwd apply L0 (statistics from the dgrad epilogue)", lambda: ops.bn_relu_bwd_slots(gy0, y0, st0, sl0, True), "hbm", 3 * 8 * vox * 4)
+        x3 = torch.randn(1, 64, D // 8, H // 8, W // 8, device=dev).contiguous(memory_format=torch.channels_last_3d)
+        _, sl3 = ops.conv3d_forward(x3, (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(dev), 1, False, want_stats=True)
+        g64, b64 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+        add("bn_relu_fwd_slots L3 (64ch, 7.7k voxels)", lambda: ops.bn_relu_fwd_slots(x3, sl3, g64, b64, None, None, 1e-5, 0.1), "hbm", 2 * 64 * vox / 512 * 4)
         # soft-argmin
         lg = torch.randn(1, D, H, W, device=dev) * 3
         add("softargmin_conf fwd", lambda: ops.softargmin_conf(lg, depth), "hbm", vox * 4)
