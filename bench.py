@@ -283,6 +283,9 @@ def main():
                          "'feature_fwd' (2-D extractor's forward through conv2d.hip + fused BatchNorm statistics) or "
                          "'<tuning key>=<value>' (mvs_set_tuning, against the library default); 5 pairs of --steps steps each")
     ap.add_argument("--ab-reps", type=int, default=5)
+    ap.add_argument("--defer-join", type=int, default=1,
+                    help="1: join the regulariser's side-stream weight gradients at the end of the backward pass (this loop has no "
+                         "gradient hooks); 0: inside the regulariser node (the library default)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check (tests, no GPU needed): start the ranks, all-reduce one number over gloo, print it, exit")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -427,7 +430,10 @@ def main():
     # MVS_ASYNC_WGRAD=0 times the synchronous mode, and the line reports the other mode's ms/step beside the headline either way
     from mvs_amd import ops as _ops
     async_wgrad = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
-    _ops.set_async_wgrad(async_wgrad)
+    # this loop reads gradients only after backward() (bucket.gather()), registers no gradient hooks and clears .grad every step, so
+    # the regulariser's side-stream weight gradients may be joined ONCE at the end of the backward pass (ops.set_async_wgrad)
+    defer_join = bool(args.defer_join) and async_wgrad
+    _ops.set_async_wgrad(async_wgrad, defer_join=defer_join)
     eager_step = step
     graph_mode = False
     if args.graph != 0:
@@ -519,7 +525,10 @@ def main():
     if args.ab and not graph_mode:
         from mvs_amd.jdacs.models.module import ConvBnReLU
         for spec in filter(None, args.ab.split(";")):
-            if spec == "feature_fwd":
+            if spec == "defer_join":
+                def setter(on, base=defer_join):
+                    _ops.set_async_wgrad(async_wgrad, defer_join=(not base) if on else base)
+            elif spec == "feature_fwd":
                 base = ConvBnReLU.hip_fwd_train
                 def setter(on, base=base):
                     ConvBnReLU.hip_fwd_train = (not base) if on else base
@@ -607,6 +616,7 @@ def main():
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
             "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
+            "wgrad_join": ("end of backward pass" if defer_join else "inside the regulariser node") if train else None,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }

@@ -21,12 +21,20 @@
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // Sum the slot rows [nslots][2][C] of one statistics group in a fixed order (fp64): tot[stat*C + c].  All 256 threads call it.
+// nslots * 2C <= 2048 doubles (mvs_bn_slots) -> <= 8 per thread, ALL requested before the first add: one memory round trip (a
+// `for (k ...) s += slots[..]` loop made hipcc wait for every load before issuing the next: 8 serial round trips ~ 10 us in the
+// prologue of every workgroup, profiles/r04_run1_*).  Thread t always sees element e = t % 2C (256 % 2C == 0).
 __device__ __forceinline__ void bn_slot_totals(const double* __restrict__ slots, int nslots, int C, double* red, double* tot) {
     const int tid = threadIdx.x, E = 2 * C, nsub = 256 / E;
-    const int e = tid % E, sub = tid / E;
-    double s = 0.0;
-    if (sub < nsub)
-        for (int k = sub; k < nslots; k += nsub) s += slots[(size_t)k * E + e];
+    const int total = nslots * E;
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j;
+        v[j] = idx < total ? slots[idx] : 0.0;
+    }
+    double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int idx = tid + 2048; idx < total; idx += 256) s += slots[idx];   // (only with more slot rows than mvs_bn_slots recommends)
     __syncthreads();                 // a previous call's readers of red / tot are done
     red[tid] = s;
     __syncthreads();
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(256) void bn_fwd_slots_kernel(const float* __restri
     __shared__ double tot[128];
     __shared__ __attribute__((aligned(16))) float aff[128];   // scale[C], shift[C]
     const int tid = threadIdx.x, G = gridDim.y, g = blockIdx.y;
-    if (blockIdx.x == 0 && g == 0 && running_mean) {
+    const bool owner = blockIdx.x == 0 && g == 0 && running_mean;
+    if (owner) {
         // running statistics, group after group like G successive BatchNorm calls (jdacs/models/mvsnet.py:115)
         for (int gg = 0; gg < G; ++gg) {
             bn_slot_totals(slots + (size_t)gg * nslots * 2 * C, nslots, C, red, tot);
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(256) void bn_fwd_slots_kernel(const float* __restri
             }
         }
     }
-    bn_slot_totals(slots + (size_t)g * nslots * 2 * C, nslots, C, red, tot);
+    if (!(owner && G == 1))          // (one group: tot already holds this workgroup's totals)
+        bn_slot_totals(slots + (size_t)g * nslots * 2 * C, nslots, C, red, tot);
     if (tid < C) {
         const double mean = tot[tid] / count;
         double var = tot[C + tid] / count - mean * mean;   // biased (normalisation)
@@ -204,7 +214,8 @@ __global__ __launch_bounds__(256) void bn_bwd_slots_kernel(const float* __restri
     __shared__ double tot[128];
     __shared__ __attribute__((aligned(16))) float sums[128];   // s1[C], s2[C]
     const int tid = threadIdx.x, G = gridDim.y, g = blockIdx.y;
-    if (blockIdx.x == 0 && g == 0 && (dgamma || dbeta)) {
+    const bool owner = blockIdx.x == 0 && g == 0 && (dgamma || dbeta);
+    if (owner) {
         double t1 = 0.0, t2 = 0.0;
         for (int gg = 0; gg < G; ++gg) {
             bn_slot_totals(slots + (size_t)gg * nslots * 2 * C, nslots, C, red, tot);
@@ -215,7 +226,8 @@ __global__ __launch_bounds__(256) void bn_bwd_slots_kernel(const float* __restri
             if (dgamma) dgamma[tid] = (float)t2;
         }
     }
-    bn_slot_totals(slots + (size_t)g * nslots * 2 * C, nslots, C, red, tot);
+    if (!(owner && G == 1))
+        bn_slot_totals(slots + (size_t)g * nslots * 2 * C, nslots, C, red, tot);
     if (tid < 2 * C) sums[tid] = (float)tot[tid];
     __syncthreads();
     const int cq = C / 4;

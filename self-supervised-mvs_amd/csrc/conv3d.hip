@@ -207,7 +207,10 @@ __device__ __forceinline__ void stage_batched(float* __restrict__ lds, int tid, 
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM forward-style kernel (conv s1/s2, transposed s2; dgrads map onto these)
 // ------------------------------------------------------------------------------------------------
-template <int GEOM, int CC, int NB>
+// SIDE: the epilogue reads side inputs (a.skip and / or a.bn_raw).  A separate instantiation, so that the plain kernels (training
+// forward, conv0's input gradient) do not pay its registers: <S1, 16, 1> 116 -> 188 VGPRs with everything in one kernel.
+// (SIDE 2: the side inputs of a one-Cout-tile kernel are requested before the class's k-loop -- knob "side_pre".)
+template <int GEOM, int CC, int NB, int SIDE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     using G = ConvGeom<GEOM>;
     constexpr int CCP = CC + 4;
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int nb = 0; nb < NB; ++nb) {
         st1[nb] = 0.f; st2[nb] = 0.f;
         bmu[nb] = bis[nb] = bsc[nb] = bsh[nb] = 0.f;
-        if (a.bn_raw) {
+        if (SIDE && a.bn_raw) {
             const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
             if (co < a.Cout) { bmu[nb] = a.bn_stats[co]; bis[nb] = a.bn_stats[a.Cout + co]; bsc[nb] = a.bn_stats[2 * a.Cout + co]; bsh[nb] = a.bn_stats[3 * a.Cout + co]; }
         }
@@ -285,11 +288,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int nchunks = G::BASE == GEOM_TR2 ? 1 : a.Cin / CC;
     const int KSF = ksteps_for(27, CC);
 
+    // side inputs of the epilogue (see there): m-blocks per load group, and -- one 16-wide Cout tile, i.e. the narrow HBM-bound
+    // layers -- requested BEFORE the class's k-loop, so that they arrive under its MFMAs
+    constexpr int EG = (MB * NB * 8 <= 64) ? MB : 1;
+    constexpr bool SIDE_PRE = SIDE == 2 && NB == 1 && EG == MB;
+    auto pd_of = [&](int cls) { return G::PW ? (cls >> 1) & 1 : (cls >> 2) & 1; };
+    auto ph_of = [&](int cls) { return G::PW ? cls & 1 : (cls >> 1) & 1; };
+    auto pw_of = [&](int cls) { return G::PW ? (l15 >> 3) : cls & 1; };
+    auto load_side = [&](int cls, int mb0, float (&sk)[EG][4][NB], float (&rwv)[EG][4][NB]) {
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+            const int f = wave * MB + mb0 + e;
+            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+            const int od = qd * G::OS + pd_of(cls), oh = qh * G::OS + ph_of(cls);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = qw0 + 4 * g + r;
+                const int ow = qw * G::OS + pw_of(cls);
+                const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
+                    const bool ok = qd < a.QD && qh < a.QH && qw < a.QW && co < a.Cout;
+                    sk[e][r][nb] = (ok && a.skip) ? a.skip[obase + co] : 0.f;
+                    rwv[e][r][nb] = (ok && a.bn_raw) ? a.bn_raw[obase + co] : 0.f;
+                }
+            }
+        }
+    };
+    float skp[SIDE_PRE ? MB : 1][4][NB], rwp[SIDE_PRE ? MB : 1][4][NB];
+
     for (int cls = 0; cls < G::NCLS; ++cls) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SIDE_PRE) {
+            if (a.skip || a.bn_raw) load_side(cls, 0, skp, rwp);
+        }
 
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (cls == 0) {
@@ -370,38 +406,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
         // ---- epilogue for this class: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
         // (PW: class = (pd, ph); the column index l15 = pw*8 + co carries the W parity -> 16 consecutive floats per voxel pair)
-        const int pd = G::PW ? (cls >> 1) & 1 : (cls >> 2) & 1, ph = G::PW ? cls & 1 : (cls >> 1) & 1, pw = G::PW ? (l15 >> 3) : cls & 1;
+        // The epilogue's side inputs (skip summand, raw tensor of the backward statistics) are read in their own phase, ALL loads
+        // of a group of m-blocks before the group's first store: a.y may alias them as far as the compiler knows, so a load written
+        // after a store waits for it, and the per-element form paid one memory round trip per output element (conv1's input
+        // gradient 0.084 -> 0.141 ms with the summand, 0.201 ms with the statistics: profiles/r04_run1_kernels.log).
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int f = wave * MB + mb;
-            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
-            if (qd >= a.QD || qh >= a.QH) continue;
-            const int od = qd * G::OS + pd, oh = qh * G::OS + ph;
+        for (int mb0 = 0; mb0 < MB; mb0 += EG) {
+            float sk[EG][4][NB], rwv[EG][4][NB];
+            if (SIDE && !SIDE_PRE && (a.skip || a.bn_raw)) load_side(cls, mb0, sk, rwv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qw = qw0 + 4 * g + r;
-                if (qw >= a.QW) continue;
-                const int ow = qw * G::OS + pw;
-                const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
+            for (int e = 0; e < EG; ++e) {
+                const int mb = mb0 + e;
+                const int f = wave * MB + mb;
+                const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+                if (qd >= a.QD || qh >= a.QH) continue;
+                const int od = qd * G::OS + pd_of(cls), oh = qh * G::OS + ph_of(cls);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
-                    if (co >= a.Cout) continue;
-                    float v = acc[mb][nb][r];
-                    float sv1 = v, sv2 = v * v;
-                    if (a.scale) v = v * a.scale[co] + a.shift[co];
-                    else if (a.shift) v = v + a.shift[co];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.skip) v += a.skip[obase + co];
-                    if (a.bn_raw) {
-                        // v is the complete output gradient of a BatchNorm+ReLU block at this voxel: its backward statistics
-                        const float rw = a.bn_raw[obase + co];
-                        sv1 = (rw * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
-                        sv2 = sv1 * ((rw - bmu[nb]) * bis[nb]);
+                for (int r = 0; r < 4; ++r) {
+                    const int qw = qw0 + 4 * g + r;
+                    if (qw >= a.QW) continue;
+                    const int ow = qw * G::OS + pw_of(cls);
+                    const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.Cout;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int co = G::PW ? (l15 & 7) : (nb0 + nb) * 16 + l15;
+                        if (co >= a.Cout) continue;
+                        float v = acc[mb][nb][r];
+                        float sv1 = v, sv2 = v * v;
+                        if (a.scale) v = v * a.scale[co] + a.shift[co];
+                        else if (a.shift) v = v + a.shift[co];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (SIDE && a.skip) v += SIDE_PRE ? skp[SIDE_PRE ? mb : 0][r][nb] : sk[e][r][nb];
+                        if (SIDE && a.bn_raw) {
+                            // v is the complete output gradient of a BatchNorm+ReLU block at this voxel: its backward statistics
+                            const float rw = SIDE_PRE ? rwp[SIDE_PRE ? mb : 0][r][nb] : rwv[e][r][nb];
+                            sv1 = (rw * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
+                            sv2 = sv1 * ((rw - bmu[nb]) * bis[nb]);
+                        }
+                        st1[nb] += sv1;
+                        st2[nb] += sv2;
+                        a.y[obase + co] = v;
                     }
-                    st1[nb] += sv1;
-                    st2[nb] += sv2;
-                    a.y[obase + co] = v;
                 }
             }
         }
@@ -451,6 +496,11 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    // the raw tensor of the backward statistics: requested before the tap loop (it arrives under the loop's 27 loads)
+    float4 rwq[COUT / 4];
+#pragma unroll
+    for (int q = 0; q < COUT / 4; ++q)
+        rwq[q] = (slots && live) ? *reinterpret_cast<const float4*>(bn_raw + v * COUT + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
         for (int t = 0; t < 27; ++t) {
@@ -472,7 +522,8 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
         for (int c = 0; c < COUT; ++c) {
             float d1 = 0.f, d2 = 0.f;
             if (live) {
-                const float rw = bn_raw[v * COUT + c];
+                const float4 rq = rwq[c / 4];
+                const float rw = (c & 3) == 0 ? rq.x : ((c & 3) == 1 ? rq.y : ((c & 3) == 2 ? rq.z : rq.w));
                 d1 = (rw * bn_stats[2 * COUT + c] + bn_stats[3 * COUT + c] > 0.f) ? acc[c] : 0.f;
                 d2 = d1 * ((rw - bn_stats[c]) * bn_stats[COUT + c]);
             }
@@ -1360,15 +1411,28 @@ int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv wit
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
+int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
 template <int GEOM, int CC>
 static int launch_igemm_nb(const ConvArgs& a, int NB, int nblocks, hipStream_t st) {
     dim3 grid(nblocks, a.nb_total / NB), block(256);
+    if (a.skip || a.bn_raw) {
+        switch (NB) {
+            case 1:
+                if (g_conv_side_pre) MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1, 2>), grid, block, 0, st, a);
+                else MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1, 1>), grid, block, 0, st, a);
+                break;
+            case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2, 1>), grid, block, 0, st, a); break;
+            case 4: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 4, 1>), grid, block, 0, st, a); break;
+            default: mvs_set_error("conv igemm: Cout tile count %d unsupported", NB); return MVS_ERR_UNSUPPORTED;
+        }
+        return mvs_check_launch("conv_igemm");
+    }
     switch (NB) {
-        case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1>), grid, block, 0, st, a); break;
-        case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2>), grid, block, 0, st, a); break;
-        case 4: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 4>), grid, block, 0, st, a); break;
+        case 1: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 1, 0>), grid, block, 0, st, a); break;
+        case 2: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 2, 0>), grid, block, 0, st, a); break;
+        case 4: MVS_LAUNCH((conv_igemm_kernel<GEOM, CC, 4, 0>), grid, block, 0, st, a); break;
         default: mvs_set_error("conv igemm: Cout tile count %d unsupported", NB); return MVS_ERR_UNSUPPORTED;
     }
     return mvs_check_launch("conv_igemm");

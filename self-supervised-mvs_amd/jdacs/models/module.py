@@ -40,18 +40,19 @@ class ConvBnReLU(nn.Module):
     # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
     hip_conv = os.environ.get("MVS_HIP_FEATURE", "0") == "1"
     # with ops.set_async_wgrad(True): weight gradient of the library's 2-D convolution on the side stream (Conv2dSplitBwdFn).
-    # OFF by default since the end of round 3: a GPU comparison of two equivalent FeatureNet paths that both ran their 2-D weight
-    # gradients on the side stream disagreed (conv0.conv.weight, 60 % relative L1) while the same comparison with synchronous
-    # weight gradients passes (tests/test_gpu_parity.py::test_featurenet_training_hip_forward_with_fused_statistics) -- an
-    # unexplained ordering problem of the library's weight-gradient call on a second stream; the gain was 0.03-0.05 ms.
+    # Opt-in.  Round 3 switched it off after a GPU comparison of two equivalent FeatureNet paths disagreed (conv0.conv.weight, 60 %
+    # relative L1) with side-stream weight gradients; round 4 found the cause (ops._maybe_on_side_stream: the library's gradient
+    # came back in another memory layout than the parameter, so AccumulateGrad cloned it on the main stream before the join) and
+    # fixed it there; tests/test_gpu_parity.py::test_featurenet_training_hip_forward_with_fused_statistics now runs both modes.
     split_bwd = os.environ.get("MVS_SPLIT_CONV2D_BWD", "0") == "1"
     # Inference (eval mode, no autograd): BatchNorm's running statistics folded into the convolution's weights and bias, ReLU in
     # the same csrc/conv2d.hip pass -- no separate normalisation pass over the activation (jdacs/eval.py:143 runs the model
     # in eval mode under no_grad).  MVS_FOLD_EVAL_BN=0 keeps convolution and BatchNorm apart.
     fold_eval = os.environ.get("MVS_FOLD_EVAL_BN", "1") != "0"
-    # training: forward convolution through csrc/conv2d.hip, backward through the library (its weight gradient is 3x faster than
-    # conv2d.hip's).  Opt-in (MVS_HIP_FEATURE_FWD=1) until measured.
-    hip_fwd_train = os.environ.get("MVS_HIP_FEATURE_FWD", "0") == "1"
+    # training: forward convolution through csrc/conv2d.hip with BatchNorm's statistics summed in its epilogue, backward through the
+    # library (its weight gradient is 3x faster than conv2d.hip's).  Default since round 4 (5 interleaved A/B pairs of the config-2
+    # step: 6.186 -> 6.142 ms, profiles/r04_run1_*); MVS_HIP_FEATURE_FWD=0 restores the library's forward.
+    hip_fwd_train = os.environ.get("MVS_HIP_FEATURE_FWD", "1") == "1"
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
         super().__init__()
@@ -73,12 +74,13 @@ class ConvBnReLU(nn.Module):
             hip_fwd = (self.hip_fwd_train and hip_conv2d_serves(self.conv, x) and x.is_contiguous(memory_format=torch.channels_last))
             if hip_fwd and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64) and self.bn.momentum is not None:
                 # convolution + BatchNorm statistics in one launch, then finalize + apply: no statistics pass over the activation
-                y, slots = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True, groups)
+                y, slots = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True, groups,
+                                                      self.split_bwd)
                 for _ in range(groups):
                     count_batch(self.bn, self.training)
                 return ops.BnReLUFn.apply(y, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, True,
                                           self.bn.eps, self.bn.momentum, groups, slots)
-            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, hip_fwd)
+            y = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, hip_fwd, False, 1, self.split_bwd)
         else:
             y = self.conv(x)
         bn = self.bn

@@ -311,6 +311,59 @@ def test_conv_epilogue_and_bn(emul_lib):
         assert float((ye - yre).abs().max()) < 2e-4
 
 
+DGRAD_BN_CASES = [   # (Cin, Cout, stride, transposed, input dims): the geometries that write a block's complete output gradient
+    (8, 16, 2, False, (4, 8, 20)),      # conv1's input gradient: transposed geometry, W-parity merged (Cout' = 8)
+    (16, 16, 1, False, (3, 5, 18)),     # stride 1, one Cout tile: side inputs requested before the k-loop
+    (16, 8, 2, True, (2, 4, 10)),       # input gradient of a transposed layer: stride-2 geometry
+    (32, 32, 1, False, (2, 3, 17)),     # two Cout tiles: side inputs in the epilogue's own phase
+    (8, 1, 1, False, (4, 5, 18)),       # the probability layer: direct Cin == 1 kernel
+]
+
+
+@pytest.mark.parametrize("side_pre", [1, 0])
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", DGRAD_BN_CASES)
+def test_conv3d_dgrad_with_summand_and_batchnorm_backward_statistics(emul_lib, cin, cout, stride, transposed, dims, side_pre):
+    """mvs_conv3d_dgrad / mvs_convT3d_dgrad with `add` and `bn_raw`: gx = d conv/dx + add, and the slots receive
+    (sum dyh, sum dyh*xhat) of the BatchNorm+ReLU block whose raw output is bn_raw -- against ATen's input gradient and the sums
+    written out in torch; then mvs_bn_relu_bwd_slots on those slots against autograd through batch_norm + relu."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin * 3 + cout + stride)
+    b = 2
+    x_shape = (b, cin) + tuple(dims)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    raw = torch.randn(x_shape, generator=g).requires_grad_(True)            # the block's pre-BatchNorm output
+    gamma, beta = 0.5 + torch.rand(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    xin = F.relu(F.batch_norm(raw, None, None, gamma, beta, True, 0.1, 1e-5))
+    y = F.conv_transpose3d(xin, w, stride=stride, padding=1, output_padding=stride - 1) if transposed else F.conv3d(xin, w, stride=stride, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    add = torch.randn(x_shape, generator=g) if cout != 1 else None
+    (gxin_ref,) = torch.autograd.grad(y, xin, gy, retain_graph=True)
+    gtot = gxin_ref + (add if add is not None else 0)                        # the block's complete output gradient
+    (graw_ref,) = torch.autograd.grad(xin, raw, gtot)
+    mean = raw.detach().mean(dim=(0, 2, 3, 4))
+    var = raw.detach().var(dim=(0, 2, 3, 4), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    stats = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    slots = torch.zeros((8, 2, cin), dtype=torch.float64)
+    emul_lib.call("mvs_set_tuning", b"side_pre", side_pre)
+    try:
+        gx = ops.conv3d_dgrad(gy, w, x_shape, stride, transposed, add=add, bn=(raw.detach(), stats, slots))
+    finally:
+        emul_lib.call("mvs_set_tuning", b"side_pre", 1)
+    assert float((gx - gtot).abs().max()) < 5e-4
+    view = lambda v: v.view(1, cin, 1, 1, 1)
+    dyh = gtot * (raw.detach() * view(stats[2]) + view(stats[3]) > 0)
+    xhat = (raw.detach() - view(mean)) * view(invstd)
+    s = slots.sum(0).float()
+    assert torch.allclose(s[0], dyh.sum(dim=(0, 2, 3, 4)), atol=2e-3, rtol=1e-4)
+    assert torch.allclose(s[1], (dyh * xhat).sum(dim=(0, 2, 3, 4)), atol=2e-3, rtol=1e-4)
+    draw, dgamma, dbeta = ops.bn_relu_bwd_slots(gx, raw.detach(), stats, slots, True)
+    assert float((draw - graw_ref).abs().max()) < 1e-3 * max(1.0, float(graw_ref.abs().max()))
+    assert torch.allclose(dbeta, dyh.sum(dim=(0, 2, 3, 4)), atol=2e-3, rtol=1e-4)
+    assert torch.allclose(dgamma, (dyh * xhat).sum(dim=(0, 2, 3, 4)), atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="2 minutes of emulation; set MVS_EMUL_FULL=1 (the same golden runs on the GPU in test_gpu_parity.py::test_golden_costregnet_mvs; the per-layer conv family runs by default)")
 def test_costregnet_golden(emul_lib):
     from mvs_amd.jdacs.models.mvsnet import CostRegNet

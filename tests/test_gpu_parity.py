@@ -486,6 +486,55 @@ def _run_regnet_golden(dev, net, g, has_second, oracle_cls):
     assert float((ye.cpu() - yev).abs().max()) < 1e-3 * max(1.0, float(yev.abs().max()))
 
 
+@pytest.mark.parametrize("side_pre", [1, 0])
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 16, 2, False, (12, 16, 40)), (16, 16, 1, False, (9, 10, 35)), (16, 8, 2, True, (6, 8, 20)),
+                                                             (32, 32, 1, False, (5, 6, 33)), (64, 64, 1, False, (4, 4, 18)), (8, 1, 1, False, (9, 11, 37))])
+def test_conv3d_dgrad_with_summand_and_batchnorm_backward_statistics(dev, cin, cout, stride, transposed, dims, side_pre):
+    """mvs_conv3d_dgrad / mvs_convT3d_dgrad with `add` and `bn_raw` (round 4: the BatchNorm backward statistics of a block summed
+    in the epilogue of the input-gradient kernel that completes its output gradient): gx vs ATen, the slots vs the sums written out
+    in torch, then mvs_bn_relu_bwd_slots on those slots vs autograd through batch_norm + relu (backward of module.py:35-42)."""
+    from mvs_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin * 3 + cout + stride)
+    b = 2
+    x_shape = (b, cin) + tuple(dims)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    raw = torch.randn(x_shape, generator=g).requires_grad_(True)
+    gamma, beta = 0.5 + torch.rand(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    xin = F.relu(F.batch_norm(raw, None, None, gamma, beta, True, 0.1, 1e-5))
+    y = F.conv_transpose3d(xin, w, stride=stride, padding=1, output_padding=stride - 1) if transposed else F.conv3d(xin, w, stride=stride, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    add = torch.randn(x_shape, generator=g) if cout != 1 else None
+    (gxin_ref,) = torch.autograd.grad(y, xin, gy, retain_graph=True)
+    gtot = gxin_ref + (add if add is not None else 0)
+    (graw_ref,) = torch.autograd.grad(xin, raw, gtot)
+    rawd = raw.detach()
+    mean, var = rawd.mean(dim=(0, 2, 3, 4)), rawd.var(dim=(0, 2, 3, 4), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    stats = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    lib = _lib.get()
+    slots = torch.zeros((lib.raw("mvs_bn_slots", cin), 2, cin), dtype=torch.float64, device=dev)
+    lib.call("mvs_set_tuning", b"side_pre", side_pre)
+    try:
+        gx = ops.conv3d_dgrad(gy.to(dev), w.to(dev), x_shape, stride, transposed, add=None if add is None else add.to(dev),
+                              bn=(rawd.to(dev), stats.to(dev), slots))
+    finally:
+        lib.call("mvs_set_tuning", b"side_pre", 1)
+    scale_g = max(1.0, float(gtot.abs().max()))
+    assert float((gx.cpu() - gtot).abs().max()) < 5e-4 * scale_g
+    view = lambda v: v.view(1, cin, 1, 1, 1)
+    dyh = gtot * (rawd * view(stats[2]) + view(stats[3]) > 0)
+    xhat = (rawd - view(mean)) * view(invstd)
+    s = slots.sum(0).float().cpu()
+    assert torch.allclose(s[0], dyh.sum(dim=(0, 2, 3, 4)), atol=2e-2, rtol=2e-4)
+    assert torch.allclose(s[1], (dyh * xhat).sum(dim=(0, 2, 3, 4)), atol=2e-2, rtol=2e-4)
+    draw, dgamma, dbeta = ops.bn_relu_bwd_slots(gx, rawd.to(dev), stats.to(dev), slots, True)
+    assert float((draw.cpu() - graw_ref).abs().max()) < 1e-3 * max(1.0, float(graw_ref.abs().max()))
+    assert torch.allclose(dbeta.cpu(), dyh.sum(dim=(0, 2, 3, 4)), atol=2e-2, rtol=2e-4)
+    assert torch.allclose(dgamma.cpu(), (dyh * xhat).sum(dim=(0, 2, 3, 4)), atol=2e-2, rtol=2e-4)
+
+
+
 def test_golden_costregnet_mvs(dev):
     from mvs_amd.jdacs.models.mvsnet import CostRegNet
     _run_regnet_golden(dev, CostRegNet(), load_golden("g4_costregnet_mvs"), True, R.OracleCostRegNet)
@@ -979,7 +1028,8 @@ def test_featurenet_training_hip_forward_with_fused_statistics(dev):
     a = FeatureNet().to(dev).train()
     b = copy.deepcopy(a).train()
     x = torch.randn(3, 3, 128, 160, device=dev).contiguous(memory_format=torch.channels_last)
-    old_flag, old_async, old_fused = MM.ConvBnReLU.hip_fwd_train, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
+    c = copy.deepcopy(a).train()
+    old_flag, old_async, old_fused, old_split = MM.ConvBnReLU.hip_fwd_train, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED, MM.ConvBnReLU.split_bwd
     try:
         ops.set_async_wgrad(False)            # synchronous weight gradients: the comparison is about the kernels
         MM.ConvBnReLU.hip_fwd_train = False
@@ -990,9 +1040,22 @@ def test_featurenet_training_hip_forward_with_fused_statistics(dev):
         ya = a(x, 3)
         ya.square().mean().backward()
         torch.cuda.synchronize()
+        # regression test of round 3's side-stream mismatch (ops._maybe_on_side_stream): the same path with the library's weight
+        # gradients on the side stream, three backward passes in a row, equals the synchronous run
+        ops.set_async_wgrad(True)
+        MM.ConvBnReLU.split_bwd = True
+        for _ in range(3):
+            for p_ in c.parameters():
+                p_.grad = None
+            yc = c(x, 3)
+            yc.square().mean().backward()
+        torch.cuda.synchronize()
     finally:
-        MM.ConvBnReLU.hip_fwd_train = old_flag
+        MM.ConvBnReLU.hip_fwd_train, MM.ConvBnReLU.split_bwd = old_flag, old_split
         ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED = old_async, old_fused
+    side_bad = {k: round(rel_l1(p.grad, q.grad), 5) for (k, p), (_, q) in zip(c.named_parameters(), a.named_parameters())
+                if not rel_l1(p.grad, q.grad) < 1e-4}
+    assert not side_bad, side_bad
     assert float((ya - yb).abs().max()) < 2e-3 * max(1.0, float(yb.abs().max()))
     bad = {k: round(rel_l1(p.grad, q.grad), 4) for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters())
            if not rel_l1(p.grad, q.grad) < 3e-2}

@@ -579,3 +579,27 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1))" "gpurun_out/bench_c${cfg}_hipfwd$f.json"; grep -E "fwd2d|bn_group" "gpurun_out/bench_c${cfg}_hipfwd$f.err" | head -10
   done; done
 fi
+if [ "$what" = "r4a" ]; then
+  # round 4, first session: statistic-slot BatchNorm + batch weight packing -- targeted parity, step time, kernel table, A/B of the HIP 2-D forward
+  timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider \
+    -k "conv3d_family or cout8 or smallest_volumes or costregnet or mvsnet_end_to_end or config2_train_step or featurenet_training or featurenet_hip or cvpmvsnet_end_to_end or config1" \
+    > gpurun_out/pytest_r4a.log 2>&1
+  echo "pytest exit $?"; tail -5 gpurun_out/pytest_r4a.log
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "feature_fwd" > gpurun_out/bench_r4a.json 2> gpurun_out/bench_r4a.err
+  echo "bench exit $?"; cut -c1-400 gpurun_out/bench_r4a.json; grep "A/B" gpurun_out/bench_r4a.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4a_k.json 2> gpurun_out/bench_r4a_k.err
+  echo "bench-k exit $?"; grep "ms/step" gpurun_out/bench_r4a_k.err | head -60
+  MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4a.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_r4a.log | tail -40
+fi
+if [ "$what" = "r4b" ]; then
+  # round 4, second session: prologue / epilogue fixes, deferred join, side-input prefetch A/B
+  timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider \
+    -k "dgrad_with_summand or conv3d_family or cout8 or costregnet or mvsnet_end_to_end or config2_train_step or featurenet_training or cvpmvsnet_end_to_end" \
+    > gpurun_out/pytest_r4b.log 2>&1
+  echo "pytest exit $?"; tail -5 gpurun_out/pytest_r4b.log
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "defer_join;side_pre=0;feature_fwd" > gpurun_out/bench_r4b.json 2> gpurun_out/bench_r4b.err
+  echo "bench exit $?"; cut -c1-400 gpurun_out/bench_r4b.json; grep "A/B" gpurun_out/bench_r4b.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4b_k.json 2> gpurun_out/bench_r4b_k.err
+  echo "bench-k exit $?"; grep "ms/step" gpurun_out/bench_r4b_k.err | head -60
+  MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4b.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_r4b.log | tail -32
+fi
