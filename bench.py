@@ -485,6 +485,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_host = time.perf_counter() - t0       # the host has ENQUEUED the K steps (eager mode: Python + ctypes + allocator time)
     barrier()
     dt = time.perf_counter() - t0
     if roctx is not None:
@@ -617,6 +618,7 @@ def main():
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
             "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
             "wgrad_join": ("end of backward pass" if defer_join else "inside the regulariser node") if train else None,
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }

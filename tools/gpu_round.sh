@@ -603,3 +603,22 @@ if [ "$what" = "r4b" ]; then
   echo "bench-k exit $?"; grep "ms/step" gpurun_out/bench_r4b_k.err | head -60
   MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4b.log 2>&1; echo "kernels exit $?"; grep -v Warn gpurun_out/kernels_r4b.log | tail -32
 fi
+if [ "$what" = "r4c" ]; then
+  # round 4, third session: clean line + A/B (side_pre, graph), rocprofv3 kernel trace of the step (durations and gaps)
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "side_pre=0;defer_join" > gpurun_out/bench_r4c.json 2> gpurun_out/bench_r4c.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4c.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ms_per_step_async_wgrad_off","wgrad_join")}, d.get("ab"))
+PY
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --graph 1 > gpurun_out/bench_r4c_graph.json 2> gpurun_out/bench_r4c_graph.err
+  echo "graph bench exit $?"; cut -c1-330 gpurun_out/bench_r4c_graph.json; tail -3 gpurun_out/bench_r4c_graph.err
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o trace -- \
+      python "$OLDPWD/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err")
+  echo "prof exit $?"; cut -c1-200 gpurun_out/prof_bench.json
+  mkdir -p gpurun_out/prof_keep; find gpurun_out/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof_keep/ \;
+  # the last 3 steps of the kernel trace (start/end per kernel): gaps and overlap
+  python tools/trace_tail.py gpurun_out/prof gpurun_out/prof_keep/r4c_trace_tail.csv 700
+  rm -rf gpurun_out/prof
+fi
