@@ -175,6 +175,13 @@ int mvs_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 int mvs_bn_relu_fwd(const float* x, const float* scale, const float* shift, const float* skip, int relu, long long V,
                     int C, float* y, hipStream_t stream);
 
+/* ---- mvsnet_loss (jdacs/models/mvsnet.py:164-166): mean smooth-L1 (beta 1) of est - gt over the n pixels with mask > 0.5 ----
+ * forward: out[0] = loss (nan for an empty mask, like the reference's mean over an empty selection), out[1] = pixel count;
+ * backward: gest[i] = [mask > 0.5] * clamp(est - gt, -1, 1) * gloss[0] / out[1].  Two launches instead of ~14. */
+int mvs_masked_smooth_l1_fwd(const float* est, const float* gt, const float* mask, long long n, float* out, hipStream_t stream);
+int mvs_masked_smooth_l1_bwd(const float* est, const float* gt, const float* mask, const float* fwd_out, const float* gloss,
+                             long long n, float* gest, hipStream_t stream);
+
 /* ---- K9/K10: softmax over depth + soft-argmin regression + photometric confidence --------------
  * Replace F.softmax(dim=1) + depth_regression + the pad/avg_pool3d/gather confidence:
  *   jdacs/models/mvsnet.py:141-151, jdacs/models/module.py:145-148;
@@ -228,7 +235,12 @@ int mvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  * the caller): the N images are G statistics groups of N/G consecutive images; consumer: mvs_bn_relu_fwd_slots.
  * The convolution + statistics half of ConvBnReLU in training (jdacs/models/module.py:15-22). */
 int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, double* slots, int nslots, int G, int N, int H,
-                         int W, int Cin, int Cout, int ks, int stride, hipStream_t stream);
+                         int W, int Cin, int Cout, int ks, int stride, int ws_packed, hipStream_t stream);
+/* Forward weight images of n layers in ONE launch (then mvs_conv2d_fwd_stats(..., ws_packed = 1) skips its own packing launch):
+ * w[n] parameter tensors [Cout][Cin][ks][ks] -- or channels-last in memory ([Cout][ks][ks][Cin]) where w_channels_last[i] --,
+ * ws[n] workspaces of mvs_conv2d_workspace_floats(0, ...) floats, shapes[n][4] = Cin, Cout, ks, stride. */
+int mvs_conv2d_pack_weights_batch(int n, const float* const* w, float* const* ws, const int* shapes, const int* w_channels_last,
+                                  hipStream_t stream);
 int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, float negative_slope, hipStream_t stream);
 int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,

@@ -48,12 +48,15 @@ SIGNATURES = {
     "mvs_bn_relu_bwd_slots": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _i, _f, _f, _f, _s]),
     "mvs_bn_eval_affine": (_i, [_f, _f, _f, _f, _fl, _i, _f, _f, _s]),
     "mvs_bn_relu_fwd": (_i, [_f, _f, _f, _f, _i, _ll, _i, _f, _s]),
+    "mvs_masked_smooth_l1_fwd": (_i, [_f, _f, _f, _ll, _f, _s]),
+    "mvs_masked_smooth_l1_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _f, _s]),
     "mvs_softargmin_conf_fwd": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _s]),
     "mvs_softargmin_conf_bwd": (_i, [_f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _s]),
     "mvs_conv2d_workspace_floats": (_ll, [_i] * 8),
     "mvs_conv2d_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_lrelu_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _fl, _s]),
-    "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_pack_weights_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), _s]),
     "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),

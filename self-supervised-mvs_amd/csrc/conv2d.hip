@@ -49,10 +49,10 @@ MVS_HD inline int c2_s2_tap(int tp, int par) {   // tp in 0..2 = offset -1, 0, +
 // of the row's pixel pair; K walks the 3 x 4 input offsets under the pair: tap' = ty*4 + tx', the weight of column (p, co) at tap'
 // is W[ty][tx' - p] (zero where tx' - p is outside 0..2).  All 16 columns carry channels (a plain Cout = 8 layer fills 8 of them),
 // 12 taps per pixel PAIR instead of 9 per pixel, and the 16 lanes of a row store 64 consecutive bytes.
-__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
-                                                          int Cin, int Cout, int NB, int transposed, int total, int cls, int pp) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+// wcl (forward images only): the parameter tensor is channels-last in memory ([Cout][ky][kx][Cin], what
+// module.to(memory_format=torch.channels_last) makes of a Conv2d weight) instead of [Cout][Cin][ky][kx].
+__device__ __forceinline__ void conv2d_pack_item(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC, int Cin, int Cout,
+                                                 int NB, int transposed, int cls, int pp, int wcl, int idx) {
     const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
     const int KS = c2_ksteps(pp ? 12 : NT, CC), chunk = kk / KS, ks = kk % KS;
     const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = pp ? (lane & 7) : nb * 16 + (lane & 15);
@@ -61,17 +61,42 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restric
         const int p = (lane & 15) >> 3, ty = tap / 4, tx = tap % 4 - p;
         if (tap < 12 && tx >= 0 && tx <= 2 && ci < Cin && co < Cout) {
             const int t9 = ty * 3 + tx;
-            v = transposed ? w[((size_t)ci * Cout + co) * 9 + (8 - t9)] : w[((size_t)co * Cin + ci) * 9 + t9];
+            v = transposed ? w[((size_t)ci * Cout + co) * 9 + (8 - t9)]
+                           : (wcl ? w[((size_t)co * 9 + t9) * Cin + ci] : w[((size_t)co * Cin + ci) * 9 + t9]);
         }
     } else if (tap < NT && ci < Cin && co < Cout) {
         if (cls >= 0) {
             const int ty = c2_s2_tap(tap / 3, cls >> 1), tx = c2_s2_tap(tap % 3, cls & 1);
             if (ty >= 0 && tx >= 0) v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
         } else {
-            v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)] : w[((size_t)co * Cin + ci) * NT + tap];
+            v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)]
+                           : (wcl ? w[((size_t)co * NT + tap) * Cin + ci] : w[((size_t)co * Cin + ci) * NT + tap]);
         }
     }
     wp[idx] = v;
+}
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
+                                                          int Cin, int Cout, int NB, int transposed, int total, int cls, int pp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    conv2d_pack_item(w, wp, NT, CC, Cin, Cout, NB, transposed, cls, pp, 0, idx);
+}
+// the forward images of a list of layers in one launch (blockIdx.y = list entry): the 2-D extractor packs its layers once per
+// step (round 3: one pack launch, plus one layout copy of a channels-last weight, in front of every convolution)
+struct Pack2dItem {
+    const float* w;
+    float* wp;
+    int NT, CC, Cin, Cout, NB, pp, wcl, total;
+};
+#define MVS_PACK2D_BATCH_MAX 16
+struct Pack2dBatch {
+    Pack2dItem it[MVS_PACK2D_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(Pack2dBatch pb) {
+    const Pack2dItem& p = pb.it[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    conv2d_pack_item(p.w, p.wp, p.NT, p.CC, p.Cin, p.Cout, p.NB, 0, -1, p.pp, p.wcl, idx);
 }
 
 // STATS: the workgroup also adds the per-channel sum and sum of squares of its outputs into a BatchNorm statistic slot row of its
@@ -436,9 +461,20 @@ static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
     else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2>), grid, dim3(256), 0, st, a);
 }
 
+// the forward weight image of a layer: which form (pixel pairs or plain) and how large
+static void c2_fwd_pack_plan(int Cin, int Cout, int ks, int stride, Pack2dItem& it) {
+    const int cc = c2_cc(ks, Cin), nt = ks * ks, nch = mvs_cdiv(Cin, cc);
+    it.NT = nt; it.CC = cc; it.Cin = Cin; it.Cout = Cout;
+    if (ks == 3 && stride == 1 && Cout <= 8 && (cc == 4 || cc == 8) && g_conv2d_pp) {
+        it.pp = 1; it.NB = 1; it.total = nch * c2_ksteps(12, cc) * 256;
+    } else {
+        it.pp = 0; it.NB = mvs_cdiv(Cout, 16); it.total = nch * c2_ksteps(nt, cc) * it.NB * 256;
+    }
+}
+
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
                         int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
-                        double* slots = nullptr, int nslots = 0, int imgs_per_group = 1) {
+                        double* slots = nullptr, int nslots = 0, int imgs_per_group = 1, int ws_packed = 0) {
     Conv2dArgs a = {};
     a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
@@ -450,7 +486,8 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
     if (ks == 3 && stride == 1 && Cout <= 8 && (cc == 4 || cc == 8) && g_conv2d_pp) {
         // narrow layers (3 -> 8, 8 -> 8 of FeatureNet): pixel pairs fill the MFMA's 16 columns (knob "conv2d_pp")
         const int totalp = nch * c2_ksteps(12, cc) * 256;
-        MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
+        if (!ws_packed)
+            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
         if (slots) {
@@ -461,7 +498,8 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
         return mvs_check_launch("conv2d_igemm (pixel pairs)");
     }
     const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
-    MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1, 0);
+    if (!ws_packed)
+        MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1, 0);
     a.wp = ws;
     const int nb = a.nb_total <= 2 ? a.nb_total : 2;   // 16-wide Cout tiles per workgroup; the rest over blockIdx.y
     dim3 grid(N * a.nth * a.ntw, mvs_cdiv(a.nb_total, nb));
@@ -496,14 +534,40 @@ extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias,
 // caller; nslots a power of two, e.g. mvs_bn_slots(Cout)): the N images are G statistics groups of N/G consecutive images (the
 // views of a sample through the shared-weight extractor).  ConvBnReLU of the 2-D extractor in training (module.py:15-22);
 // consumer: mvs_bn_relu_fwd_slots.
+// ws_packed = 1: ws already holds the layer's forward weight image (mvs_conv2d_pack_weights_batch); w is not read then.
 extern "C" int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, float* ws, double* slots, int nslots, int G, int N,
-                                    int H, int W, int Cin, int Cout, int ks, int stride, hipStream_t stream) {
+                                    int H, int W, int Cin, int Cout, int ks, int stride, int ws_packed, hipStream_t stream) {
     int rc = c2_check("conv2d_fwd_stats", N, H, W, Cin, Cout, ks, stride);
     if (rc) return rc;
-    MVS_REQUIRE(x && w && y && ws && slots, MVS_ERR_NULL, "conv2d_fwd_stats: null pointer argument");
+    MVS_REQUIRE(x && (w || ws_packed) && y && ws && slots, MVS_ERR_NULL, "conv2d_fwd_stats: null pointer argument");
     MVS_REQUIRE(G >= 1 && N % G == 0 && nslots >= 1 && nslots <= 256 && (nslots & (nslots - 1)) == 0, MVS_ERR_SHAPE,
                 "conv2d_fwd_stats: %d images do not split into %d groups, or bad slot count %d", N, G, nslots);
-    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, slots, nslots, N / G);
+    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, slots, nslots, N / G, ws_packed);
+}
+
+// Forward weight images of n layers in ONE launch: w[n] (parameter tensors [Cout][Cin][ks][ks], or channels-last in memory when
+// w_channels_last[i]), ws[n] (each >= mvs_conv2d_workspace_floats(0, ...)), shapes[n][4] = Cin, Cout, ks, stride.
+extern "C" int mvs_conv2d_pack_weights_batch(int n, const float* const* w, float* const* ws, const int* shapes, const int* w_channels_last,
+                                             hipStream_t stream) {
+    MVS_REQUIRE(w && ws && shapes && w_channels_last, MVS_ERR_NULL, "conv2d_pack_weights_batch: null pointer argument");
+    MVS_REQUIRE(n >= 0 && n <= 1024, MVS_ERR_SHAPE, "conv2d_pack_weights_batch: bad count %d", n);
+    for (int i0 = 0; i0 < n; i0 += MVS_PACK2D_BATCH_MAX) {
+        Pack2dBatch pb = {};
+        const int m = n - i0 < MVS_PACK2D_BATCH_MAX ? n - i0 : MVS_PACK2D_BATCH_MAX;
+        int maxtotal = 0;
+        for (int i = 0; i < m; ++i) {
+            const int* sh = shapes + (size_t)(i0 + i) * 4;
+            int rc = c2_check("conv2d_pack_weights_batch", 1, 1, 1, sh[0], sh[1], sh[2], sh[3]);
+            if (rc) return rc;
+            MVS_REQUIRE(w[i0 + i] && ws[i0 + i], MVS_ERR_NULL, "conv2d_pack_weights_batch: null pointer in entry %d", i0 + i);
+            Pack2dItem& it = pb.it[i];
+            it.w = w[i0 + i]; it.wp = ws[i0 + i]; it.wcl = w_channels_last[i0 + i] ? 1 : 0;
+            c2_fwd_pack_plan(sh[0], sh[1], sh[2], sh[3], it);
+            if (it.total > maxtotal) maxtotal = it.total;
+        }
+        if (m > 0) MVS_LAUNCH(conv2d_pack_batch_kernel, dim3(mvs_cdiv(maxtotal, 256), m), dim3(256), 0, stream, pb);
+    }
+    return mvs_check_launch("conv2d_pack_weights_batch");
 }
 
 // the same followed by LeakyReLU(negative_slope): the `conv` block of the feature pyramid (jdacs-ms/models/modules.py:15-19,

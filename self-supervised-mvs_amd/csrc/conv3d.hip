@@ -486,30 +486,45 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
                                                         float* __restrict__ y, int B, int D, int H, int W,
                                                         const float* __restrict__ bn_raw, const float* __restrict__ bn_stats,
                                                         double* __restrict__ slots, int nslots) {
-    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+    // Round 4 form: branch-free.  The 27 input values sit at per-axis CLAMPED coordinates, so all 27 loads are unconditional and
+    // issued back to back (the round 1-3 loop tested the bounds of every tap and `continue`d: one load -> wait -> FMAs round trip
+    // per tap, 0.083 ms for a 15.7 MB read + 126 MB write); out-of-volume taps are zeroed by three per-axis flags; the weights are
+    // read at compile-time offsets of the read-only table (uniform: scalar loads, SGPR operands of the FMAs), not from LDS.
     __shared__ float red[4 * 2 * COUT];
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = wt[i];
-    __syncthreads();
     const size_t total = (size_t)B * D * H * W;
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = v < total;
-    float acc[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-    // the raw tensor of the backward statistics: requested before the tap loop (it arrives under the loop's 27 loads)
+    const size_t v0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = v0 < total;
+    const size_t v = live ? v0 : total - 1;
+    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
+    // the raw tensor of the backward statistics: requested first (it arrives under the taps' loads and FMAs)
     float4 rwq[COUT / 4];
 #pragma unroll
     for (int q = 0; q < COUT / 4; ++q)
         rwq[q] = (slots && live) ? *reinterpret_cast<const float4*>(bn_raw + v * COUT + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-        const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
-        for (int t = 0; t < 27; ++t) {
-            const int dd = d_ + t / 9 - 1, hh = h_ + (t / 3) % 3 - 1, ww = w_ + t % 3 - 1;
-            if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-            const float xv = x[v + ((long long)(t / 9 - 1) * H + ((t / 3) % 3 - 1)) * W + (t % 3 - 1)];
+    int dofs[3], hofs[3], wofs[3];
+    bool vd[3], vh[3], vw[3];
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xv, ws[t * COUT + c], acc[c]);
-        }
+    for (int i = 0; i < 3; ++i) {
+        const int d = d_ + i - 1, h = h_ + i - 1, w = w_ + i - 1;
+        vd[i] = d >= 0 && d < D; vh[i] = h >= 0 && h < H; vw[i] = w >= 0 && w < W;
+        dofs[i] = (min(max(d, 0), D - 1) - d_) * H * W;
+        hofs[i] = (min(max(h, 0), H - 1) - h_) * W;
+        wofs[i] = min(max(w, 0), W - 1) - w_;
+    }
+    const float* __restrict__ xc = x + v;
+    float xv[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) xv[t] = xc[dofs[t / 9] + hofs[(t / 3) % 3] + wofs[t % 3]];
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const float xt = (vd[t / 9] && vh[(t / 3) % 3] && vw[t % 3]) ? xv[t] : 0.f;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xt, wt[t * COUT + c], acc[c]);
+    }
+    if (live) {
 #pragma unroll
         for (int c = 0; c < COUT; c += 4)
             *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
@@ -745,7 +760,6 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     constexpr int NR = G::RD * G::RH * G::RW;
     constexpr int CQ = CIN / 4;
     __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
-    __shared__ __attribute__((aligned(16))) float wl[27 * CIN];   // [tap][ci]
     const int tid = threadIdx.x;
     int t = blockIdx.x;
     const int tw = t % a.ntw; t /= a.ntw;
@@ -753,7 +767,9 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     const int td = t % a.ntd; t /= a.ntd;
     const int b = t;
     const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-    for (int i = tid; i < 27 * CIN; i += 256) wl[i] = w[(size_t)(i % CIN) * 27 + i / CIN];   // W[0][ci][tap]
+    // (round 4: the 27 x CIN weights are read at compile-time offsets of the read-only parameter W[0][ci][tap] -- uniform addresses:
+    //  scalar loads, SGPR operands of the FMAs -- instead of a second LDS image: the kernel was LDS-read bound, 108 ds_read_b128 per
+    //  output at CIN = 8, half of them weights)
     stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
         const int vox = i / CQ, cq = i % CQ;
         const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
@@ -772,8 +788,8 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
 #pragma unroll
         for (int cq = 0; cq < CQ; ++cq) {
             const float4 xv = *reinterpret_cast<const float4*>(&tile[off + 4 * cq]);
-            const float4 wv = *reinterpret_cast<const float4*>(&wl[tap * CIN + 4 * cq]);
-            acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+            acc = fmaf(xv.x, w[(4 * cq + 0) * 27 + tap], acc); acc = fmaf(xv.y, w[(4 * cq + 1) * 27 + tap], acc);
+            acc = fmaf(xv.z, w[(4 * cq + 2) * 27 + tap], acc); acc = fmaf(xv.w, w[(4 * cq + 3) * 27 + tap], acc);
         }
     }
     const int qd = qd0 + pd, qh = qh0 + ph, qw = qw0 + pw;

@@ -59,9 +59,18 @@ class ConvBnReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
 
-    def forward(self, x, groups=1):
+    def hip_train_forward_serves(self, x) -> bool:
+        """the training path of this block through csrc/conv2d.hip with fused BatchNorm statistics (hip_fwd_train) applies to x"""
+        return (self.hip_fwd_train and not self.hip_conv and x.is_cuda and self.training and torch.is_grad_enabled()
+                and self.conv.bias is None and self.conv.groups == 1 and self.conv.dilation == (1, 1) and hip_conv2d_serves(self.conv, x)
+                and x.is_contiguous(memory_format=torch.channels_last) and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64)
+                and self.bn.momentum is not None)
+
+    def forward(self, x, groups=1, packed_ws=None):
         """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one
-        after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk."""
+        after the other (the views of a sample); BatchNorm statistics / running-stat updates stay per chunk.
+        packed_ws: this block's forward weight image, already written (ops.pack_conv2d_weights; FeatureNet packs all its blocks
+        in one launch)."""
         if (self.fold_eval and not self.training and not torch.is_grad_enabled() and self.bn.track_running_stats
                 and self.bn.running_mean is not None and self.bn.affine and hip_conv2d_serves(self.conv, x)):
             w, b = self._folded()
@@ -75,7 +84,7 @@ class ConvBnReLU(nn.Module):
             if hip_fwd and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64) and self.bn.momentum is not None:
                 # convolution + BatchNorm statistics in one launch, then finalize + apply: no statistics pass over the activation
                 y, slots = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True, groups,
-                                                      self.split_bwd)
+                                                      self.split_bwd, packed_ws)
                 for _ in range(groups):
                     count_batch(self.bn, self.training)
                 return ops.BnReLUFn.apply(y, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, True,

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...nn3d import batched_bn_counters
-from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, conv2d_maybe_hip
+from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, conv2d_maybe_hip, hip_conv2d_serves
 
 
 # (name, Cin, Cout, kernel, stride, pad) in registration order == the reference's (same seed => same init)
@@ -34,8 +34,13 @@ class FeatureNet(nn.Module):
 
     def forward(self, x, groups=1):
         """groups: number of views stacked along the batch dim (per-view BatchNorm statistics are kept)."""
-        for name, *_ in _FEATURE_LAYERS:
-            x = getattr(self, name)(x, groups)
+        blocks = [getattr(self, name) for name, *_ in _FEATURE_LAYERS]
+        packed = [None] * len(blocks)
+        if blocks[0].hip_train_forward_serves(x) and all(hip_conv2d_serves(m.conv, x) for m in blocks):
+            # training through csrc/conv2d.hip: the weight images of all blocks in ONE launch (channels-last parameters read as they are)
+            packed = ops.pack_conv2d_weights([m.conv.weight for m in blocks], [m.conv.stride[0] for m in blocks], x)
+        for m, ws in zip(blocks, packed):
+            x = m(x, groups, ws)
         # inference: the closing convolution through csrc/conv2d.hip like the folded blocks before it
         hip = ConvBnReLU.hip_conv or (ConvBnReLU.fold_eval and not self.training and not torch.is_grad_enabled())
         return conv2d_maybe_hip(self.feature, x) if hip else self.feature(x)
@@ -162,8 +167,11 @@ class MVSNet(nn.Module):
 
 
 def mvsnet_loss(depth_est, depth_gt, mask):
-    """mvsnet.py:164-166: mean smooth-L1 over the pixels with mask > 0.5.  Same value and gradient as the
-    reference's boolean-index form, written without `tensor[mask]` (which launches nonzero + a host sync)."""
+    """mvsnet.py:164-166: mean smooth-L1 over the pixels with mask > 0.5.  fp32 maps on the GPU: one HIP launch forward, one backward
+    (ops.MaskedSmoothL1); anything else: the same value and gradient from torch ops, written without `tensor[mask]` (which
+    launches nonzero + a host sync)."""
+    if depth_est.is_cuda and depth_est.dtype == torch.float32:
+        return ops.MaskedSmoothL1.apply(depth_est, depth_gt, mask)
     m = (mask > 0.5).to(depth_est.dtype)
     per_pixel = F.smooth_l1_loss(depth_est, depth_gt, reduction='none')
     return (per_pixel * m).sum() / m.sum()

@@ -526,13 +526,6 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
     ok = _async_safe(weight) and weight.data_ptr() not in _WEIGHT_MULTI.get(idx, ())
     _weight_use_done(idx, weight.data_ptr())
-    if ok and lib.profiler is not None:
-        # a call the KernelTimer brackets with events stays on the main stream: its duration should be the kernel's,
-        # not the kernel's plus whatever shares the chip with it on the other stream
-        b, cin, d, h, w = x.shape
-        cout = weight.shape[1] if transposed else weight.shape[0]
-        ok = not lib.profiler.wants("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad",
-                                    _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
     side = _SIDE_STREAMS.get(idx)
@@ -734,12 +727,10 @@ class UNetRegulariserFn(torch.autograd.Function):
             """weight gradient, on the side stream when allowed (joined before this node returns)"""
             if not wanted:
                 return None
+            # (a call the KernelTimer brackets is bracketed on the stream it runs on -- _lib.MvsLib.call records its events on the
+            #  current stream --, so a profiled weight gradient stays on the side stream and its duration includes whatever shares
+            #  the chip with it; rounds 1-3 moved profiled calls to the main stream, which took the overlap out of the timed step)
             use_side = _ASYNC_WGRAD_FUSED and x.is_cuda
-            if use_side and lib.profiler is not None:
-                b, cin, d, h, w = xin.shape
-                cout = weight.shape[1] if transposed else weight.shape[0]
-                use_side = not lib.profiler.wants("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad",
-                                                  _ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
             if not use_side:
                 return conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
             idx = dev.index
@@ -831,7 +822,7 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False, groups=1, side_stream=True):
+    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False, groups=1, side_stream=True, packed_ws=None):
         """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
         the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm statistic slots of y for `groups` equal batch
         chunks), the slots not differentiable."""
@@ -840,8 +831,11 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
         ctx.side_stream = bool(side_stream)   # False: the weight gradient stays on the main stream whatever set_async_wgrad says
+        # (the statistic slots are a second, non-differentiable output: without this autograd would hand backward() a zero-filled
+        #  float64 tensor of their shape -- one fill launch per layer and step, seen in profiles/r04_run3_trace_tail.csv)
+        ctx.set_materialize_grads(False)
         if hip_forward and want_stats:
-            y, slots = conv2d_forward(x, weight, None, stride[0], want_stats=True, groups=groups)
+            y, slots = conv2d_forward(x, weight, None, stride[0], want_stats=True, groups=groups, packed_ws=packed_ws)
             ctx.mark_non_differentiable(slots)
             return y, slots
         if hip_forward:
@@ -850,6 +844,8 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *_unused_grad_of_the_slots):
+        if gy is None:
+            return (None,) * 9
         x, weight = ctx.saved_tensors
         stride, padding = ctx.cfg
         bwd = torch.ops.aten.convolution_backward
@@ -859,7 +855,7 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
             gw = _maybe_on_side_stream(fn, weight, (x, gy)) if ctx.side_stream else fn()
-        return gx, gw, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None
 
 
 def _maybe_on_side_stream(fn, weight, inputs):
@@ -1008,10 +1004,13 @@ class SoftArgminConf(torch.autograd.Function):
         ctx.save_for_backward(logits, dv, depth, smax, ssum)
         ctx.per_pixel = per_pixel
         ctx.mark_non_differentiable(conf)
+        ctx.set_materialize_grads(False)     # no zero-filled gradient tensor for the confidence output
         return depth, conf
 
     @staticmethod
     def backward(ctx, gdepth, _gconf):
+        if gdepth is None:
+            return None, None
         logits, dv, depth, smax, ssum = ctx.saved_tensors
         lib = _lib_for(logits)
         b, nd, h, w = logits.shape
@@ -1023,6 +1022,32 @@ class SoftArgminConf(torch.autograd.Function):
 
 def softargmin_conf(logits, depth_values):
     return SoftArgminConf.apply(logits, depth_values)
+
+
+class MaskedSmoothL1(torch.autograd.Function):
+    """mvsnet_loss (jdacs/models/mvsnet.py:164-166): mean smooth-L1 of est - gt over mask > 0.5, as one launch forward and one
+    backward; differentiable w.r.t. the estimate."""
+
+    @staticmethod
+    def forward(ctx, est, gt, mask):
+        lib = _lib_for(est)
+        est, gt = est.contiguous(), gt.contiguous().to(torch.float32)
+        mask = mask.contiguous().to(torch.float32)
+        if est.shape != gt.shape or est.shape != mask.shape:
+            raise ValueError("mvsnet_loss: shapes differ: %s %s %s" % (tuple(est.shape), tuple(gt.shape), tuple(mask.shape)))
+        out = torch.empty(2, dtype=torch.float32, device=est.device)
+        lib.call("mvs_masked_smooth_l1_fwd", _p(est), _p(gt), _p(mask), est.numel(), _p(out), _stream(est))
+        ctx.save_for_backward(est, gt, mask, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        est, gt, mask, out = ctx.saved_tensors
+        lib = _lib_for(est)
+        gest = torch.empty_like(est)
+        g = gloss.contiguous().reshape(1).to(torch.float32)
+        lib.call("mvs_masked_smooth_l1_bwd", _p(est), _p(gt), _p(mask), _p(out), _p(g), est.numel(), _p(gest), _stream(est))
+        return gest, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1118,7 +1143,38 @@ def _c2_ws(lib, op, n, h, w, cin, cout, ks, stride, like):
     return torch.empty(nfl, dtype=torch.float32, device=like.device)
 
 
-def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1):
+def pack_conv2d_weights(weights, strides, like):
+    """Forward weight images of a list of Conv2d layers (weights [Cout,Cin,k,k], contiguous OR channels-last in memory) in ONE
+    launch; returns the workspaces to hand to conv2d_forward(want_stats=True, packed_ws=...)."""
+    lib = _lib_for(like)
+    n = len(weights)
+    sizes, shapes, wcl, ptrs = [], [], [], []
+    for wt, st in zip(weights, strides):
+        cout, cin, ks, _ = wt.shape
+        nfl = lib.raw("mvs_conv2d_workspace_floats", 0, 1, 8, 8, cin, cout, ks, st)
+        if nfl < 0:
+            raise ValueError("conv2d: unsupported shape Cin=%d Cout=%d k=%d s=%d" % (cin, cout, ks, st))
+        sizes.append((nfl + 3) // 4 * 4)
+        shapes += [cin, cout, ks, st]
+        if wt.is_contiguous():
+            wcl.append(0)
+        elif wt.is_contiguous(memory_format=CL2):
+            wcl.append(1)
+        else:
+            wt = wt.contiguous()
+            wcl.append(0)
+        ptrs.append(wt)
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=like.device)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(buf[off:off + sz])
+        off += sz
+    lib.call("mvs_conv2d_pack_weights_batch", n, _ptr_array(ptrs), _ptr_array(views), (C.c_int * (4 * n))(*shapes),
+             (C.c_int * n)(*wcl), _stream(like))
+    return views
+
+
+def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1, packed_ws=None):
     """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last);
     negative_slope: LeakyReLU fused after the bias.  want_stats (no bias / activation): -> (y, slots [groups,nslots,2,Cout] fp64),
     the BatchNorm statistics of y summed by the convolution's epilogue, the N images being `groups` equal chunks (BnReLUFn's
@@ -1130,16 +1186,19 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
     if cin_w != cin or ks != ks2:
         raise ValueError("weight shape %s does not match %d input channels" % (tuple(weight.shape), cin))
     ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
-    ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x)
+    ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x) if packed_ws is None else packed_ws
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=CL2)
+    if packed_ws is not None and not want_stats:
+        raise ValueError("conv2d_forward: packed_ws serves the want_stats (training) form")
     if want_stats:
         if bias is not None or negative_slope is not None:
             raise ValueError("conv2d_forward: statistics are those of the plain convolution (no bias / activation)")
         if n % groups:
             raise ValueError("conv2d_forward: %d images do not split into %d statistics groups" % (n, groups))
         (slots,) = stat_slots(x, groups, bn_nslots(lib, cout), cout, 1)
-        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous()), _p(y), _p(ws), _p(slots), slots.shape[1], groups, n, h, w,
-                 cin, cout, ks, stride, _stream(x), tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous() if packed_ws is None else weight), _p(y), _p(ws), _p(slots),
+                 slots.shape[1], groups, n, h, w, cin, cout, ks, stride, int(packed_ws is not None), _stream(x),
+                 tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
         return y, slots
     if negative_slope is not None:
         lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),

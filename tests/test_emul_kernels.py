@@ -1315,6 +1315,12 @@ def test_conv2d_forward_with_batchnorm_partial_sums(emul_lib, cin, cout, ks, str
     y, parts = ops.conv2d_forward(x, w, None, stride, want_stats=True, groups=n)
     assert torch.equal(y, y0)
     assert parts.dtype == torch.float64 and parts.shape[0] == n and tuple(parts.shape[2:]) == (2, cout)
+    # the same with the weight image written ahead of time by the batch packer, from a channels-last AND a contiguous parameter
+    w_cl = w.contiguous(memory_format=torch.channels_last)
+    ws_cl, ws_ct = ops.pack_conv2d_weights([w_cl, w], [stride, stride], x)
+    for wt, ws_ in ((w_cl, ws_cl), (w, ws_ct)):
+        y2, parts2 = ops.conv2d_forward(x, wt, None, stride, want_stats=True, groups=n, packed_ws=ws_)
+        assert torch.equal(y2, y0) and torch.equal(parts2.sum(1), parts.sum(1))
     per_img = parts.sum(1).float()
     assert torch.allclose(per_img[:, 0], y.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
     assert torch.allclose(per_img[:, 1], (y * y).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
@@ -1326,3 +1332,24 @@ def test_conv2d_forward_with_batchnorm_partial_sums(emul_lib, cin, cout, ks, str
     assert torch.allclose(rm_a, rm_b, rtol=1e-5, atol=1e-6) and torch.allclose(rv_a, rv_b, rtol=1e-5, atol=1e-6)
     ref = torch.cat([F.relu(F.batch_norm(y[i:i + 1], None, None, gamma, beta, True, 0.1, 1e-5)) for i in range(n)], 0)
     assert float((zb - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape,empty", [((1, 7, 9), False), ((2, 33, 41), False), ((1, 5, 5), True)])
+def test_masked_smooth_l1_loss(emul_lib, shape, empty):
+    """mvs_masked_smooth_l1_fwd / _bwd (mvsnet_loss, mvsnet.py:164-166) vs the reference's formulation
+    F.smooth_l1_loss(est[mask], gt[mask]): value, gradient, both branches of the loss, an empty mask (nan like the reference)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    est = (torch.randn(shape, generator=g) * 2).requires_grad_(True)
+    gt = torch.randn(shape, generator=g)
+    mask = torch.zeros(shape) if empty else (torch.rand(shape, generator=g) > 0.3).float()
+    loss = ops.MaskedSmoothL1.apply(est, gt, mask)
+    est_r = est.detach().clone().requires_grad_(True)
+    ref = F.smooth_l1_loss(est_r[mask > 0.5], gt[mask > 0.5], reduction="mean")
+    if empty:
+        assert torch.isnan(loss) and torch.isnan(ref)
+        return
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    (loss * 3.0).backward()
+    (ref * 3.0).backward()
+    assert float((est.grad - est_r.grad).abs().max()) < 1e-6

@@ -1355,3 +1355,21 @@ def test_feature_pyramid_and_refinenet_hip_convs_vs_stock(dev):
     finally:
         ConvBnReLU.hip_conv = oldc
     assert rel_l1(r1, r0) < 1e-5
+
+
+def test_mvsnet_loss_kernel_vs_reference_formulation(dev):
+    """mvsnet_loss on the GPU (one launch forward, one backward) vs F.smooth_l1_loss(est[mask], gt[mask]) as the reference writes it
+    (mvsnet.py:164-166), config-2 map size, bool and float masks."""
+    from mvs_amd.jdacs.models.mvsnet import mvsnet_loss
+    g = torch.Generator().manual_seed(3)
+    est0 = 650 + torch.randn(2, 128, 160, generator=g) * 2
+    gt = 650 + torch.randn(2, 128, 160, generator=g)
+    for mask in ((torch.rand(2, 128, 160, generator=g) > 0.4), (torch.rand(2, 128, 160, generator=g) > 0.4).float()):
+        est = est0.clone().to(dev).requires_grad_(True)
+        loss = mvsnet_loss(est, gt.to(dev), mask.to(dev))
+        loss.backward()
+        est_r = est0.clone().requires_grad_(True)
+        ref = F.smooth_l1_loss(est_r[mask > 0.5], gt[mask > 0.5], reduction="mean")
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        assert float((est.grad.cpu() - est_r.grad).abs().max()) < 1e-7

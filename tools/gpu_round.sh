@@ -622,3 +622,20 @@ PY
   python tools/trace_tail.py gpurun_out/prof gpurun_out/prof_keep/r4c_trace_tail.csv 700
   rm -rf gpurun_out/prof
 fi
+if [ "$what" = "r4d" ]; then
+  # round 4, fourth session: launch-count items (materialised grads, 2-D batch pack, fused loss), branch-free cin1, scalar-weight cout1
+  timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider \
+    -k "dgrad_with_summand or conv3d_family or smallest_volumes or costregnet_mvs or mvsnet_end_to_end or config2_train_step or featurenet_training or mvsnet_loss" \
+    > gpurun_out/pytest_r4d.log 2>&1
+  echo "pytest exit $?"; tail -4 gpurun_out/pytest_r4d.log
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "defer_join" --ab-reps 3 > gpurun_out/bench_r4d.json 2> gpurun_out/bench_r4d.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4d.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ms_per_step_async_wgrad_off","wgrad_join")}, d.get("ab"))
+print({k:(round(v["ms"],4), round(v.get("frac",0),3)) for k,v in d["kernels"].items()}, d["roofline"])
+PY
+  timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4d_k.json 2> gpurun_out/bench_r4d_k.err
+  echo "bench-k exit $?"; grep "ms/step" gpurun_out/bench_r4d_k.err | head -24
+  MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4d.log 2>&1; echo "kernels exit $?"; grep -E "prob|conv1 dgrad" gpurun_out/kernels_r4d.log
+fi
