@@ -760,6 +760,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     constexpr int NR = G::RD * G::RH * G::RW;
     constexpr int CQ = CIN / 4;
     __shared__ __attribute__((aligned(16))) float tile[NR * CCP];
+    __shared__ __attribute__((aligned(16))) float wl[27 * CIN];   // [tap][ci]
     const int tid = threadIdx.x;
     int t = blockIdx.x;
     const int tw = t % a.ntw; t /= a.ntw;
@@ -767,9 +768,10 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     const int td = t % a.ntd; t /= a.ntd;
     const int b = t;
     const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-    // (round 4: the 27 x CIN weights are read at compile-time offsets of the read-only parameter W[0][ci][tap] -- uniform addresses:
-    //  scalar loads, SGPR operands of the FMAs -- instead of a second LDS image: the kernel was LDS-read bound, 108 ds_read_b128 per
-    //  output at CIN = 8, half of them weights)
+    // (measured and rejected in round 4, profiles/r04_run4_*: the weights as scalar loads at compile-time offsets of the parameter
+    //  instead of this LDS image -- 0.089 -> 0.173 ms: scalar loads and LDS reads share the lgkmcnt counter, so every wait for a
+    //  weight also drained the tile reads in flight)
+    for (int i = tid; i < 27 * CIN; i += 256) wl[i] = w[(size_t)(i % CIN) * 27 + i / CIN];   // W[0][ci][tap]
     stage_batched<NR * CQ>(tile, tid, [&](int i, const float*& src, int& o) {
         const int vox = i / CQ, cq = i % CQ;
         const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
@@ -788,8 +790,8 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
 #pragma unroll
         for (int cq = 0; cq < CQ; ++cq) {
             const float4 xv = *reinterpret_cast<const float4*>(&tile[off + 4 * cq]);
-            acc = fmaf(xv.x, w[(4 * cq + 0) * 27 + tap], acc); acc = fmaf(xv.y, w[(4 * cq + 1) * 27 + tap], acc);
-            acc = fmaf(xv.z, w[(4 * cq + 2) * 27 + tap], acc); acc = fmaf(xv.w, w[(4 * cq + 3) * 27 + tap], acc);
+            const float4 wv = *reinterpret_cast<const float4*>(&wl[tap * CIN + 4 * cq]);
+            acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
         }
     }
     const int qd = qd0 + pd, qh = qh0 + ph, qw = qw0 + pw;
@@ -1391,19 +1393,35 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// first level of a two-level reduction: [nparts][n] -> [nout][n], block y sums parts y, y+nout, ...
-__global__ __launch_bounds__(256) void conv_wgrad_prereduce_kernel(const float* __restrict__ part, int nparts, int n,
-                                                                   int nout, float* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float s0 = 0.f, s1 = 0.f;
-    int p = blockIdx.y;
-    for (; p + nout < nparts; p += 2 * nout) {
-        s0 += part[(size_t)p * n + e];
-        s1 += part[(size_t)(p + nout) * n + e];
+// Many partial images in ONE launch (round 4; rounds 1-3: a 16-row pre-reduction launch + the kernel above, 22 launches per
+// step): a workgroup owns 16 output elements; its 16 x 16 threads = (element, slice) walk the images slice, slice + 16, ... with
+// all loads of a batch of four in flight, then the 16 slices are summed through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const float* __restrict__ part, int nparts, int CX, int CG,
+                                                                     float* __restrict__ gw) {
+    __shared__ float red[16][17];
+    const int n = 27 * CX * CG;
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const size_t stride = (size_t)n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int p = slice;
+        for (; p + 48 < nparts; p += 64) {
+            const float a0 = part[(size_t)p * stride + e], a1 = part[(size_t)(p + 16) * stride + e];
+            const float a2 = part[(size_t)(p + 32) * stride + e], a3 = part[(size_t)(p + 48) * stride + e];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; p < nparts; p += 16) s0 += part[(size_t)p * stride + e];
     }
-    if (p < nparts) s0 += part[(size_t)p * n + e];
-    out[(size_t)blockIdx.y * n + e] = s0 + s1;
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][el];
+        const int cg = e % CG, cx = (e / CG) % CX, tap = e / (CG * CX);
+        gw[((size_t)cg * CX + cx) * 27 + tap] = t;
+    }
 }
 
 // ================================================================================================
@@ -1727,18 +1745,14 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
 
 static size_t wgrad_ws_floats(int CX, int CG) { return (size_t)(WGRAD_MAX_GROUPS + 16) * 27 * CX * CG; }
 
-// deterministic reduction of the per-workgroup partial images: > 32 images go through 16 intermediate rows first
-// (a single pass has only 27*CX*CG threads, each walking all images serially -> latency bound)
+// deterministic reduction of the per-workgroup partial images: > 32 images take the wide kernel (16 slices per output element)
+// (one thread per element walking all images serially is latency bound)
 static int wgrad_finish(float* ws, int nparts, int CX, int CG, float* gw, hipStream_t st) {
     const int n = 27 * CX * CG;
-    const float* src = ws;
-    if (nparts > 32) {
-        float* mid = ws + (size_t)WGRAD_MAX_GROUPS * n;
-        MVS_LAUNCH(conv_wgrad_prereduce_kernel, dim3(mvs_cdiv(n, 256), 16), dim3(256), 0, st, (const float*)ws, nparts, n, 16, mid);
-        src = mid;
-        nparts = 16;
-    }
-    MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, st, src, nparts, CX, CG, gw);
+    if (nparts > 32)
+        MVS_LAUNCH(conv_wgrad_reduce_wide_kernel, dim3(mvs_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nparts, CX, CG, gw);
+    else
+        MVS_LAUNCH(conv_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nparts, CX, CG, gw);
     return mvs_check_launch("conv_wgrad_reduce");
 }
 

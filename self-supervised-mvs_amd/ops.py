@@ -451,7 +451,32 @@ _ASYNC_WGRAD = os.environ.get("MVS_ASYNC_WGRAD", "0") == "1"
 # Bookkeeping is per DEVICE, not per thread: the autograd engine runs backward nodes on its own worker threads and the
 # final callback on the thread that called backward(), so thread-local state would not connect them; one-thread-per-GPU
 # callers (nn.DataParallel style) touch disjoint entries.
-_SIDE_STREAMS = {}      # device index -> side stream (created once)
+_SIDE_STREAMS = {}      # device index -> [side streams] (created once), handed out round-robin
+_SIDE_NEXT = {}         # device index -> next pool slot
+_N_SIDE = max(1, int(os.environ.get("MVS_WGRAD_STREAMS", "1")))
+
+
+def set_wgrad_streams(n: int) -> None:
+    """Number of side streams the weight gradients are dealt to round-robin (default 1).  The deep U-Net levels' weight gradients
+    are launches of 48-250 workgroups on a 256-CU chip and independent of each other: on several streams they run next to each
+    other instead of one after the other."""
+    global _N_SIDE
+    _N_SIDE = max(1, int(n))
+
+
+def _side_stream(dev):
+    idx = dev.index
+    pool = _SIDE_STREAMS.setdefault(idx, [])
+    while len(pool) < _N_SIDE:
+        pool.append(torch.cuda.Stream(device=dev))
+    k = _SIDE_NEXT.get(idx, 0) % _N_SIDE
+    _SIDE_NEXT[idx] = k + 1
+    return pool[k]
+
+
+def _join_side(main, idx) -> None:
+    for sd in _SIDE_STREAMS.get(idx, ()):
+        main.wait_stream(sd)
 _WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses whose backward node has not run yet}
 _WEIGHT_MULTI = {}      # device index -> {weight data_ptr} that had > 1 outstanding use at some point (until all of them have run)
 _BWD_OPEN = {}          # device index -> [main stream, side stream used?] while a backward pass with our nodes is running
@@ -503,7 +528,7 @@ def _weight_use_done(idx: int, ptr: int) -> None:
 def _end_of_backward(idx: int) -> None:
     ent = _BWD_OPEN.pop(idx, None)
     if ent is not None and ent[1]:
-        ent[0].wait_stream(_SIDE_STREAMS[idx])
+        _join_side(ent[0], idx)
 
 
 def _async_safe(weight: torch.Tensor) -> bool:
@@ -528,9 +553,7 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     _weight_use_done(idx, weight.data_ptr())
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
-    side = _SIDE_STREAMS.get(idx)
-    if side is None:
-        side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=x.device))
+    side = _side_stream(x.device)
     x, gy = as_cl3(x), as_cl3(gy)
     side.wait_stream(main)                       # gy was produced on the main stream
     with torch.cuda.stream(side):
@@ -733,10 +756,7 @@ class UNetRegulariserFn(torch.autograd.Function):
             use_side = _ASYNC_WGRAD_FUSED and x.is_cuda
             if not use_side:
                 return conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
-            idx = dev.index
-            side = _SIDE_STREAMS.get(idx)
-            if side is None:
-                side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=dev))
+            side = _side_stream(dev)
             side.wait_stream(main)                       # gout was produced on the main stream
             with torch.cuda.stream(side):
                 gw = conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
@@ -799,7 +819,7 @@ class UNetRegulariserFn(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
                 ent[1] = True
             else:
-                main.wait_stream(_SIDE_STREAMS[dev.index])   # every weight gradient is complete before autograd sees it
+                _join_side(main, dev.index)                  # every weight gradient is complete before autograd sees it
         return (gx, None) + tuple(grads)
 
 
@@ -876,9 +896,7 @@ def _maybe_on_side_stream(fn, weight, inputs):
     _weight_use_done(idx, weight.data_ptr())
     if not ok:
         return fn()
-    side = _SIDE_STREAMS.get(idx)
-    if side is None:
-        side = _SIDE_STREAMS.setdefault(idx, torch.cuda.Stream(device=ref.device))
+    side = _side_stream(ref.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()

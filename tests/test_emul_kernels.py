@@ -1353,3 +1353,18 @@ def test_masked_smooth_l1_loss(emul_lib, shape, empty):
     (loss * 3.0).backward()
     (ref * 3.0).backward()
     assert float((est.grad - est_r.grad).abs().max()) < 1e-6
+
+
+def test_conv3d_wgrad_wide_reduction_of_many_partial_images(emul_lib):
+    """More than 32 persistent workgroups -> conv_wgrad_reduce_wide_kernel (one launch: 16 slices per output element, fixed order)
+    instead of the serial one-thread-per-element reduce: weight gradient vs ATen on a volume of 36 tiles, ragged in W."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 8, 12, 16, 41, generator=g)
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    gw = ops.conv3d_wgrad(x, gy, tuple(w.shape), 1, False)
+    assert float((gw - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))

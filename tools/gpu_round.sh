@@ -639,3 +639,17 @@ PY
   echo "bench-k exit $?"; grep "ms/step" gpurun_out/bench_r4d_k.err | head -24
   MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4d.log 2>&1; echo "kernels exit $?"; grep -E "prob|conv1 dgrad" gpurun_out/kernels_r4d.log
 fi
+if [ "$what" = "r4e" ]; then
+  # round 4, fifth session: several side streams, 2-D weight gradients on them, wide wgrad reduction, cout1 back on LDS weights
+  timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider \
+    -k "conv3d_family or costregnet_mvs or mvsnet_end_to_end or config2_train_step or featurenet_training" > gpurun_out/pytest_r4e.log 2>&1
+  echo "pytest exit $?"; tail -3 gpurun_out/pytest_r4e.log
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "wgrad_streams=2;wgrad_streams=3;wgrad_streams=4;split_bwd" --ab-reps 3 > gpurun_out/bench_r4e.json 2> gpurun_out/bench_r4e.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4e.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ms_per_step_async_wgrad_off","wgrad_join")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+  MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4e.log 2>&1; echo "kernels exit $?"; grep -E "prob|wgrad" gpurun_out/kernels_r4e.log
+fi
