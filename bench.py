@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--ab-reps", type=int, default=5)
     ap.add_argument("--wgrad-streams", type=int, default=1,
                     help="side streams the regulariser's weight gradients are dealt to round-robin (ops.set_wgrad_streams)")
+    ap.add_argument("--side-priority", type=str, default="default", choices=["default", "low"],
+                    help="priority of the weight-gradient side stream (ops.set_side_stream_priority)")
     ap.add_argument("--defer-join", type=int, default=1,
                     help="1: join the regulariser's side-stream weight gradients at the end of the backward pass (this loop has no "
                          "gradient hooks); 0: inside the regulariser node (the library default)")
@@ -437,6 +439,7 @@ def main():
     defer_join = bool(args.defer_join) and async_wgrad
     _ops.set_async_wgrad(async_wgrad, defer_join=defer_join)
     _ops.set_wgrad_streams(args.wgrad_streams)
+    _ops.set_side_stream_priority(args.side_priority)
     eager_step = step
     graph_mode = False
     if args.graph != 0:
@@ -535,6 +538,10 @@ def main():
             elif spec.startswith("wgrad_streams="):
                 def setter(on, n=int(spec.split("=")[1]), base=args.wgrad_streams):
                     _ops.set_wgrad_streams(n if on else base)
+            elif spec == "side_low":
+                def setter(on, base=args.side_priority):
+                    other = "default" if base == "low" else "low"
+                    _ops.set_side_stream_priority(other if on else base)
             elif spec == "split_bwd":
                 def setter(on, base=ConvBnReLU.split_bwd):
                     ConvBnReLU.split_bwd = (not base) if on else base
@@ -627,7 +634,7 @@ def main():
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
             "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
             "wgrad_join": ("end of backward pass" if defer_join else "inside the regulariser node") if train else None,
-            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "wgrad_streams": args.wgrad_streams,
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }

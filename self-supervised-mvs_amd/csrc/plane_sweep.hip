@@ -90,12 +90,8 @@ template <int C, int CPT> struct TileC {
     static constexpr int LPP = C / CPT, PPB = 256 / LPP, TW = PPB >= 128 ? 16 : 8, TH = PPB / TW;
 };
 
-// QS (quad-shared coordinates; C == 32, CPT == 8 -> the 4 lanes of a quad are the 4 channel groups of ONE pixel, NS_T in
-// {2, 4}): the per-plane projection of source view s (homography, reciprocal, floor, fractions) is the same for the four
-// lanes, so lane q computes only view q % NS_T and the others fetch (wx, wy, x0, y0) with quad-broadcast DPP moves
-// instead of recomputing them: ~20 (NS_T = 2) / ~70 (NS_T = 4) fewer VALU instructions per plane in a kernel whose VALU
-// is busy 73 % of the time.  Bit-identical results.  Knob "fwd_qs" (or variant 6 of "sweep_fwd").  Round 3: also 3 views, and 6
-// views at 4 channels per lane (8 lanes per pixel: the values travel by ds_bpermute_b32 instead of a DPP move).
+// (Round 3's "shared projection" form -- one lane of a pixel's lane group computes a view's projection, the others fetch it by DPP /
+// ds_bpermute -- was bit-identical and slower everywhere (N=3 0.1023 -> 0.1064 ms, N=7 bf16 2.57 -> 2.87) and was removed in round 4.)
 // BF (inference path, BASELINE configs[4]): the volume is stored in bf16 (round to nearest even) -- a lane then owns CPT
 // CONSECUTIVE channels so that its values are one 16- (8-) byte store and the lanes of a pixel write one 64-byte segment.
 // DL (per-plane hypotheses only): the slab's depths are staged in LDS once and read back one plane ahead.  DL == 2 is the MERGED
@@ -105,11 +101,10 @@ template <int C, int CPT> struct TileC {
 // (An earlier DL == 2, waiting for the taps INSIDE the re-gather block, measured slower and is gone.)  Without DL the plane loop
 // starts with a vmcnt(0) (the depth is a vector load) that also waits for the previous plane's stores -- on gfx9 stores and loads
 // share the counter.
-template <int C, int NS_T, int CPT, bool QS = false, bool BF = false, int DL = 0>
+template <int C, int NS_T, int CPT, bool BF = false, int DL = 0>
 __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(SweepArgs a) {
     static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
     constexpr int V = CPT / 4;                     // float4s per tap per thread
-    static_assert(!QS || ((C / CPT == 4 || C / CPT == 8) && NS_T <= C / CPT), "shared projection: 4 or 8 lanes per pixel, one view per lane");
     constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB;
     const int TW = a.tile_w, TH = PPB / TW;
     const int tid = threadIdx.x;
@@ -124,12 +119,8 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         for (int i = tid; i < d1 - d0; i += 256) s_dep[i] = a.depth[b * a.D + d0 + i];
         __syncthreads();
     }
-    if (!QS) {
-        if (xr >= a.W || yr >= a.H) return;  // no barriers / cross-lane ops below
-    }
-    // QS: quad exchanges below -> out-of-image lanes follow along on pixel 0 and store nothing
-    const bool live = !QS || (xr < a.W && yr < a.H);
-    const int x = live ? xr : 0, y = live ? yr : 0;
+    if (xr >= a.W || yr >= a.H) return;  // no barriers / cross-lane ops below
+    const int x = xr, y = yr;
     const int HW = a.H * a.W, pix = y * a.W + x;
     const float xf = (float)x, yf = (float)y;
     // channel of float4 k of lane q: 4q + 4*LPP*k, so that ONE store instruction writes whole 64-byte segments
@@ -156,7 +147,7 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
-        const int sv = QS ? (s == 0 ? q % NS_T : 0) : s;   // QS: slot 0 holds the lane's own view, the other slots are unused
+        const int sv = s;
         const float* R = rotb + sv * 9;
         rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
         ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
@@ -183,36 +174,12 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
         float4 S[V], Q[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
-        // QS: this lane's own view (index 0 of the per-lane arrays), computed once per plane
-        float own_wx = 0.f, own_wy = 0.f;
-        int own_x0 = 0, own_y0 = 0;
-        if (QS) {
-            const float zz = fmaf(rz[0], dep, tz[0]);
-            float iz = MVS_RCP(zz);
-            iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
-            const float ix = fmaf(fmaf(rx[0], dep, tx[0]) * iz, a.sx, a.ox);
-            const float iy = fmaf(fmaf(ry[0], dep, ty[0]) * iz, a.sy, a.oy);
-            const float fx = floorf(ix), fy = floorf(iy);
-            own_wx = ix - fx; own_wy = iy - fy;
-            own_x0 = MVS_F2I(fx); own_y0 = MVS_F2I(fy);
-        }
         float wxs[DL == 2 ? NS_T : 1], wys[DL == 2 ? NS_T : 1];
 #pragma unroll
         for (int s = 0; s < NS_T; ++s) {
             float wx, wy;
             int x0, y0;
-            if (QS) {
-                // view s was computed by lane s of the pixel's lane group (fewer views than lanes: the others computed some again).
-                // 4 lanes per pixel: one quad-broadcast DPP move per value; 8 lanes: ds_bpermute_b32 (LDS crossbar, no LDS memory)
-                if constexpr (LPP == 4) {
-                    wx = MVS_QUAD_BCAST_F(own_wx, s); wy = MVS_QUAD_BCAST_F(own_wy, s);
-                    x0 = MVS_QUAD_BCAST_I(own_x0, s); y0 = MVS_QUAD_BCAST_I(own_y0, s);
-                } else {
-                    const int srcl = (tid & 63 & ~(LPP - 1)) | s;
-                    wx = __shfl(own_wx, srcl); wy = __shfl(own_wy, srcl);
-                    x0 = __shfl(own_x0, srcl); y0 = __shfl(own_y0, srcl);
-                }
-            } else {
+            {
                 const float zz = fmaf(rz[s], dep, tz[s]);
                 float iz = MVS_RCP(zz);                 // v_rcp_f32 (1 ulp) + one Newton step: < 1 ulp, 3 instructions
                 iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz); // instead of the ~10 of an IEEE division
@@ -290,158 +257,14 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
                 packed[2 * k + 1] = mvs_cvt_pk_bf16(o.z, o.w);
                 continue;
             }
-            if (QS && !live) continue;
             if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
             else *reinterpret_cast<float4*>(outp + ck * k) = o;
         }
-        if (BF && (!QS || live)) {
+        if (BF) {
             if (V == 2) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.var) + oidx) =
                             make_uint4(packed[0], packed[1], packed[2 % (2 * V)], packed[3 % (2 * V)]);
             else { uint2 o2; o2.x = packed[0]; o2.y = packed[1]; *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.var) + oidx) = o2; }
         }
-    }
-}
-
-// Forward, LDS-staged variant.  The direct kernel above pulls every bilinear tap through the vector
-// L1 (4 taps x C*4 B per voxel and view ~ 4 GB per launch at config 2, i.e. TA bound at ~64 B/clk/CU).
-// Here the workgroup first copies each source view's footprint window of its (pixel tile x depth
-// segment) box into LDS with coalesced loads -- every source texel is fetched once per segment instead
-// of once per tap -- and the taps become ds_read_b128 (4x the L1 rate).  Window = image-clipped bounding
-// box of the 8 projected corners (the warp is projective); a tap that rounding puts outside it, or a
-// plane whose footprint does not fit, falls back to the global load, so results never depend on it.
-template <int C> struct FwdCfg { static constexpr int CPF = C + 4, WTOT = C == 32 ? 480 : (C == 16 ? 900 : 1600); };
-
-template <int C>
-__device__ __forceinline__ float4 tap_load(const float* __restrict__ win, const Win& w, bool use_win,
-                                           const float* __restrict__ f, int xi, int yi, int W, int q) {
-    const int wx = xi - w.x0, wy = yi - w.y0;
-    if (use_win && wx >= 0 && wx < w.w && wy >= 0 && wy < w.h)
-        return *reinterpret_cast<const float4*>(win + (wy * w.w + wx) * FwdCfg<C>::CPF + 4 * q);
-    return ld4(f + ((size_t)yi * W + xi) * C);
-}
-
-template <int C>
-__device__ __forceinline__ float4 sample4_win(const float* __restrict__ win, const Win& w, bool use_win,
-                                              const float* __restrict__ f, const Taps& t, int W, int q) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t.v00) { float4 a = tap_load<C>(win, w, use_win, f, t.x0, t.y0, W, q); v.x = a.x * t.w00; v.y = a.y * t.w00; v.z = a.z * t.w00; v.w = a.w * t.w00; }
-    if (t.v01) {
-        float4 a = tap_load<C>(win, w, use_win, f, t.x0 + 1, t.y0, W, q);
-        v.x = fmaf(a.x, t.w01, v.x); v.y = fmaf(a.y, t.w01, v.y); v.z = fmaf(a.z, t.w01, v.z); v.w = fmaf(a.w, t.w01, v.w);
-    }
-    if (t.v10) {
-        float4 a = tap_load<C>(win, w, use_win, f, t.x0, t.y0 + 1, W, q);
-        v.x = fmaf(a.x, t.w10, v.x); v.y = fmaf(a.y, t.w10, v.y); v.z = fmaf(a.z, t.w10, v.z); v.w = fmaf(a.w, t.w10, v.w);
-    }
-    if (t.v11) {
-        float4 a = tap_load<C>(win, w, use_win, f, t.x0 + 1, t.y0 + 1, W, q);
-        v.x = fmaf(a.x, t.w11, v.x); v.y = fmaf(a.y, t.w11, v.y); v.z = fmaf(a.z, t.w11, v.z); v.w = fmaf(a.w, t.w11, v.w);
-    }
-    return v;
-}
-
-template <int C, int NS_T>
-__global__ __launch_bounds__(256) void plane_sweep_variance_fwd_lds_kernel(SweepArgs a) {
-    constexpr int QUADS = C / 4;
-    constexpr int TW = Tile<C>::TW, TH = Tile<C>::TH;
-    constexpr int CPF = FwdCfg<C>::CPF, WCAP = FwdCfg<C>::WTOT / NS_T;
-    __shared__ __attribute__((aligned(16))) float win[NS_T * WCAP * CPF];
-    __shared__ float red[8];
-    const int tid = threadIdx.x;
-    const int q = tid % QUADS, pl = tid / QUADS;
-    const int tx0 = (blockIdx.x % a.tiles_x) * TW, ty0 = (blockIdx.x / a.tiles_x) * TH;
-    const int x = tx0 + pl % TW, y = ty0 + pl / TW;
-    const int b = blockIdx.z;
-    const bool valid = x < a.W && y < a.H;
-    const int HW = a.H * a.W, pix = valid ? y * a.W + x : 0;
-    const int d0 = blockIdx.y * a.dslab;
-    const int d1 = min(a.D, d0 + a.dslab);
-    const float xf = (float)x, yf = (float)y;
-    const size_t fbase = (size_t)b * HW * C + 4 * q;
-    const float4 r = ld4(a.ref + fbase + (size_t)pix * C);
-    const float4 r2 = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
-    const float inv_n = 1.0f / (float)(NS_T + 1);
-    const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
-    const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
-    const float cxa = (float)tx0, cxb = (float)min(tx0 + TW - 1, a.W - 1);
-    const float cya = (float)ty0, cyb = (float)min(ty0 + TH - 1, a.H - 1);
-
-    int ds = d0;
-    while (ds < d1) {
-        int de = d1;
-        Win w[NS_T];
-        bool use[NS_T];
-        for (int it = 0; it < 12; ++it) {
-            float da, db;
-            if (a.per_pixel) {
-                float lo = 3.0e38f, hi = -3.0e38f;
-                if (valid && q == 0)
-                    for (int d = ds; d < de; ++d) {
-                        float v = a.depth[((size_t)b * a.D + d) * HW + pix];
-                        lo = fminf(lo, v); hi = fmaxf(hi, v);
-                    }
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) { lo = fminf(lo, __shfl_xor(lo, m)); hi = fmaxf(hi, __shfl_xor(hi, m)); }
-                __syncthreads();
-                if ((tid & 63) == 0) { red[(tid >> 6) * 2] = lo; red[(tid >> 6) * 2 + 1] = hi; }
-                __syncthreads();
-                da = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
-                db = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
-            } else {
-                da = a.depth[b * a.D + ds];
-                db = a.depth[b * a.D + de - 1];
-            }
-            bool fits = true;
-#pragma unroll
-            for (int s = 0; s < NS_T; ++s) {
-                float lox, hix, loy, hiy;
-                corner_bounds(a, rotb + s * 9, trb + s * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
-                w[s] = make_window(a, lox, hix, loy, hiy);
-                use[s] = (long)w[s].w * w[s].h <= WCAP;
-                fits = fits && use[s];
-            }
-            if (fits || de - ds <= 1) break;
-            de = ds + (de - ds + 1) / 2;
-        }
-        // ---- stage the windows: texel-major, quad-minor => 128-B coalesced global reads ----
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NS_T; ++s) {
-            if (!use[s]) continue;
-            const float* __restrict__ f = a.src[s] + (size_t)b * HW * C;
-            float* __restrict__ ws = win + s * WCAP * CPF;
-            for (int i = tid; i < w[s].w * w[s].h * QUADS; i += 256) {
-                const int t = i / QUADS, qq = i % QUADS;
-                const int wy = t / w[s].w, wx = t - wy * w[s].w;
-                *reinterpret_cast<float4*>(ws + t * CPF + 4 * qq) =
-                    ld4(f + ((size_t)(w[s].y0 + wy) * a.W + w[s].x0 + wx) * C + 4 * qq);
-            }
-        }
-        __syncthreads();
-        if (valid) {
-            for (int d = ds; d < de; ++d) {
-                const float dep = a.per_pixel ? a.depth[((size_t)b * a.D + d) * HW + pix] : a.depth[b * a.D + d];
-                float4 S = a.ms_alias ? r2 : r;
-                float4 Q = r2;
-#pragma unroll
-                for (int s = 0; s < NS_T; ++s) {
-                    float ix, iy;
-                    source_index(rotb + s * 9, trb + s * 3, xf, yf, dep, a, ix, iy);
-                    float4 v = sample4_win<C>(win + s * WCAP * CPF, w[s], use[s], a.src[s] + fbase, make_taps(ix, iy, a.H, a.W),
-                                              a.W, q);
-                    S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
-                    Q.x = fmaf(v.x, v.x, Q.x); Q.y = fmaf(v.y, v.y, Q.y); Q.z = fmaf(v.z, v.z, Q.z); Q.w = fmaf(v.w, v.w, Q.w);
-                }
-                float4 o;
-                float m;
-                m = S.x * inv_n; o.x = Q.x * inv_n - m * m;
-                m = S.y * inv_n; o.y = Q.y * inv_n - m * m;
-                m = S.z * inv_n; o.z = Q.z * inv_n - m * m;
-                m = S.w * inv_n; o.w = Q.w * inv_n - m * m;
-                *reinterpret_cast<float4*>(a.var + (((size_t)b * a.D + d) * HW + pix) * C + 4 * q) = o;
-            }
-        }
-        ds = de;
     }
 }
 
@@ -1288,11 +1111,6 @@ static int sweep_fwd_variant() {
 static int g_sweep_nt = 0;
 static int g_sweep_tile_w = 0;   // knob "tile_w": 0 = default square-ish tile
 static int g_sweep_dslab = 0;    // knob "dslab": planes per workgroup of the forward kernels, 0 = auto
-extern int g_sweep_bwd_cpl;   // plane_sweep_bwd.hip: knob "bwd_cpl"
-extern int g_sweep_bwd_wf;    // plane_sweep_bwd.hip: knob "bwd_wf"
-extern int g_sweep_bwd_pd;    // plane_sweep_bwd.hip: knob "bwd_pd"
-bool sweep_bwd_tb_supports(const SweepArgs& a, int C);
-int launch_sweep_bwd_tb(SweepArgs& a, int C, hipStream_t st);
 extern int g_conv_split;
 extern int g_conv_small;
 extern int g_conv_small_wgs;
@@ -1305,10 +1123,9 @@ extern int g_conv_bf16_dp;
 extern int g_conv2d_s2_mfma;
 extern int g_conv2d_pp;
 extern int g_conv2d_wgrad_groups;
-static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views; the default), 1 = view-pair kernel with LDS atomics, 2 = projection-table form with an LDS-DMA ring (plane_sweep_bwd.hip; round 3, measured slower: DESIGN.md section 4)
+static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views; the default), 1 = view-pair kernel with LDS atomics (what > 4 source views run).  (Round 3's projection-table form with an LDS-DMA ring measured 2.2x slower and was removed in round 4: DESIGN.md section 4, git tag r3-rejected-variants.)
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
-static int g_sweep_fwd_qs = 0;        // knob "fwd_qs": 1 = one projection per (pixel, view) shared by the pixel's channel lanes (C = 32; 2-4 views: quad DPP, 6 views: ds_bpermute); also selected by sweep_fwd = 6
 static int g_sweep_xcd = 0;           // knob "sweep_xcd": XCD-compact workgroup order of the cached forward and the per-wave-window backward
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
@@ -1323,8 +1140,8 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"cout1_d4", &g_conv_cout1_d4, 0, 3}, {"bf16_dp", &g_conv_bf16_dp, 0, 1}, {"conv2d_pp", &g_conv2d_pp, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
-        {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 6}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 2}, {"bwd_cpl", &g_sweep_bwd_cpl, 1, 4}, {"bwd_wf", &g_sweep_bwd_wf, 1024, 8192}, {"bwd_pd", &g_sweep_bwd_pd, 0, 16},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1}, {"fwd_qs", &g_sweep_fwd_qs, 0, 1},
+        {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
     };
     for (const Knob& k : knobs)
         if (strcmp(key, k.name) == 0) {
@@ -1383,36 +1200,24 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             a.dslab = g_sweep_dslab > 0 ? g_sweep_dslab : slab;
             if (dl && a.dslab > 512) a.dslab = 512;
             dim3 gridb(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
-            const bool qsb = (g_sweep_fwd_qs || variant == 6) && C == 32 && a.NS >= 2;
 #define MVS_BF_CASE(N, CPTN)                                                                                                   \
     case N:                                                                                                                    \
-        if (qsb && N >= 2 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 1>), gridb, block, 0, st, a); \
-        else if (qsb && N >= 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, (CB == 32 && N >= 2), true, 0>), gridb, block, 0, st, a); \
-        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 2>), gridb, block, 0, st, a); \
-        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 1>), gridb, block, 0, st, a); \
-        else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, false, true, 0>), gridb, block, 0, st, a);         \
+        if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 2>), gridb, block, 0, st, a);       \
+        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 1>), gridb, block, 0, st, a);       \
+        else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 0>), gridb, block, 0, st, a);               \
         break;
             switch (a.NS) { MVS_BF_CASE(1, 8) MVS_BF_CASE(2, 8) MVS_BF_CASE(3, 8) MVS_BF_CASE(4, 8) MVS_BF_CASE(6, 4) }
 #undef MVS_BF_CASE
             return mvs_check_launch("plane_sweep_variance_fwd_cached (bf16 volume)");
         }
-        const bool qs = (g_sweep_fwd_qs || variant == 6) && C == 32 && !c16;
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
-        else if (qs && N >= 2 && N <= 4 && c8 && dl)                                                              \
-            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, (C == 32 && N >= 2 && N <= 4), false, 1>), gridc, block, 0, st, a); \
-        else if (qs && N >= 2 && N <= 4 && c8)                                                                    \
-            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, (C == 32 && N >= 2 && N <= 4), false, 0>), gridc, block, 0, st, a); \
-        else if (qs && N == 6 && !c8 && dl)                                                                       \
-            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, (C == 32 && N == 6), false, 1>), gridc, block, 0, st, a); \
-        else if (qs && N == 6 && !c8)                                                                             \
-            MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, (C == 32 && N == 6), false, 0>), gridc, block, 0, st, a); \
-        else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 2>), gridc, block, 0, st, a); \
-        else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, false, 1>), gridc, block, 0, st, a); \
+        else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, 2>), gridc, block, 0, st, a); \
+        else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, 1>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \
-        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, false, 2>), gridc, block, 0, st, a); \
-        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, false, 1>), gridc, block, 0, st, a); \
+        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, 2>), gridc, block, 0, st, a); \
+        else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4, false, 1>), gridc, block, 0, st, a); \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, 4>), gridc, block, 0, st, a);            \
         break;
         switch (a.NS) {
@@ -1423,18 +1228,6 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
     }
     MVS_REQUIRE(!a.bf16_out, MVS_ERR_UNSUPPORTED, "plane_sweep bf16 volume: only the register-cached forward (knob sweep_fwd >= 2) "
                 "with 1, 2, 3, 4 or 6 source views stores bf16");
-    if (!a.warp_only && variant == 1) {
-        bool done = true;
-        switch (a.NS) {
-            case 1: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 1>), grid, block, 0, st, a); break;
-            case 2: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 2>), grid, block, 0, st, a); break;
-            case 3: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 3>), grid, block, 0, st, a); break;
-            case 4: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 4>), grid, block, 0, st, a); break;
-            case 6: MVS_LAUNCH((plane_sweep_variance_fwd_lds_kernel<C, 6>), grid, block, 0, st, a); break;
-            default: done = false;
-        }
-        if (done) return mvs_check_launch("plane_sweep_variance_fwd_lds");
-    }
     switch (a.warp_only ? 1 : a.NS) {
         case 1: MVS_LAUNCH((plane_sweep_variance_fwd_kernel<C, 1>), grid, block, 0, st, a); break;
         case 2: MVS_LAUNCH((plane_sweep_variance_fwd_kernel<C, 2>), grid, block, 0, st, a); break;
@@ -1474,7 +1267,6 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
 
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
-    if (g_sweep_bwd_variant == 2 && sweep_bwd_tb_supports(a, C)) return launch_sweep_bwd_tb(a, C, st);
     if (g_sweep_bwd_variant != 1 && a.NS <= 4) {
         // 1-2 views: 2 waves per SIMD with the upstream gradient requested two planes ahead (knob "bwd_gd" = 0: 3 waves per SIMD, one
         // rotating register set); 3-4 views: 2 waves per SIMD (knob "bwd_pf" = 2: ONE wave per SIMD, 512 registers, nothing spills)

@@ -464,11 +464,38 @@ def set_wgrad_streams(n: int) -> None:
     _N_SIDE = max(1, int(n))
 
 
+_SIDE_PRIORITY = os.environ.get("MVS_SIDE_PRIORITY", "default")   # "low": the lowest stream priority the device offers
+
+
+def set_side_stream_priority(which: str) -> None:
+    """"low": the side streams are created with the lowest priority of the device (torch.cuda.Stream.priority_range()), so the
+    main stream's kernels -- the critical path -- are dispatched first and the weight gradients fill what is left; "default": the
+    priority of an ordinary stream.  Drops the existing pool (new streams are made on demand)."""
+    global _SIDE_PRIORITY
+    if which not in ("low", "default"):
+        raise ValueError("side stream priority must be 'low' or 'default'")
+    _SIDE_PRIORITY = which
+    for idx, pool in _SIDE_STREAMS.items():
+        for sd in pool:
+            sd.synchronize()
+    _SIDE_STREAMS.clear()
+
+
+def _new_side_stream(dev):
+    if _SIDE_PRIORITY == "low":
+        try:
+            least = torch.cuda.Stream.priority_range()[0]     # (least, greatest): numerically larger = lower priority
+            return torch.cuda.Stream(device=dev, priority=least)
+        except Exception:
+            pass
+    return torch.cuda.Stream(device=dev)
+
+
 def _side_stream(dev):
     idx = dev.index
     pool = _SIDE_STREAMS.setdefault(idx, [])
     while len(pool) < _N_SIDE:
-        pool.append(torch.cuda.Stream(device=dev))
+        pool.append(_new_side_stream(dev))
     k = _SIDE_NEXT.get(idx, 0) % _N_SIDE
     _SIDE_NEXT[idx] = k + 1
     return pool[k]

@@ -98,7 +98,7 @@ def test_plane_sweep_variance_vs_oracle(dev, c, ns, per_pixel, alias, ac, dims):
         assert float((a.grad.cpu() - t.grad).abs().max()) < 2e-3 * max(1.0, float(t.grad.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("c,ns,step", [(32, 2, 60.0), (32, 2, 400.0), (16, 3, 150.0), (32, 4, 90.0)])
 def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     """Backward with footprints that do not fit one accumulation window: depth segmentation and, for the widest range,
@@ -116,9 +116,8 @@ def test_plane_sweep_backward_wide_depth_range(dev, c, ns, step, variant):
     # variant 2 = the per-wave-window kernel with its windows switched off (every flush takes the global-atomic path),
     # variant 3 = ... in its 3-waves/SIMD form (one rotating register set for the upstream gradient), variant 4 = ... at ONE
     # wave/SIMD for 3-4 source views, variant 5 = ... with the block lookahead (1-2 source views)
-    # variant 6 = the projection-table form with the LDS-DMA ring (round 3, knob sweep_bwd=2), 7 = ... with its windows switched off
-    lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else (2 if variant >= 6 else 0))
-    lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant in (2, 7) else 0)
+    lib.call("mvs_set_tuning", b"sweep_bwd", 1 if variant == 1 else 0)
+    lib.call("mvs_set_tuning", b"bwd_nowin", 1 if variant == 2 else 0)
     lib.call("mvs_set_tuning", b"bwd_gd", 0 if variant == 3 else 2)
     lib.call("mvs_set_tuning", b"bwd_pf", 2 if variant == 4 else (1 if variant == 5 else 0))
     try:
@@ -1096,29 +1095,6 @@ def test_featurenet_eval_folded_batchnorm_vs_stock(dev):
     scale = float(yr.abs().max())
     assert float((y1 - y0).abs().max()) < 2e-5 * scale
     assert float((y1.cpu() - yr).abs().max()) < 1e-4 * scale
-
-
-@pytest.mark.parametrize("ns,hw", [(2, (61, 83)), (4, (32, 40))])
-def test_plane_sweep_fwd_quad_shared_projection(dev, ns, hw):
-    """Forward variant 6 (per-view projection computed once per pixel quad, quad-broadcast DPP moves; not the default) must be
-    bit-identical to the default variant 3: N = 3 and N = 5 views, ragged image size."""
-    from mvs_amd import _lib, ops
-    lib = _lib.get()
-    g = torch.Generator().manual_seed(31 + ns)
-    b, c, d = 2, 32, 24
-    h, w = hw
-    rot, trans = _cams(b, ns, h, w)
-    ref = torch.randn(b, c, h, w, generator=g).to(dev)
-    srcs = [torch.randn(b, c, h, w, generator=g).to(dev) for _ in range(ns)]
-    depth = (430 + 11.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1).to(dev)
-    outs = {}
-    for variant in (3, 6):
-        lib.call("mvs_set_tuning", b"sweep_fwd", variant)
-        try:
-            outs[variant] = ops.plane_sweep_variance(ref, srcs, rot.to(dev), trans.to(dev), depth)
-        finally:
-            lib.call("mvs_set_tuning", b"sweep_fwd", 3)
-    assert torch.equal(outs[3], outs[6])
 
 
 # ---- bf16-storage inference path (BASELINE configs[4]); the reference has no reduced-precision path, so the oracle is the

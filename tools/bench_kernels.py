@@ -66,8 +66,7 @@ def main():
     k1_bytes = (NS + 1) * C * H * W * 4 + C * vox * 4
     skip_sweep = bool(os.environ.get("MVS_BENCH_SKIP_SWEEP"))
     with torch.no_grad():
-        for variant, label in (((3, "cached8"),) if skip_sweep else ((0, "direct"), (2, "cached4"), (3, "cached8"), (6, "cached8, quad-shared projection"), (3, "cached8"),
-                               (6, "cached8, quad-shared projection"), (4, "cached16"))):
+        for variant, label in (((3, "cached8"),) if skip_sweep else ((0, "direct"), (2, "cached4"), (3, "cached8"), (4, "cached16"))):
             lib.call("mvs_set_tuning", b"sweep_fwd", variant)
             add("sweep_fwd[%s]" % label, lambda: ops.plane_sweep_variance(feats[0], feats[1:], rot, trans, depth), "hbm", k1_bytes)
         lib.call("mvs_set_tuning", b"dslab", 0)
@@ -94,18 +93,6 @@ def main():
         v5 = ops.plane_sweep_variance(f5[0], f5[1:], rot5, trans5, depth)
         gv5 = torch.randn_like(v5)
         nbytes = C * vox * 4 + 2 * (ns_ + 1) * C * H * W * 4
-        # round 3: the projection-table form (plane_sweep_bwd.hip) over its knobs, then the round-2 / round-1 kernels for reference
-        for pd, wf, dslab in ((8, 1536, 0), (16, 1536, 0), (8, 2048, 0), (16, 2048, 0), (8, 3200, 0), (8, 1536, 24), (8, 1536, 32), (8, 1536, 64),
-                              (8, 1536, 96), (16, 1536, 96), (8, 1536, 192), (8, 1536, 0)):
-            lib.call("mvs_set_tuning", b"sweep_bwd", 2)
-            lib.call("mvs_set_tuning", b"bwd_pd", pd)
-            lib.call("mvs_set_tuning", b"bwd_wf", wf)
-            lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
-            add("sweep_bwd N=%d [table form, DMA ring %d planes, %d window floats/wave%s]%s" % (ns_ + 1, pd, wf, ", dslab %d" % dslab if dslab else "", label),
-                lambda: torch.autograd.grad(v5, f5, gv5, retain_graph=True), "hbm", nbytes)
-        lib.call("mvs_set_tuning", b"bwd_pd", _lib.DEFAULT_TUNING.get("bwd_pd", 8))
-        lib.call("mvs_set_tuning", b"bwd_wf", _lib.DEFAULT_TUNING.get("bwd_wf", 1536))
-        lib.call("mvs_set_tuning", b"bwd_dslab", 0)
         for variant, gd, pf, dslab in ((1, 2, 0, 0), (0, 0, 0, 0), (0, 2, 0, 0)):
             lib.call("mvs_set_tuning", b"sweep_bwd", variant)
             lib.call("mvs_set_tuning", b"bwd_dslab", dslab)
