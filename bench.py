@@ -227,6 +227,30 @@ def cpu_baseline(net_state, seed):
                 oracle(i1, p1, d1)
                 t1.append(time.perf_counter() - t0)
         c1 = sorted(t1)[2]
+        # thread sweep: threads = physical cores oversubscribes small problems (config 1: 0.5 s on 128 threads
+        # against 0.044 s on 8), so the best of a small sweep is reported beside the contract's number -- one timed sample per
+        # thread count for config 2 (stopping when a sample passes 40 s), median of 3 for config 1
+        sweep2, sweep1 = {}, {}
+        for nt in [t for t in (64, 32, 16) if t < phys]:
+            torch.set_num_threads(nt)
+            oracle.train()
+            sample()
+            sweep2[nt] = round(sample(), 3)
+            if sweep2[nt] > 40.0:
+                break
+        oracle.eval()
+        for nt in [t for t in (64, 32, 16, 8) if t < phys]:
+            torch.set_num_threads(nt)
+            with torch.no_grad():
+                oracle(i1, p1, d1)
+                tt = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    oracle(i1, p1, d1)
+                    tt.append(time.perf_counter() - t0)
+            sweep1[nt] = round(sorted(tt)[1], 4)
+        sweep2[phys], sweep1[phys] = round(dt, 3), round(c1, 4)
+        best2, best1 = min(sweep2, key=sweep2.get), min(sweep1, key=sweep1.get)
     finally:
         torch.set_num_threads(old_threads)
         R.set_sampler(old_sampler)
@@ -235,8 +259,12 @@ def cpu_baseline(net_state, seed):
             "sample": "1 warm-up + 3 timed samples (median) of the same workload (MVSNet N=3 640x512 D=192 fp32 fwd+loss+bwd), "
                       "oracle/ref_torch.py with sampler='aten' (F.grid_sample called as the reference calls it, ATen/oneDNN conv3d, batch_norm, "
                       "softmax) on %d CPU threads = physical cores" % phys,
+            "best_of_threads": {"threads": best2, "seconds_per_sample": sweep2[best2], "value": 1.0 / sweep2[best2],
+                                "seconds_per_sample_by_threads": {str(k): v for k, v in sorted(sweep2.items())}},
             "config1": {"value": 1.0 / c1, "unit": "depth-samples/s", "seconds_per_sample": c1,
-                        "what": "BASELINE configs[0]: MVSNet eval forward N=3 160x128 D=48 on the same CPU, median of 5 after 1 warm-up"}}
+                        "what": "BASELINE configs[0]: MVSNet eval forward N=3 160x128 D=48 on the same CPU, median of 5 after 1 warm-up",
+                        "best_of_threads": {"threads": best1, "seconds_per_sample": sweep1[best1], "value": 1.0 / sweep1[best1],
+                                            "seconds_per_sample_by_threads": {str(k): v for k, v in sorted(sweep1.items())}}}}
 
 
 def calibrate_bn(net, *inputs):

@@ -1516,9 +1516,10 @@ static int check_stride(int stride, int D, int H, int W, const char* what) {
 static int plan_for(int op, int B, int D, int H, int W, int Cin, int Cout, int stride, IgemmPlan& p, const char* what) {
     int rc = check_stride(stride, D, H, W, what);
     if (rc) return rc;
-    // the kernels index voxels with 32-bit ints inside a tile's neighbourhood and size_t beyond; the element counts themselves
-    // must fit the int arithmetic of the tile maps
-    MVS_REQUIRE(B > 0 && (long long)B * D * H * W * 8 < (1LL << 40), MVS_ERR_SHAPE, "%s: volume %dx%dx%dx%d too large", what, B, D, H, W);
+    // element offsets are size_t everywhere (a batch-3 config-5 volume has 2.9 G elements: tests/test_gpu_parity.py); VOXEL counts,
+    // tile counts and in-tile offsets are 32-bit ints, so the number of (fine-grid) voxels has to fit one
+    MVS_REQUIRE(B > 0 && (long long)B * D * H * W * (stride == 2 ? 8 : 1) < (1LL << 31), MVS_ERR_SHAPE,
+                "%s: %d x %d x %d x %d voxels do not fit the kernels' 32-bit voxel indices", what, B, D, H, W);
     p = {};
     p.B = B; p.cin1 = false;
     switch (op) {

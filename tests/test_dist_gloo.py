@@ -84,6 +84,12 @@ def test_bench_launches_its_own_ranks():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["rank_sum"] == 3.0     # ranks 0 and 1 both took part in the collective
+    # the 8-rank launch the driver uses on an 8-GPU node (VERDICT r3 next #8f): same self-launcher, gloo, one all-reduce + barrier
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["rank_sum"] == 36.0
     # a launcher that starts a different number of ranks than --gpus asks for is an error, not a warning
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,

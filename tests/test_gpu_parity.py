@@ -1195,6 +1195,40 @@ def test_bf16_inference_path(dev, n, ih, iw, nd):
     torch.cuda.empty_cache()
 
 
+def test_config5_batch3_bf16_volume_crosses_2g_elements(dev):
+    """BASELINE configs[4] ("in-HBM cost volume exercising 288 GB") at batch 3: the bf16 volume has 3 x 970 M = 2.9 G elements, past
+    2^31 -- every kernel of the inference path (sweep store, bf16 regulariser, soft-argmin) must index it with 64-bit arithmetic.
+    Eval mode is sample-independent, so each sample of the batch must reproduce its own batch-1 run (VERDICT r3 weak #3)."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(0)
+    n, ih, iw, nd = 7, 1184, 1600, 256
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    net = net.to(dev)
+    ins = [R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=11 + k) for k in range(3)]
+    i0, p0, d0 = (t.to(dev) for t in ins[0])
+    calibrate_batchnorm(net, i0, p0, d0)
+    net.storage_dtype = torch.bfloat16
+    singles = []
+    with torch.no_grad():
+        for im, pr, dv in ins:
+            o = net(im.to(dev), pr.to(dev), dv.to(dev))
+            singles.append((o["depth"].clone(), o["photometric_confidence"].clone()))
+        imgs = torch.cat([t[0] for t in ins]).to(dev)
+        proj = torch.cat([t[1] for t in ins]).to(dev)
+        dvs = torch.cat([t[2] for t in ins]).to(dev)
+        assert 3 * 32 * nd * (ih // 4) * (iw // 4) > 2 ** 31
+        ob = net(imgs, proj, dvs)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert float(singles[k][0].std()) > 1.0                       # a non-degenerate depth map
+        assert torch.equal(ob["depth"][k:k + 1], singles[k][0]), "sample %d of the batch differs from its batch-1 run" % k
+        assert torch.equal(ob["photometric_confidence"][k:k + 1], singles[k][1])
+    del ob, singles, imgs
+    torch.cuda.empty_cache()
+
+
 def test_geo_consistency_filter_golden(dev):
     """SURVEY 8(f)-4: the HIP geometric-consistency filter (jdacs/eval.py:169-224 + the aggregation of filter_depth) against the
     fixture produced by EXECUTING the reference's own functions (tests/golden/make_golden_geo.py), and a 1600x1184-sized run
@@ -1221,6 +1255,12 @@ def test_geo_consistency_filter_golden(dev):
     ok = cnt == z["geo_count"]
     assert np.allclose(r["depth_avg"].cpu().numpy()[ok], z["depth_avg"][ok], rtol=1e-6)
     assert float((r["final_mask"].cpu().numpy() != z["final_mask"]).mean()) < 2e-3
+
+
+def test_filter_depth_scan_level_golden(dev, tmp_path):
+    """The scan-level tail of filter_depth (eval.py:340-447) on the GPU vs the fixture made by executing the reference's own function."""
+    from test_emul_kernels import _run_filter_depth_golden
+    _run_filter_depth_golden(tmp_path, "cuda")
 
 
 def test_fusibile_fusion_kernel_and_folder_run(dev, tmp_path):
