@@ -90,8 +90,12 @@ class MvsLib:
             fn.argtypes = args
             setattr(self, "_" + name, fn)
 
-    def call(self, name: str, *args, tag: str = ""):
+    def call(self, name: str, *args, tag=""):
+        """tag: a string, or (format, *values) -- formatted only when a KernelTimer is attached (the hot path builds ~100 tags per
+        training step that nobody reads)."""
         prof = self.profiler
+        if prof is not None and not isinstance(tag, str):
+            tag = tag[0] % tuple(tag[1:])
         if prof is not None and prof.wants(name, tag):
             import torch
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -57,11 +57,12 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
 
 
 def as_cl2(t: torch.Tensor) -> torch.Tensor:
-    return t.contiguous(memory_format=CL2)
+    # (the layout test costs a tenth of a no-op .contiguous() call; these run ~300 times per training step)
+    return t if t.is_contiguous(memory_format=CL2) else t.contiguous(memory_format=CL2)
 
 
 def as_cl3(t: torch.Tensor) -> torch.Tensor:
-    return t.contiguous(memory_format=CL3)
+    return t if t.is_contiguous(memory_format=CL3) else t.contiguous(memory_format=CL3)
 
 
 def empty_cl3(b, c, d, h, w, like: torch.Tensor) -> torch.Tensor:
@@ -231,7 +232,8 @@ def _ws(lib, op, b, d, h, w, cin, cout, stride, like):
 
 
 def _ctag(kind, cin, cout, stride, b, d, h, w):
-    return "%s:%d>%d:s%d:%dx%dx%dx%d" % (kind, cin, cout, stride, b, d, h, w)
+    # formatted by _lib.MvsLib.call only when a KernelTimer is attached ("%s:%d>%d:s%d:%dx%dx%dx%d")
+    return ("%s:%d>%d:s%d:%dx%dx%dx%d", kind, cin, cout, stride, b, d, h, w)
 
 
 def _out_dims(d, h, w, stride, transposed):

@@ -1259,8 +1259,8 @@ def test_geo_consistency_filter_golden(dev):
 
 def test_filter_depth_scan_level_golden(dev, tmp_path):
     """The scan-level tail of filter_depth (eval.py:340-447) on the GPU vs the fixture made by executing the reference's own function."""
-    from test_emul_kernels import _run_filter_depth_golden
-    _run_filter_depth_golden(tmp_path, "cuda")
+    from conftest import run_filter_depth_golden
+    run_filter_depth_golden(tmp_path, "cuda")
 
 
 def test_fusibile_fusion_kernel_and_folder_run(dev, tmp_path):

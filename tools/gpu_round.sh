@@ -653,3 +653,22 @@ for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_to
 PY
   MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py > gpurun_out/kernels_r4e.log 2>&1; echo "kernels exit $?"; grep -E "prob|wgrad" gpurun_out/kernels_r4e.log
 fi
+if [ "$what" = "r4f" ]; then
+  # round 4, sixth session: low-priority side stream A/B, cleanup regression (sweep variants removed), other configs
+  timeout 1200 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider \
+    -k "plane_sweep or filter_depth_scan or batch3 or mvsnet_loss or mvsnet_end_to_end or config2_train_step or cvpmvsnet_end_to_end or bf16_inference" > gpurun_out/pytest_r4f.log 2>&1
+  echo "pytest exit $?"; tail -3 gpurun_out/pytest_r4f.log
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "side_low" --ab-reps 3 > gpurun_out/bench_r4f.json 2> gpurun_out/bench_r4f.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4f.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ms_per_step_async_wgrad_off")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+  for cfg in 3 4 5; do
+    timeout 600 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4f_c$cfg.json 2> gpurun_out/bench_r4f_c$cfg.err
+    echo "config $cfg exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3)) for k,v in d['kernels'].items()})" gpurun_out/bench_r4f_c$cfg.json
+  done
+fi
