@@ -1445,6 +1445,7 @@ int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv wit
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
+int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
@@ -1716,10 +1717,10 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     if (geom == GEOM_S1) { a.QD = Di; a.QH = Hi; a.QW = Wi; }
     else { a.QD = (Di - 1) / 2 + 1; a.QH = (Hi - 1) / 2 + 1; a.QW = (Wi - 1) / 2 + 1; }
     a.ntd = mvs_cdiv(a.QD, geom == GEOM_S2 ? 2 : 4); a.nth = mvs_cdiv(a.QH, 4); a.ntw = mvs_cdiv(a.QW, 16);
-    const int ntiles = B * a.ntd * a.nth * a.ntw;
+    int ntiles = B * a.ntd * a.nth * a.ntw;
     const int cc = CX % 16 == 0 ? 16 : 8;
     const int nbw = CG > 16 ? 2 : 1;
-    const int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+    int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
     if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
         const int g8 = ntiles < 512 ? ntiles : 512;   // 60 KB LDS -> 2 resident workgroups per CU
         if (g_conv_c8 & 4) MVS_LAUNCH(conv_c8_wgrad_kernel<true>, dim3(g8, CX / 16), dim3(256), 0, st, a);
@@ -1734,6 +1735,23 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
         else MVS_LAUNCH((conv_wgrad_cg1_kernel<16>), dim3(groups), dim3(256), 0, st, a);
         int rc1 = mvs_check_launch("conv_wgrad_cg1");
         if (rc1) return rc1;
+        return wgrad_finish(ws, groups, CX, CG, gw, st);
+    }
+    // knob "wgrad_small": quarter-size tiles (the *_SMALL geometries) for the generic kernel when the launch has many tiles anyway:
+    // a stride-2 layer with 8 X channels (the L0 layers) holds a 5x9x33-voxel halo + the G tile = 87 KB of LDS per workgroup, ONE
+    // workgroup per CU; at 3x9x33 it is 51 KB and three fit (latency bound: 126 MB + 31 MB read in 99 us)
+    const bool small = g_conv_wgrad_small == 3 ||      // (3: always -- tests)
+                       (g_conv_wgrad_small && ntiles >= 2 * WGRAD_MAX_GROUPS && (g_conv_wgrad_small == 2 || cc == 8 || geom == GEOM_S2));
+    if (small) {
+        const int kg = geom + GEOM_S1_SMALL;
+        a.ntd = mvs_cdiv(a.QD, geom_tqd(kg)); a.nth = mvs_cdiv(a.QH, geom_tqh(kg));
+        ntiles = B * a.ntd * a.nth * a.ntw;
+        groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+        dim3 grids(groups, CX / cc, mvs_cdiv(CG, nbw * 16));
+        if (geom == GEOM_S1) { if (cc == 16) launch_wgrad<GEOM_S1_SMALL, 16>(a, nbw, grids, st); else launch_wgrad<GEOM_S1_SMALL, 8>(a, nbw, grids, st); }
+        else { if (cc == 16) launch_wgrad<GEOM_S2_SMALL, 16>(a, nbw, grids, st); else launch_wgrad<GEOM_S2_SMALL, 8>(a, nbw, grids, st); }
+        int rcs = mvs_check_launch("conv_wgrad (small tiles)");
+        if (rcs) return rcs;
         return wgrad_finish(ws, groups, CX, CG, gw, st);
     }
     dim3 grid(groups, CX / cc, mvs_cdiv(CG, nbw * 16));

@@ -1289,3 +1289,29 @@ def test_conv3d_wgrad_wide_reduction_of_many_partial_images(emul_lib):
     yr.backward(gy)
     gw = ops.conv3d_wgrad(x, gy, tuple(w.shape), 1, False)
     assert float((gw - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [(8, 16, 2, False, (4, 8, 20)), (16, 16, 1, False, (3, 5, 18)), (16, 8, 2, True, (2, 4, 10)),
+                                                             (8, 8, 1, False, (4, 3, 17)), (32, 32, 1, False, (2, 3, 17))])
+def test_conv3d_wgrad_quarter_size_tiles(emul_lib, cin, cout, stride, transposed, dims):
+    """Knob wgrad_small: the generic weight-gradient kernel on the *_SMALL geometries (3x9x33- instead of 5x9x33-voxel halos for the
+    stride-2 L0 layers: three workgroups per CU instead of one) -- same result as the full-size tiles, and vs ATen."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + stride)
+    x = torch.randn(2, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(x, wr, stride=stride, padding=1, output_padding=stride - 1) if transposed else F.conv3d(x, wr, stride=stride, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    outs = {}
+    try:
+        for mode in (0, 3):
+            emul_lib.call("mvs_set_tuning", b"wgrad_small", mode)
+            outs[mode] = ops.conv3d_wgrad(x, gy, wshape, stride, transposed)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"wgrad_small", 0)
+    scale = max(1.0, float(wr.grad.abs().max()))
+    assert float((outs[3] - wr.grad).abs().max()) < 1e-3 * scale
+    assert float((outs[3] - outs[0]).abs().max()) < 2e-4 * scale

@@ -672,3 +672,16 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3)) for k,v in d['kernels'].items()})" gpurun_out/bench_r4f_c$cfg.json
   done
 fi
+if [ "$what" = "r4g" ]; then
+  # round 4, session 7: quarter-size tiles in the generic weight-gradient kernels
+  timeout 600 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "conv3d_family or costregnet_mvs" > gpurun_out/pytest_r4g.log 2>&1
+  echo "pytest exit $?"; tail -2 gpurun_out/pytest_r4g.log
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "wgrad_small=1;wgrad_small=2" --ab-reps 3 > gpurun_out/bench_r4g.json 2> gpurun_out/bench_r4g.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4g.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+  for m in 0 1 2; do echo "wgrad_small=$m"; MVS_TUNING="wgrad_small=$m" MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py 2>&1 | grep -E "conv1 wgrad|conv2 wgrad|prob wgrad"; done
+fi
