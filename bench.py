@@ -517,9 +517,12 @@ def main():
     if roctx is not None:
         roctx.roctxProfilerResume(0)
     t0 = time.perf_counter()
+    host_marks = [t0]
     for _ in range(args.steps):
         loss = step()
-    t_host = time.perf_counter() - t0       # the host has ENQUEUED the K steps (eager mode: Python + ctypes + allocator time)
+        host_marks.append(time.perf_counter())
+    t_host = host_marks[-1] - t0            # the host has ENQUEUED the K steps (eager mode: Python + ctypes + allocator time)
+    host_steps = sorted((b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:]))
     barrier()
     dt = time.perf_counter() - t0
     if roctx is not None:
@@ -662,7 +665,8 @@ def main():
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
             "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
             "wgrad_join": ("end of backward pass" if defer_join else "inside the regulariser node") if train else None,
-            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "host_enqueue_ms_per_step_median_max": [host_steps[len(host_steps) // 2], host_steps[-1]], "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }

@@ -90,26 +90,33 @@ class MvsLib:
             fn.argtypes = args
             setattr(self, "_" + name, fn)
 
-    def call(self, name: str, *args, tag=""):
+    def call(self, name: str, *args, tag="", tstream=None):
         """tag: a string, or (format, *values) -- formatted only when a KernelTimer is attached (the hot path builds ~100 tags per
-        training step that nobody reads)."""
+        training step that nobody reads).  tstream: the torch stream the kernel is enqueued on when that is not the current one
+        (the HIP-event brackets of a KernelTimer go on that stream)."""
         prof = self.profiler
-        if prof is not None and not isinstance(tag, str):
-            tag = tag[0] % tuple(tag[1:])
-        if prof is not None and prof.wants(name, tag):
-            import torch
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()  # current stream == the stream the kernel is enqueued on (ops._stream)
-            rc = getattr(self, "_" + name)(*args)
-            ev1.record()
-            prof.add(name, tag, ev0, ev1)
-        else:
-            rc = getattr(self, "_" + name)(*args)
+        if prof is not None:
+            if not isinstance(tag, str):
+                tag = tag[0] % tuple(tag[1:])
+            if prof.wants(name, tag):
+                import torch
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(tstream)  # default: the current stream == the stream the kernel is enqueued on (ops._stream)
+                rc = getattr(self, "_" + name)(*args)
+                ev1.record(tstream)
+                prof.add(name, tag, ev0, ev1)
+                if rc != 0:
+                    self._raise(name, rc)
+                return
+        rc = getattr(self, "_" + name)(*args)
         if rc != 0:
-            msg = self._mvs_last_error().decode("utf-8", "replace")
-            if rc in (-1, -2, -4):
-                raise ValueError("%s failed (%d): %s" % (name, rc, msg))
-            raise RuntimeError("%s failed (%d): %s" % (name, rc, msg))
+            self._raise(name, rc)
+
+    def _raise(self, name, rc):
+        msg = self._mvs_last_error().decode("utf-8", "replace")
+        if rc in (-1, -2, -4):
+            raise ValueError("%s failed (%d): %s" % (name, rc, msg))
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, msg))
 
     def raw(self, name: str, *args):
         return getattr(self, "_" + name)(*args)
@@ -119,7 +126,7 @@ _INSTANCE = None
 
 # library defaults of the measurement knobs (csrc: g_conv_c8, g_conv_xcd); MVS_TUNING="k8=2,xcd=0" overrides them
 # for A/B runs of bench.py / tools without touching code
-DEFAULT_TUNING = {"k8": 7, "xcd": 1, "side_pre": 1, "conv_small": 1, "tr2pw": 1, "sweep_bwd": 0, "wgrad_small": 0}
+DEFAULT_TUNING = {"k8": 7, "xcd": 1, "side_pre": 1, "conv_small": 1, "tr2pw": 1, "sweep_bwd": 0, "wgrad_small": 0, "wgrad_groups": 768, "wgrad8_groups": 512}
 
 
 def get() -> MvsLib:

@@ -1445,6 +1445,8 @@ int g_conv_tr2pw = 1;       // tuning knob "tr2pw": transposed stride-2 conv wit
 int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tiles below this many workgroups (~1.5 per CU)
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
+int g_conv_wgrad_groups = 768;   // tuning knob "wgrad_groups": persistent workgroups of the generic weight-gradient kernels (<= 768)
+int g_conv_wgrad8_groups = 512;  // tuning knob "wgrad8_groups": ... of the CG == 8 kernel (conv0; <= 512)
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
@@ -1720,9 +1722,13 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     int ntiles = B * a.ntd * a.nth * a.ntw;
     const int cc = CX % 16 == 0 ? 16 : 8;
     const int nbw = CG > 16 ? 2 : 1;
-    int groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+    // knobs "wgrad_groups" / "wgrad8_groups": persistent workgroups of a launch.  The weight gradients run on a side stream next
+    // to the backward pass's critical path; fewer workgroups take longer but leave more of the chip to the main stream.
+    const int maxg = g_conv_wgrad_groups < 1 ? 1 : (g_conv_wgrad_groups > WGRAD_MAX_GROUPS ? WGRAD_MAX_GROUPS : g_conv_wgrad_groups);
+    int groups = ntiles < maxg ? ntiles : maxg;
     if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
-        const int g8 = ntiles < 512 ? ntiles : 512;   // 60 KB LDS -> 2 resident workgroups per CU
+        const int max8 = g_conv_wgrad8_groups < 1 ? 1 : (g_conv_wgrad8_groups > 512 ? 512 : g_conv_wgrad8_groups);
+        const int g8 = ntiles < max8 ? ntiles : max8;   // 60 KB LDS -> 2 resident workgroups per CU
         if (g_conv_c8 & 4) MVS_LAUNCH(conv_c8_wgrad_kernel<true>, dim3(g8, CX / 16), dim3(256), 0, st, a);
         else MVS_LAUNCH(conv_c8_wgrad_kernel<false>, dim3(g8, CX / 16), dim3(256), 0, st, a);
         int rc8 = mvs_check_launch("conv_c8_wgrad");
@@ -1746,7 +1752,7 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
         const int kg = geom + GEOM_S1_SMALL;
         a.ntd = mvs_cdiv(a.QD, geom_tqd(kg)); a.nth = mvs_cdiv(a.QH, geom_tqh(kg));
         ntiles = B * a.ntd * a.nth * a.ntw;
-        groups = ntiles < WGRAD_MAX_GROUPS ? ntiles : WGRAD_MAX_GROUPS;
+        groups = ntiles < maxg ? ntiles : maxg;
         dim3 grids(groups, CX / cc, mvs_cdiv(CG, nbw * 16));
         if (geom == GEOM_S1) { if (cc == 16) launch_wgrad<GEOM_S1_SMALL, 16>(a, nbw, grids, st); else launch_wgrad<GEOM_S1_SMALL, 8>(a, nbw, grids, st); }
         else { if (cc == 16) launch_wgrad<GEOM_S2_SMALL, 16>(a, nbw, grids, st); else launch_wgrad<GEOM_S2_SMALL, 8>(a, nbw, grids, st); }

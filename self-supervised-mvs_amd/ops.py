@@ -285,17 +285,14 @@ def stat_slots(like: torch.Tensor, groups: int, nslots: int, c: int, pieces: int
     n = groups * nslots * 2 * c
     st = getattr(_SLOT_TLS, "state", None)
     if st is None or st["depth"] == 0:
-        z = torch.zeros(pieces * n, dtype=torch.float64, device=like.device)
-        return [z[i * n:(i + 1) * n].view(groups, nslots, 2, c) for i in range(pieces)]
-    out = []
+        return list(torch.zeros((pieces, groups, nslots, 2, c), dtype=torch.float64, device=like.device).unbind(0))
     key = (like.device.type, like.device.index)
-    for _ in range(pieces):
-        ent = st["arenas"].get(key)
-        if ent is None or ent[1] + n > ent[0].numel():
-            ent = st["arenas"][key] = [torch.zeros(max(_ARENA_DOUBLES, n), dtype=torch.float64, device=like.device), 0]
-        out.append(ent[0][ent[1]:ent[1] + n].view(groups, nslots, 2, c))
-        ent[1] += n
-    return out
+    ent = st["arenas"].get(key)
+    if ent is None or ent[1] + pieces * n > ent[0].numel():
+        ent = st["arenas"][key] = [torch.zeros(max(_ARENA_DOUBLES, pieces * n), dtype=torch.float64, device=like.device), 0]
+    off = ent[1]
+    ent[1] = off + pieces * n
+    return list(ent[0][off:off + pieces * n].view(pieces, groups, nslots, 2, c).unbind(0))
 
 
 def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None, skip=None, relu=False,
@@ -331,21 +328,27 @@ def conv3d_forward(x, weight, stride=1, transposed=False, scale=None, shift=None
     return y, slots
 
 
+_PACK_PLANS = {}   # (op, shape) tuple of a list of layers -> (workspace sizes, ctypes op / shape arrays): the same every training step
+
+
 def pack_conv3d_weights(items, like):
     """items: list of (op, weight, (B, D, H, W, Cin, Cout, stride)) -- forward / input-gradient ops with the FORWARD op's shape.
     ONE launch writes all their weight images; returns the list of workspace tensors (views of one buffer) to hand to
     conv3d_forward / conv3d_dgrad as ``packed_ws``."""
     lib = _lib_for(like)
     n = len(items)
-    sizes = [_ws_floats(lib, op, *shape) for op, _, shape in items]
+    key = tuple((op, shape) for op, _, shape in items)
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        if len(_PACK_PLANS) > 64:
+            _PACK_PLANS.clear()
+        sizes = [_ws_floats(lib, op, *shape) for op, _, shape in items]
+        plan = _PACK_PLANS[key] = (sizes, (C.c_int * n)(*[op for op, _, _ in items]),
+                                   (C.c_int * (7 * n))(*[int(v) for _, _, shape in items for v in shape]))
+    sizes, ops_arr, shp_arr = plan
     buf = torch.empty(sum(sizes), dtype=torch.float32, device=like.device)
-    views, off = [], 0
-    for sz in sizes:
-        views.append(buf[off:off + sz])
-        off += sz
-    ws_ = [wt.contiguous() for _, wt, _ in items]
-    ops_arr = (C.c_int * n)(*[op for op, _, _ in items])
-    shp_arr = (C.c_int * (7 * n))(*[int(v) for _, _, shape in items for v in shape])
+    views = list(torch.split(buf, sizes))
+    ws_ = [wt if wt.is_contiguous() else wt.contiguous() for _, wt, _ in items]
     lib.call("mvs_conv3d_pack_weights_batch", n, ops_arr, _ptr_array(ws_), _ptr_array(views), shp_arr, _stream(like))
     return views
 
@@ -421,7 +424,10 @@ def conv3d_dgrad(gy, weight, in_shape, stride=1, transposed=False, add=None, bn=
     return gx
 
 
-def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
+def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False, on_stream=None):
+    """on_stream: a torch stream OTHER than the current one to enqueue the kernels on (the caller has made it wait for the producers
+    of x and gy).  The output and the workspace are allocated from the current stream's pool -- no stream switch on the host, which
+    costs more than the launch -- and handed to `on_stream` with record_stream, so the allocator does not recycle them early."""
     lib = _lib_for(x)
     x = as_cl3(x)
     gy = as_cl3(gy)
@@ -431,7 +437,11 @@ def conv3d_wgrad(x, gy, weight_shape, stride=1, transposed=False):
     gw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
     ws = _ws(lib, op, b, d, h, w, cin, cout, stride, x)
     lib.call("mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad", _p(x), _p(gy), _p(gw), _p(ws), b, d, h, w,
-             cin, cout, stride, _stream(x), tag=_ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w))
+             cin, cout, stride, _stream(x) if on_stream is None else on_stream.cuda_stream,
+             tag=_ctag("wgradT" if transposed else "wgrad", cin, cout, stride, b, d, h, w), tstream=on_stream)
+    if on_stream is not None:
+        for ten in (x, gy, gw, ws):
+            ten.record_stream(on_stream)
     return gw
 
 
@@ -583,13 +593,9 @@ def _wgrad_maybe_async(x, gy, weight, stride, transposed):
     if not ok:
         return conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
     side = _side_stream(x.device)
-    x, gy = as_cl3(x), as_cl3(gy)
+    x, gy = as_cl3(x), as_cl3(gy)                # (a layout copy, if one is needed, runs on the main stream: before the fork)
     side.wait_stream(main)                       # gy was produced on the main stream
-    with torch.cuda.stream(side):
-        gw = conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed)
-    for ten in (x, gy):
-        ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
-    gw.record_stream(main)
+    gw = conv3d_wgrad(x, gy, tuple(weight.shape), stride, transposed, on_stream=side)
     ent[1] = True
     return gw
 
@@ -787,11 +793,7 @@ class UNetRegulariserFn(torch.autograd.Function):
                 return conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
             side = _side_stream(dev)
             side.wait_stream(main)                       # gout was produced on the main stream
-            with torch.cuda.stream(side):
-                gw = conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed)
-            for ten in (xin, gout):
-                ten.record_stream(side)                  # the caching allocator must not recycle them under the side kernels
-            gw.record_stream(main)
+            gw = conv3d_wgrad(xin, gout, tuple(weight.shape), stride, transposed, on_stream=side)
             side_used[0] = True
             return gw
 

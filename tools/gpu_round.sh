@@ -685,3 +685,21 @@ for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_to
 PY
   for m in 0 1 2; do echo "wgrad_small=$m"; MVS_TUNING="wgrad_small=$m" MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py 2>&1 | grep -E "conv1 wgrad|conv2 wgrad|prob wgrad"; done
 fi
+if [ "$what" = "r4h" ]; then
+  # round 4, session 8: host-side trims (no stream switch for side-stream wgrads, cached pack plans), wgrad workgroup-count knobs
+  timeout 600 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "costregnet_mvs or mvsnet_end_to_end or config2_train_step or featurenet_training" > gpurun_out/pytest_r4h.log 2>&1
+  echo "pytest exit $?"; tail -2 gpurun_out/pytest_r4h.log
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "wgrad_groups=256;wgrad_groups=512;wgrad8_groups=256" --ab-reps 3 > gpurun_out/bench_r4h.json 2> gpurun_out/bench_r4h.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4h.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max","ms_per_step_async_wgrad_off")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4h_2.json 2> gpurun_out/bench_r4h_2.err
+  python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4h_2.json"))
+print("second process:", {k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max")})
+PY
+fi
