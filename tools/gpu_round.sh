@@ -703,3 +703,13 @@ d=json.load(open("gpurun_out/bench_r4h_2.json"))
 print("second process:", {k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max")})
 PY
 fi
+if [ "$what" = "r4i" ]; then
+  timeout 600 python tools/bench_conv2d.py > gpurun_out/conv2d_layers_r4i.log 2>&1; echo "conv2d exit $?"; grep -v Warn gpurun_out/conv2d_layers_r4i.log | tail -32
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "wgrad8_groups=128;wgrad8_groups=256;wgrad8_groups=384" --ab-reps 3 > gpurun_out/bench_r4i.json 2> gpurun_out/bench_r4i.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4i.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+fi
