@@ -576,6 +576,12 @@ def main():
             elif spec == "split_bwd":
                 def setter(on, base=ConvBnReLU.split_bwd):
                     ConvBnReLU.split_bwd = (not base) if on else base
+            elif spec == "feature_dgrad":
+                def setter(on, base=ConvBnReLU.hip_dgrad_auto):
+                    ConvBnReLU.hip_dgrad_auto = (not base) if on else base
+            elif spec == "feature_wgrad":
+                def setter(on, base=ConvBnReLU.hip_wgrad):
+                    ConvBnReLU.hip_wgrad = (not base) if on else base
             elif spec == "feature_fwd":
                 base = ConvBnReLU.hip_fwd_train
                 def setter(on, base=base):

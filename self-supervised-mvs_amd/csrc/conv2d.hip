@@ -418,6 +418,41 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
     gw[((size_t)(co0 + co) * CXT + ci0 + ci) * NT + tap] = (s0 + s1) + (s2 + s3);
 }
 
+// The same in one WIDE launch (round 4): the kernel above gives every output element ONE thread that walks all partial images --
+// 64 dependent rounds of strided loads at 256 images, a ~90 us floor under every layer's weight gradient
+// (profiles/r04_run9_conv2d_layers.log: 0.09-0.17 ms against the library's 0.03-0.085).  Here a workgroup owns 16 consecutive
+// elements of the partial-image layout (coalesced 64-byte rows); its 16 x 16 threads = (element, slice) walk the images slice,
+// slice + 16, ... four loads in flight, then the slices are summed through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void conv2d_wgrad_reduce_wide_kernel(const float* __restrict__ part, int nparts, int NT, int CX, int CXP,
+                                                                       int CG, int CGP, float* __restrict__ gw, int CXT, int ci0, int co0) {
+    __shared__ float red[16][17];
+    const int n = NT * CXP * CGP;                       // elements of one partial image, padding included
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const size_t stride = (size_t)n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int p = slice;
+        for (; p + 48 < nparts; p += 64) {
+            const float a0 = part[(size_t)p * stride + e], a1 = part[(size_t)(p + 16) * stride + e];
+            const float a2 = part[(size_t)(p + 32) * stride + e], a3 = part[(size_t)(p + 48) * stride + e];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; p < nparts; p += 16) s0 += part[(size_t)p * stride + e];
+    }
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && e < n) {
+        const int co = e % CGP, row = e / CGP, ci = row % CXP, tap = row / CXP;
+        if (co < CG && ci < CX) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][el];
+            gw[((size_t)(co0 + co) * CXT + ci0 + ci) * NT + tap] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -658,8 +693,12 @@ extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, floa
             rc = mvs_check_launch("conv2d_wgrad");
             if (rc) return rc;
             const int n = a.CG * a.CX * nt;
-            MVS_LAUNCH(conv2d_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, groups, nt, a.CX, cxp, a.CG,
-                       nb * 16, gw, Cin, ci0, co0);
+            if (groups > 16)
+                MVS_LAUNCH(conv2d_wgrad_reduce_wide_kernel, dim3(mvs_cdiv(nt * cxp * nb * 16, 16)), dim3(256), 0, stream, (const float*)ws, groups, nt,
+                           a.CX, cxp, a.CG, nb * 16, gw, Cin, ci0, co0);
+            else
+                MVS_LAUNCH(conv2d_wgrad_reduce_kernel, dim3(mvs_cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, groups, nt, a.CX, cxp, a.CG,
+                           nb * 16, gw, Cin, ci0, co0);
         }
     return mvs_check_launch("conv2d_wgrad_reduce");
 }

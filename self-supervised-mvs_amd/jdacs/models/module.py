@@ -59,6 +59,17 @@ class ConvBnReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
 
+    # backward kernels of the training path above, chosen per layer from measurements at BASELINE config 2 (3 views of 512x640:
+    # profiles/r04_run9_conv2d_layers.log): csrc/conv2d.hip's input gradient wins on the 3x3 stride-1 layers with <= 16 channels
+    # (8->8: 0.035 vs 0.080 ms, 16->16: 0.026 vs 0.039), the library's on the 5x5 stride-2 layers and at 32 channels; the weight
+    # gradient stays the library's unless MVS_HIP_FEATURE_WGRAD=1.  MVS_HIP_FEATURE_DGRAD=0 keeps the library's everywhere.
+    hip_dgrad_auto = os.environ.get("MVS_HIP_FEATURE_DGRAD", "1") == "1"
+    hip_wgrad = os.environ.get("MVS_HIP_FEATURE_WGRAD", "0") == "1"
+
+    def _hip_dgrad(self) -> bool:
+        c = self.conv
+        return self.hip_dgrad_auto and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.in_channels * c.out_channels <= 256
+
     def hip_train_forward_serves(self, x) -> bool:
         """the training path of this block through csrc/conv2d.hip with fused BatchNorm statistics (hip_fwd_train) applies to x"""
         return (self.hip_fwd_train and not self.hip_conv and x.is_cuda and self.training and torch.is_grad_enabled()
@@ -84,7 +95,7 @@ class ConvBnReLU(nn.Module):
             if hip_fwd and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64) and self.bn.momentum is not None:
                 # convolution + BatchNorm statistics in one launch, then finalize + apply: no statistics pass over the activation
                 y, slots = ops.Conv2dSplitBwdFn.apply(x, self.conv.weight, self.conv.stride, self.conv.padding, True, True, groups,
-                                                      self.split_bwd, packed_ws)
+                                                      self.split_bwd, packed_ws, self._hip_dgrad(), self.hip_wgrad)
                 for _ in range(groups):
                     count_batch(self.bn, self.training)
                 return ops.BnReLUFn.apply(y, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, True,

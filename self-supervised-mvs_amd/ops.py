@@ -873,7 +873,8 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     of ATen's single node that runs both one after the other.  Same kernels, same results; only the schedule differs."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False, groups=1, side_stream=True, packed_ws=None):
+    def forward(ctx, x, weight, stride, padding, hip_forward=False, want_stats=False, groups=1, side_stream=True, packed_ws=None,
+                hip_dgrad=False, hip_wgrad=False):
         """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
         the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm statistic slots of y for `groups` equal batch
         chunks), the slots not differentiable."""
@@ -882,6 +883,8 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
         ctx.side_stream = bool(side_stream)   # False: the weight gradient stays on the main stream whatever set_async_wgrad says
+        # per-layer choice of the backward kernels (measured per layer: profiles/r04_run9_conv2d_layers.log)
+        ctx.hip_dgrad, ctx.hip_wgrad = bool(hip_dgrad), bool(hip_wgrad)
         # (the statistic slots are a second, non-differentiable output: without this autograd would hand backward() a zero-filled
         #  float64 tensor of their shape -- one fill launch per layer and step, seen in profiles/r04_run3_trace_tail.csv)
         ctx.set_materialize_grads(False)
@@ -896,17 +899,25 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_unused_grad_of_the_slots):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 11
         x, weight = ctx.saved_tensors
         stride, padding = ctx.cfg
         bwd = torch.ops.aten.convolution_backward
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if ctx.hip_dgrad:
+                gx = conv2d_dgrad(gy, weight, tuple(x.shape), stride[0])
+            else:
+                gx = bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
-            gw = _maybe_on_side_stream(fn, weight, (x, gy)) if ctx.side_stream else fn()
-        return gx, gw, None, None, None, None, None, None, None
+            if ctx.hip_wgrad:
+                gw = conv2d_wgrad(x, gy, tuple(weight.shape), stride[0])
+                if gw.stride() != weight.stride():       # the parameter's layout (channels-last extractor weights)
+                    gw = torch.empty_strided(weight.shape, weight.stride(), dtype=gw.dtype, device=gw.device).copy_(gw)
+            else:
+                fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                gw = _maybe_on_side_stream(fn, weight, (x, gy)) if ctx.side_stream else fn()
+        return gx, gw, None, None, None, None, None, None, None, None, None
 
 
 def _maybe_on_side_stream(fn, weight, inputs):

@@ -1315,3 +1315,18 @@ def test_conv3d_wgrad_quarter_size_tiles(emul_lib, cin, cout, stride, transposed
     scale = max(1.0, float(wr.grad.abs().max()))
     assert float((outs[3] - wr.grad).abs().max()) < 1e-3 * scale
     assert float((outs[3] - outs[0]).abs().max()) < 2e-4 * scale
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,hw", [(3, 8, 3, 1, (40, 130)), (8, 16, 5, 2, (44, 132)), (16, 32, 3, 1, (24, 200))])
+def test_conv2d_wgrad_wide_reduction(emul_lib, cin, cout, ks, stride, hw):
+    """More than 16 persistent workgroups -> conv2d_wgrad_reduce_wide_kernel (16 slices per element of the partial-image layout,
+    channel padding skipped): weight gradient vs ATen on images of 20+ tiles."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(1, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(cout, cin, ks, ks, requires_grad=True)
+    y = F.conv2d(x, w, stride=stride, padding=ks // 2)
+    gy = torch.randn(y.shape, generator=g).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    gw = ops.conv2d_wgrad(x, gy, tuple(w.shape), stride)
+    assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))

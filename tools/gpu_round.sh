@@ -713,3 +713,15 @@ print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step")})
 for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
 PY
 fi
+if [ "$what" = "r4j" ]; then
+  timeout 600 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "featurenet or conv2d_family or mvsnet_end_to_end or config2_train_step" > gpurun_out/pytest_r4j.log 2>&1
+  echo "pytest exit $?"; tail -2 gpurun_out/pytest_r4j.log
+  timeout 600 python tools/bench_conv2d.py > gpurun_out/conv2d_layers_r4j.log 2>&1; echo "conv2d exit $?"; grep -E "weight grad|TOTAL" gpurun_out/conv2d_layers_r4j.log
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "feature_dgrad;feature_wgrad;wgrad8_groups=64;wgrad8_groups=192" --ab-reps 3 > gpurun_out/bench_r4j.json 2> gpurun_out/bench_r4j.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4j.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+fi
