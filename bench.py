@@ -576,6 +576,9 @@ def main():
             elif spec == "split_bwd":
                 def setter(on, base=ConvBnReLU.split_bwd):
                     ConvBnReLU.split_bwd = (not base) if on else base
+            elif spec.startswith("fork_early="):
+                def setter(on, n=int(spec.split("=")[1])):
+                    _ops._WGRAD_FORK_EARLY = n if on else 0
             elif spec == "feature_dgrad":
                 def setter(on, base=ConvBnReLU.hip_dgrad_auto):
                     ConvBnReLU.hip_dgrad_auto = (not base) if on else base

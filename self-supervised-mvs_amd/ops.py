@@ -520,6 +520,7 @@ _WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses whose b
 _WEIGHT_MULTI = {}      # device index -> {weight data_ptr} that had > 1 outstanding use at some point (until all of them have run)
 _BWD_OPEN = {}          # device index -> [main stream, side stream used?] while a backward pass with our nodes is running
 _DEFER_JOIN = os.environ.get("MVS_WGRAD_DEFER_JOIN", "0") == "1"
+_WGRAD_FORK_EARLY = int(os.environ.get("MVS_WGRAD_FORK_EARLY", "0"))   # 0: after the block's input gradient, 1: before it (not conv0), 2: always before
 
 
 def set_async_wgrad(flag: bool, defer_join=None) -> None:
@@ -832,13 +833,19 @@ class UNetRegulariserFn(torch.autograd.Function):
             if skip >= 0:                                # y = relu(bn(raw)) + y_skip: the skip source receives gy as it is
                 g[skip] = gy if g[skip] is None else g[skip] + gy
             xin = x if src < 0 else ys[src]
+            # the side stream forks where the weight gradient is ENQUEUED: after the block's input gradient (it then starts when
+            # that kernel has finished) or, knob _WGRAD_FORK_EARLY, before it (it starts as soon as `draw` exists)
+            early = _WGRAD_FORK_EARLY == 2 or (_WGRAD_FORK_EARLY == 1 and src >= 0)
+            if early:
+                grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
             if src >= 0:
                 bn = bn_of(src, i)
                 g[src] = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=g[src], bn=bn, packed_ws=packed[dg_index[i]])
                 have[src] = bn is not None
             elif need[0]:
                 gx = conv3d_dgrad(draw, w, tuple(xin.shape), stride, transposed, add=gx, packed_ws=packed[dg_index[i]])
-            grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
+            if not early:
+                grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
         if side_used[0]:
             deferred = _DEFER_JOIN and all(gw is None or _async_safe(params_w) for gw, params_w in zip(grads[0:5 * n:5] + [grads[5 * n]], list(ws_) + [wp]))
             if deferred:

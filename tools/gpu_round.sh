@@ -725,3 +725,12 @@ print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ho
 for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
 PY
 fi
+if [ "$what" = "r4k" ]; then
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "fork_early=1;fork_early=2;split_bwd;wgrad_groups=512" --ab-reps 3 > gpurun_out/bench_r4k.json 2> gpurun_out/bench_r4k.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4k.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+fi
