@@ -734,3 +734,8 @@ print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","ho
 for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
 PY
 fi
+if [ "$what" = "full" ]; then
+  timeout 2400 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider --durations=15 > gpurun_out/pytest_gpu_full.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/pytest_gpu_full.log; grep -E "passed|failed|FAILED|pytest exit" gpurun_out/pytest_gpu_full.log | tail -8
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -2 gpurun_out/smoke.log
+fi
