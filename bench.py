@@ -513,6 +513,12 @@ def main():
     timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
     if not graph_mode:
         lib.profiler = timer   # live HIP-event brackets inside the timed region (eager mode)
+    # the cyclic garbage collector is kept out of the timed steps (an autograd step allocates ~10^4 Python objects; a generation-2
+    # collection landing inside a step stalls the launch thread for 5-10 ms -- profiles/r04_run11: one 11.7 ms step among 4.0 ms ones);
+    # one collection before the region, automatic collection back on after it.  Reference counting frees everything as usual.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     if roctx is not None:
         roctx.roctxProfilerResume(0)
@@ -527,6 +533,7 @@ def main():
     dt = time.perf_counter() - t0
     if roctx is not None:
         roctx.roctxProfilerPause(0)
+    gc.enable()
     lib.profiler = None
     if graph_mode:
         # kernels inside a graph replay cannot be bracketed by events; time the very same launches with HIP

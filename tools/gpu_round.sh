@@ -739,3 +739,7 @@ if [ "$what" = "full" ]; then
   echo "pytest exit $?" >> gpurun_out/pytest_gpu_full.log; grep -E "passed|failed|FAILED|pytest exit" gpurun_out/pytest_gpu_full.log | tail -8
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -2 gpurun_out/smoke.log
 fi
+if [ "$what" = "heavyfast" ]; then
+  MIOPEN_FIND_MODE=FAST timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=5 -k "config5_shape_seven_views_eval" > gpurun_out/pytest_heavyfast.log 2>&1
+  echo "pytest exit $?"; tail -12 gpurun_out/pytest_heavyfast.log
+fi
