@@ -670,7 +670,9 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     // LDS per wave: 12.5 KiB when 3 workgroups share a CU (4 channels per thread, <= 2 views: 3 waves/SIMD by registers),
     // 19.5 KiB when registers allow only 2 waves/SIMD anyway (8 channels per thread, or 3-4 views: more room per view -> longer
     // depth segments before a window overflows)
-    constexpr int WAVE_FLOATS = WPS >= 3 ? 3200 : 4992;
+    // (WPS = 1 -- knob "bwd_pf" = 2, 3-4 source views -- has the CU's LDS to itself: 37.5 KiB per wave, twice the window per view,
+    //  i.e. depth segments twice as long before a window overflows and half the window write-outs)
+    constexpr int WAVE_FLOATS = WPS >= 3 ? 3200 : (WPS == 1 ? 9600 : 4992);
     constexpr int VIEW_FLOATS = WAVE_FLOATS / NS_T / C * C, WCAP = VIEW_FLOATS / C;
     __shared__ __attribute__((aligned(16))) float lds[4 * NS_T * VIEW_FLOATS];   // [wave][view][texel][C]
     __shared__ int s_win[4][NS_T][5];                // per wave and view: x0, y0, w, h, usable

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The ORACLE's stock convolutions (MIOpen) otherwise spend minutes in the library's exhaustive find mode at BASELINE's full sizes
+# (one full-size eval test: 389 s; with the fast / immediate mode: 1.6 s -- profiles/r04_full_pytest_gpu.log vs
+# r04_final_pytest_gpu.log).  The product's own kernels are unaffected; its LIBRARY calls (the 2-D extractor's backward) pick their algorithm by heuristic instead of by timing -- same results.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import numpy as np
 import pytest
 import torch

@@ -743,3 +743,12 @@ if [ "$what" = "heavyfast" ]; then
   MIOPEN_FIND_MODE=FAST timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=5 -k "config5_shape_seven_views_eval" > gpurun_out/pytest_heavyfast.log 2>&1
   echo "pytest exit $?"; tail -12 gpurun_out/pytest_heavyfast.log
 fi
+if [ "$what" = "r4l" ]; then
+  for pf in 0 2; do
+    MVS_TUNING="bwd_pf=$pf" timeout 600 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 > gpurun_out/bench_r4l_c3_pf$pf.json 2> gpurun_out/bench_r4l_c3_pf$pf.err
+    echo "config 3 bwd_pf=$pf exit $?"; python -c "
+import json,sys
+d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'],1), {k:(round(v['ms'],4), round(v.get('frac',0),3)) for k,v in d['kernels'].items()})" gpurun_out/bench_r4l_c3_pf$pf.json
+  done
+  timeout 300 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "wide_depth_range or config3_shape" 2>&1 | tail -2
+fi
