@@ -597,12 +597,16 @@ def main():
                 def setter(on, base=base):
                     ConvBnReLU.hip_fwd_train = (not base) if on else base
             else:
-                key, _, val = spec.partition("=")
-                dflt = _lib.DEFAULT_TUNING.get(key)
-                if dflt is None:
-                    raise SystemExit("bench.py --ab: give the library default of '%s' in _lib.DEFAULT_TUNING first" % key)
-                def setter(on, key=key, val=int(val), dflt=dflt):
-                    lib.call("mvs_set_tuning", key.encode(), val if on else dflt)
+                pairs = []     # "key=value[,key=value...]": several knobs toggled together
+                for item in spec.split(","):
+                    key, _, val = item.partition("=")
+                    dflt = _lib.DEFAULT_TUNING.get(key)
+                    if dflt is None:
+                        raise SystemExit("bench.py --ab: give the library default of '%s' in _lib.DEFAULT_TUNING first" % key)
+                    pairs.append((key, int(val), dflt))
+                def setter(on, pairs=pairs):
+                    for key, val, dflt in pairs:
+                        lib.call("mvs_set_tuning", key.encode(), val if on else dflt)
             times = ([], [])
             for _ in range(args.ab_reps):
                 for on in (0, 1):

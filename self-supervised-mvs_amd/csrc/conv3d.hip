@@ -1216,7 +1216,11 @@ __global__ __launch_bounds__(256) void conv_c8_fwd_bc_kernel(ConvArgs a, const f
 // BC = true: the output gradient is the MFMA's broadcast operand instead (cbsz = 4: one VGPR pair carries g of 16
 // consecutive W positions, abid selects the position), so g costs 2 LDS reads per 16 positions instead of 2 per
 // position and each lane ends up owning its (tap, input channel) for 4 output channels.
-template <bool BC>
+// NCH: 16-channel chunks of X one workgroup handles (blockIdx.y counts groups of NCH chunks).  NCH = 2 at conv0 (32 input channels):
+// the X halo tile of BOTH chunks -- the whole 128-byte line of every voxel -- is staged by the workgroup that needs it, the output
+// gradient tile once for both (NCH = 1 fetched every X line from two workgroups and the g tile twice: 2.12 GB of HBM traffic for
+// 0.63 GB algorithmic); 110 KB of LDS = one workgroup per CU, which is all this kernel is given on the side stream.
+template <bool BC, int NCH>
 __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     using G = ConvGeom<GEOM_S1>;
     // LDS image of the X halo region: 16 floats per voxel, ODD row / plane strides (RHP x RWP = 7 x 19), so the
@@ -1228,12 +1232,12 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     constexpr int NRP = G::RD * RHP * RWP;
     constexpr int NPOS = G::TQD * G::TQH * G::TQW;   // 256
     constexpr int NTG = 7;                           // tap groups of 4 (27 -> 28)
-    __shared__ __attribute__((aligned(16))) float xt[NRP * CCP];
+    __shared__ __attribute__((aligned(16))) float xt[NCH * NRP * CCP];
     __shared__ __attribute__((aligned(16))) float gt[NPOS * 8];
     __shared__ int tapmap[32];   // slot (tg, lane group) -> tap id (27 = dummy)
     __shared__ int tapoff[32];   // slot -> LDS offset of that tap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.y;
+    const int chunk0 = blockIdx.y * NCH;
     if (tid == 0) {
         int ne = 0, no = 0;
         int ev[16], od[16];
@@ -1253,14 +1257,16 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     int toff[NTG];
 #pragma unroll
     for (int tg = 0; tg < NTG; ++tg) toff[tg] = tapoff[4 * tg + (lane >> 4)] + (lane & 15);
-    f32x4 acc[NTG][2];
+    f32x4 acc[NCH][NTG][2];
 #pragma unroll
-    for (int tg = 0; tg < NTG; ++tg) { acc[tg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[tg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int tg = 0; tg < NTG; ++tg) { acc[ch][tg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[ch][tg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int ntiles = a.B * a.ntd * a.nth * a.ntw;
     constexpr int NXI = G::RD * G::RH * G::RW * (CC / 4);
     constexpr int XIT = (NXI + 255) / 256, GIT = (NPOS * 2 + 255) / 256;
-    float4 xv[XIT], gv[GIT];
+    float4 xv[NCH][XIT], gv[GIT];
     // per-item offsets relative to the tile's origin voxel / position and their LDS slots: tile-invariant, computed
     // once per persistent workgroup; tiles that do not touch the volume boundary skip the per-item bounds checks
     int xrel[XIT], xlo[XIT], grel[GIT], glo[GIT];
@@ -1283,14 +1289,16 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
         if (a.xcd) brick_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
         else linear_tile(tile, a.ntw, a.nth, a.ntd, b, td, th, tw);
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
-        const float* __restrict__ xb = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.CX + chunk * CC;
+        const float* __restrict__ xb = a.x + ((((size_t)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * a.CX + chunk0 * CC;
         const float* __restrict__ gb = a.g + ((((size_t)b * a.QD + qd0) * a.QH + qh0) * a.QW + qw0) * 8;
         const bool interior = qd0 >= 1 && qd0 + G::TQD + 1 <= a.Di && qh0 >= 1 && qh0 + G::TQH + 1 <= a.Hi &&
                               qw0 >= 1 && qw0 + G::TQW + 1 <= a.Wi;
         if (interior) {
 #pragma unroll
-            for (int k = 0; k < XIT; ++k)
-                if (tid + 256 * k < NXI) xv[k] = *reinterpret_cast<const float4*>(xb + xrel[k]);
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int k = 0; k < XIT; ++k)
+                    if (tid + 256 * k < NXI) xv[ch][k] = *reinterpret_cast<const float4*>(xb + ch * CC + xrel[k]);
 #pragma unroll
             for (int k = 0; k < GIT; ++k)
                 if (tid + 256 * k < NPOS * 2) gv[k] = *reinterpret_cast<const float4*>(gb + grel[k]);
@@ -1300,9 +1308,10 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
                 const int i = tid + 256 * k, vox = i / (CC / 4);
                 const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
                 const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
-                xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < NXI && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                    xv[k] = *reinterpret_cast<const float4*>(xb + xrel[k]);
+                const bool in = i < NXI && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch)
+                    xv[ch][k] = in ? *reinterpret_cast<const float4*>(xb + ch * CC + xrel[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < GIT; ++k) {
@@ -1316,8 +1325,10 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int k = 0; k < XIT; ++k)
-            if (tid + 256 * k < NXI) *reinterpret_cast<float4*>(xt + xlo[k]) = xv[k];
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int k = 0; k < XIT; ++k)
+                if (tid + 256 * k < NXI) *reinterpret_cast<float4*>(xt + ch * NRP * CCP + xlo[k]) = xv[ch][k];
 #pragma unroll
         for (int k = 0; k < GIT; ++k)
             if (tid + 256 * k < NPOS * 2) *reinterpret_cast<float4*>(gt + glo[k]) = gv[k];
@@ -1338,13 +1349,16 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
                 const float ga0 = gt[(p0 + (lane >> 2)) * 8 + (lane & 3)], ga1 = gt[(p0 + (lane >> 2)) * 8 + 4 + (lane & 3)];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    float av[NTG];
 #pragma unroll
-                    for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[xoff0 + k * CCP + toff[tg]];
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        float av[NTG];
 #pragma unroll
-                    for (int tg = 0; tg < NTG; ++tg) {
-                        acc[tg][0] = mfma_4x4x1_bc(ga0, av[tg], acc[tg][0], k);
-                        acc[tg][1] = mfma_4x4x1_bc(ga1, av[tg], acc[tg][1], k);
+                        for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[ch * NRP * CCP + xoff0 + k * CCP + toff[tg]];
+#pragma unroll
+                        for (int tg = 0; tg < NTG; ++tg) {
+                            acc[ch][tg][0] = mfma_4x4x1_bc(ga0, av[tg], acc[ch][tg][0], k);
+                            acc[ch][tg][1] = mfma_4x4x1_bc(ga1, av[tg], acc[ch][tg][1], k);
+                        }
                     }
                 }
             }
@@ -1355,41 +1369,47 @@ __global__ __launch_bounds__(256) void conv_c8_wgrad_kernel(WgradArgs a) {
             const int pw_ = p % G::TQW, ph_ = (p / G::TQW) % G::TQH, pd_ = p / (G::TQW * G::TQH);
             const int xoff = ((pd_ * RHP + ph_) * RWP + pw_) * CCP;
             const float b0 = gt[p * 8 + (lane & 3)], b1 = gt[p * 8 + 4 + (lane & 3)];
-            float av[NTG];
 #pragma unroll
-            for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[xoff + toff[tg]];
+            for (int ch = 0; ch < NCH; ++ch) {
+                float av[NTG];
 #pragma unroll
-            for (int tg = 0; tg < NTG; ++tg) {
-                acc[tg][0] = MVS_MFMA_4x4x1(av[tg], b0, acc[tg][0]);
-                acc[tg][1] = MVS_MFMA_4x4x1(av[tg], b1, acc[tg][1]);
+                for (int tg = 0; tg < NTG; ++tg) av[tg] = xt[ch * NRP * CCP + xoff + toff[tg]];
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg) {
+                    acc[ch][tg][0] = MVS_MFMA_4x4x1(av[tg], b0, acc[ch][tg][0]);
+                    acc[ch][tg][1] = MVS_MFMA_4x4x1(av[tg], b1, acc[ch][tg][1]);
+                }
             }
         }
         }
     }
-    // sum the 4 waves through LDS (reusing xt: 28 slots x 16 cx x 8 co = 3584 floats), then one partial image
-    __syncthreads();
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+    // sum the 4 waves through LDS (reusing xt: 28 slots x 16 cx x 8 co = 3584 floats), then one partial image -- chunk after chunk
 #pragma unroll
-            for (int tg = 0; tg < NTG; ++tg)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // lane: block bl = lane>>2 -> slot 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
-                        // (BC: the lane is (slot, cx) = (lane>>4, lane&15) and reg r -> co = 4h + r)
-                        const int bl = lane >> 2;
-                        const int idx = BC ? ((4 * tg + (lane >> 4)) * 16 + (lane & 15)) * 8 + 4 * h + r
-                                           : ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
-                        if (wv == 0) xt[idx] = acc[tg][h][r];
-                        else xt[idx] += acc[tg][h][r];
-                    }
-        }
+    for (int ch = 0; ch < NCH; ++ch) {
         __syncthreads();
-    }
-    for (int i = tid; i < 28 * 16 * 8; i += 256) {
-        const int co = i & 7, cx = (i >> 3) & 15, tap = tapmap[i >> 7];
-        if (tap < 27) a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + chunk * 16 + cx) * 8 + co] = xt[i];
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // lane: block bl = lane>>2 -> slot 4*tg + (bl>>2), cx group bl&3; j = lane&3 -> co = j + 4h; reg r -> cx = 4*(bl&3) + r
+                            // (BC: the lane is (slot, cx) = (lane>>4, lane&15) and reg r -> co = 4h + r)
+                            const int bl = lane >> 2;
+                            const int idx = BC ? ((4 * tg + (lane >> 4)) * 16 + (lane & 15)) * 8 + 4 * h + r
+                                               : ((4 * tg + (bl >> 2)) * 16 + 4 * (bl & 3) + r) * 8 + (lane & 3) + 4 * h;
+                            if (wv == 0) xt[idx] = acc[ch][tg][h][r];
+                            else xt[idx] += acc[ch][tg][h][r];
+                        }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < 28 * 16 * 8; i += 256) {
+            const int co = i & 7, cx = (i >> 3) & 15, tap = tapmap[i >> 7];
+            if (tap < 27) a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + (chunk0 + ch) * 16 + cx) * 8 + co] = xt[i];
+        }
     }
 }
 
@@ -1447,6 +1467,7 @@ int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tile
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
 int g_conv_wgrad_groups = 768;   // tuning knob "wgrad_groups": persistent workgroups of the generic weight-gradient kernels (<= 768)
 int g_conv_wgrad8_groups = 128;  // tuning knob "wgrad8_groups": ... of the CG == 8 kernel (conv0; <= 512).  128 = one workgroup on every other CU: on the side stream it runs under the plane-sweep backward and the 2-D extractor's backward, and the step is faster the less it takes from them (5.440 ms at 512, 5.416 at 384, 5.413 at 256, 5.400 at 128: profiles/r04_run9_*)
+int g_conv_wgrad8_nch = 1;       // tuning knob "wgrad8_nch": 2 = the CG == 8 weight gradient stages both 16-channel chunks of a 32-channel X in one workgroup
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
@@ -1729,8 +1750,16 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
         const int max8 = g_conv_wgrad8_groups < 1 ? 1 : (g_conv_wgrad8_groups > 512 ? 512 : g_conv_wgrad8_groups);
         const int g8 = ntiles < max8 ? ntiles : max8;   // 60 KB LDS -> 2 resident workgroups per CU
-        if (g_conv_c8 & 4) MVS_LAUNCH(conv_c8_wgrad_kernel<true>, dim3(g8, CX / 16), dim3(256), 0, st, a);
-        else MVS_LAUNCH(conv_c8_wgrad_kernel<false>, dim3(g8, CX / 16), dim3(256), 0, st, a);
+        if (CX % 32 == 0 && g_conv_wgrad8_nch == 2) {     // both 16-channel chunks of a 32-channel line in one workgroup (knob "wgrad8_nch")
+            const int g2 = g8 > 256 ? 256 : g8;              // 110 KB of LDS: one workgroup per CU
+            if (g_conv_c8 & 4) MVS_LAUNCH((conv_c8_wgrad_kernel<true, 2>), dim3(g2, CX / 32), dim3(256), 0, st, a);
+            else MVS_LAUNCH((conv_c8_wgrad_kernel<false, 2>), dim3(g2, CX / 32), dim3(256), 0, st, a);
+            int rc2 = mvs_check_launch("conv_c8_wgrad");
+            if (rc2) return rc2;
+            return wgrad_finish(ws, g2, CX, CG, gw, st);
+        }
+        if (g_conv_c8 & 4) MVS_LAUNCH((conv_c8_wgrad_kernel<true, 1>), dim3(g8, CX / 16), dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv_c8_wgrad_kernel<false, 1>), dim3(g8, CX / 16), dim3(256), 0, st, a);
         int rc8 = mvs_check_launch("conv_c8_wgrad");
         if (rc8) return rc8;
         return wgrad_finish(ws, g8, CX, CG, gw, st);

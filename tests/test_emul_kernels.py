@@ -1330,3 +1330,28 @@ def test_conv2d_wgrad_wide_reduction(emul_lib, cin, cout, ks, stride, hw):
     y.backward(gy)
     gw = ops.conv2d_wgrad(x, gy, tuple(w.shape), stride)
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dims,xcd", [((4, 4, 18), 1), ((5, 6, 16), 0), ((3, 9, 33), 1)])
+def test_conv_cout8_weight_gradient_two_chunks_per_workgroup(emul_lib, dims, xcd):
+    """Knob wgrad8_nch = 2 (conv0, mvsnet.py:40: 32 -> 8): one workgroup stages the X halo of BOTH 16-channel chunks and the output
+    gradient tile once -- the same weight gradient as the one-chunk form, and vs ATen; ragged tiles, both tile orders."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(sum(dims))
+    x = torch.randn(2, 32, *dims, generator=g)
+    w = torch.zeros(8, 32, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, w, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    outs = {}
+    emul_lib.call("mvs_set_tuning", b"xcd", xcd)
+    try:
+        for nch in (1, 2):
+            emul_lib.call("mvs_set_tuning", b"wgrad8_nch", nch)
+            outs[nch] = ops.conv3d_wgrad(x, gy, tuple(w.shape), 1, False)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"wgrad8_nch", 1)
+        emul_lib.call("mvs_set_tuning", b"xcd", 1)
+    scale = max(1.0, float(w.grad.abs().max()))
+    assert float((outs[2] - w.grad).abs().max()) < 1e-3 * scale
+    assert float((outs[2] - outs[1]).abs().max()) < 2e-4 * scale

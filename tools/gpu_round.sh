@@ -752,3 +752,14 @@ d=json.load(open(sys.argv[1])); print(round(d['ms_per_step'],3), round(d['value'
   done
   timeout 300 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "wide_depth_range or config3_shape" 2>&1 | tail -2
 fi
+if [ "$what" = "r4m" ]; then
+  timeout 300 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "cout8 or costregnet_mvs" 2>&1 | tail -2
+  timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pmc 0 --gpu-reference 0 --ab "wgrad8_nch=2;wgrad8_nch=2,wgrad8_groups=256" --ab-reps 3 > gpurun_out/bench_r4m.json 2> gpurun_out/bench_r4m.err
+  echo "bench exit $?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_r4m.json"))
+print({k:d.get(k) for k in ("ms_per_step","value","host_enqueue_ms_per_step","host_enqueue_ms_per_step_median_max")})
+for k,v in d.get("ab",{}).items(): print(k, v["median_default_ms"], v["median_toggled_ms"], v["default_ms"], v["toggled_ms"])
+PY
+  for m in 1 2; do echo "wgrad8_nch=$m"; MVS_TUNING="wgrad8_nch=$m,wgrad8_groups=256" MVS_BENCH_SKIP_SWEEP=1 timeout 600 python tools/bench_kernels.py 2>&1 | grep -E "conv0 wgrad \[4x4x1 broadcast operand, XCD"; done
+fi
