@@ -311,6 +311,8 @@ def main():
                          "'feature_fwd' (2-D extractor's forward through conv2d.hip + fused BatchNorm statistics) or "
                          "'<tuning key>=<value>' (mvs_set_tuning, against the library default); 5 pairs of --steps steps each")
     ap.add_argument("--ab-reps", type=int, default=5)
+    ap.add_argument("--host-profile", type=str, default="",
+                    help="after the timed region: cProfile of --steps more steps on the launch thread, top entries written to this file")
     ap.add_argument("--wgrad-streams", type=int, default=1,
                     help="side streams the regulariser's weight gradients are dealt to round-robin (ops.set_wgrad_streams)")
     ap.add_argument("--side-priority", type=str, default="default", choices=["default", "low"],
@@ -566,6 +568,23 @@ def main():
         ms_other_mode = float(tm.item()) / args.steps * 1e3
         _ops.set_async_wgrad(async_wgrad)
 
+    if args.host_profile and rank == 0:
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        barrier()
+        pr.enable()
+        for _ in range(args.steps):
+            step()
+        pr.disable()
+        barrier()
+        buf = io.StringIO()
+        st = pstats.Stats(pr, stream=buf)
+        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("cumulative").print_stats(60)
+        with open(args.host_profile, "w") as fh:
+            fh.write("%d steps\n" % args.steps + buf.getvalue())
     ab = {}
     if args.ab and not graph_mode:
         from mvs_amd.jdacs.models.module import ConvBnReLU
