@@ -102,6 +102,12 @@ def algorithmic_work(cfg):
     return work, tags
 
 
+# the kernel the roofline object describes (the longest-running tagged kernel of the step, profiles/r04_final_bench*.json): the ONLY
+# one bracketed by HIP events inside the timed region -- every bracket is two event records on the launch stream (~5 us of stream
+# time each; five bracketed kernels cost the headline ~0.1 ms/step in round 4's first sessions).  The other tagged kernels are timed
+# in a second pass of the same K steps right after the region (--region-timers all: everything inside the region, as before).
+DOMINANT = {2: "conv0_wgrad", 3: "sweep_bwd", 4: "conv_64_64", 5: "sweep_fwd_bf16"}
+
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
     "sweep_fwd": "plane_sweep_variance_fwd", "sweep_bwd": "plane_sweep_variance_bwd",
     "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2,",
@@ -285,6 +291,11 @@ def calibrate_bn(net, *inputs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--region-timers", choices=("dominant", "all"), default="dominant",
+                    help="HIP-event brackets inside the timed region: the roofline kernel only (default; the other tagged kernels in a "
+                         "second pass of K steps after the region) or all tagged kernels")
+    ap.add_argument("--step-events", type=int, default=0,
+                    help="diagnostics: 1 = one HIP event after every timed step; the per-step GPU times go to the line as step_gpu_ms")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
@@ -426,6 +437,8 @@ def main():
             # (as 32 slices of the flat store: a fused multi-tensor optimiser runs one workgroup per tensor chunk)
             opt = torch.optim.Adam(bucket.optimizer_params(32), lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
 
+            phase_marks = [] if args.step_events else None     # diagnostics: host clock after forward+loss / backward, per step
+
             def fwd_bwd():
                 bucket.zero()
                 out = net(imgs, proj, dv)
@@ -433,7 +446,11 @@ def main():
                     loss = unsup(imgs, cams, out["depth"])          # jdacs/train.py:199-210 (standard unsupervised loss)
                 else:
                     loss = mvsnet_loss(out["depth"], gt, mask)
+                if phase_marks is not None:
+                    phase_marks.append(time.perf_counter())
                 loss.backward()
+                if phase_marks is not None:
+                    phase_marks.append(time.perf_counter())
                 bucket.gather()
                 return loss
         else:
@@ -512,9 +529,22 @@ def main():
         step()
     # live HIP-event timing of the roofline kernels over the timed region, on the launch stream
     work, tagmap = algorithmic_work(args.config)
-    timer = _lib.KernelTimer(only={t for _, t in tagmap.values()})
+    dom_key = DOMINANT.get(args.config) if (args.region_timers == "dominant" and DOMINANT.get(args.config) in tagmap) else None
+    in_region = {k: v for k, v in tagmap.items() if dom_key is None or k == dom_key}
+    later = {k: v for k, v in tagmap.items() if k not in in_region}
+    timer = _lib.KernelTimer(only={t for _, t in in_region.values()}, names={n for n, _ in in_region.values()})
     if not graph_mode:
         lib.profiler = timer   # live HIP-event brackets inside the timed region (eager mode)
+    host_trace = None
+    if args.step_events >= 2:
+        class HostTrace:       # diagnostics: host clock at every C-ABI call of the timed steps (no HIP events)
+            names = None
+            rows = []
+
+            def wants(self, name, tag):
+                self.rows.append((time.perf_counter(), name, tag))
+                return False
+        host_trace = lib.profiler = HostTrace()
     # the cyclic garbage collector is kept out of the timed steps (an autograd step allocates ~10^4 Python objects; a generation-2
     # collection landing inside a step stalls the launch thread for 5-10 ms -- profiles/r04_run11: one 11.7 ms step among 4.0 ms ones);
     # one collection before the region, automatic collection back on after it.  Reference counting frees everything as usual.
@@ -526,9 +556,19 @@ def main():
         roctx.roctxProfilerResume(0)
     t0 = time.perf_counter()
     host_marks = [t0]
+    step_events = []
+    if args.step_events and train:
+        del phase_marks[:]
+        _ops.JOIN_TRACE = []
+    if args.step_events:
+        step_events.append(torch.cuda.Event(enable_timing=True))
+        step_events[0].record()
     for _ in range(args.steps):
         loss = step()
         host_marks.append(time.perf_counter())
+        if args.step_events:
+            step_events.append(torch.cuda.Event(enable_timing=True))
+            step_events[-1].record()
     t_host = host_marks[-1] - t0            # the host has ENQUEUED the K steps (eager mode: Python + ctypes + allocator time)
     host_steps = sorted((b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:]))
     barrier()
@@ -537,10 +577,21 @@ def main():
         roctx.roctxProfilerPause(0)
     gc.enable()
     lib.profiler = None
+    join_trace, _ops.JOIN_TRACE = _ops.JOIN_TRACE, None
     if graph_mode:
         # kernels inside a graph replay cannot be bracketed by events; time the very same launches with HIP
         # events in an eager pass of the same K steps directly after the timed region (same process, same data)
         lib.profiler = timer
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        lib.profiler = None
+    timer2 = None
+    if later:
+        # the other tagged kernels: the same K steps again (on every rank: a step holds the collective), bracketed, right after
+        # the timed region (never part of `value`)
+        timer2 = _lib.KernelTimer(only={t for _, t in later.values()}, names={n for n, _ in later.values()})
+        lib.profiler = timer2
         for _ in range(args.steps):
             eager_step()
         torch.cuda.synchronize()
@@ -605,6 +656,13 @@ def main():
             elif spec.startswith("fork_early="):
                 def setter(on, n=int(spec.split("=")[1])):
                     _ops._WGRAD_FORK_EARLY = n if on else 0
+            elif spec == "feature_one_node":
+                from mvs_amd.jdacs.models.mvsnet import FeatureNet as _FN
+                def setter(on, base=_FN.one_node):
+                    _FN.one_node = (not base) if on else base
+            elif spec == "feature_wgrad_batch":
+                def setter(on, base=_ops.FEATURE_WGRAD_BATCH):
+                    _ops.FEATURE_WGRAD_BATCH = (not base) if on else base
             elif spec == "feature_dgrad":
                 def setter(on, base=ConvBnReLU.hip_dgrad_auto):
                     ConvBnReLU.hip_dgrad_auto = (not base) if on else base
@@ -648,17 +706,20 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
+        summ2 = timer2.summary() if timer2 is not None else {}
         kernels = {}
         for key, (name, tag) in tagmap.items():
-            if (name, tag) in summ:
-                calls, ms = summ[(name, tag)]
+            if (name, tag) in summ or (name, tag) in summ2:
+                calls, ms = summ[(name, tag)] if (name, tag) in summ else summ2[(name, tag)]
                 bound, amount = work[key]
                 if bound == "hbm":
                     ach, peak, unit = amount / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
                 else:
                     ach, peak, unit = amount / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
                 kernels[key] = {"bound": bound, "ms": ms, "achieved": ach, "peak": peak, "unit": unit,
-                                "frac": ach / peak, "calls": calls}
+                                "frac": ach / peak, "calls": calls,
+                                "timed": "HIP events inside the timed region" if (name, tag) in summ
+                                else "HIP events, second pass of the same K steps after the timed region"}
         traffic, traffic_note = None, "not collected"
         if args.pmc and world == 1:    # tools/pmc_driver.py replays this config's tagged kernels at this config's shapes
             try:
@@ -685,7 +746,7 @@ def main():
             roof = {"kernel": dom, "hip_kernel": HIP_KERNEL_OF[dom], "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                     "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                     "traffic": kernels[dom].get("traffic"), "traffic_unit": "bytes of HBM traffic per launch", "traffic_source": traffic_note,
-                    "ms": kernels[dom]["ms"]}
+                    "ms": kernels[dom]["ms"], "timed": kernels[dom]["timed"]}
         metric = {2: "depth-samples/sec (N=3, 640x512, D=192)", 3: "depth-samples/sec (JDACS self-supervised step, N=5, 640x512, D=192)",
                   4: "depth-samples/sec (CVP-MVSNet 3-level inference, N=5, 1152x864, D=(48,8,8))",
                   5: "depth-samples/sec (MVSNet inference, N=7, 1600x1184, D=256)"}[args.config]
@@ -711,6 +772,21 @@ def main():
         }
         if ab:
             res["ab"] = ab
+        if host_trace is not None:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open("gpurun_out/host_trace.json", "w") as f:
+                json.dump({"marks": host_marks, "rows": host_trace.rows}, f)
+        if step_events:
+            res["step_gpu_ms"] = [round(a.elapsed_time(b), 3) for a, b in zip(step_events, step_events[1:])]
+            res["step_host_ms"] = [round((b - a) * 1e3, 3) for a, b in zip(host_marks, host_marks[1:])]
+            if train and join_trace:
+                # > 0: the side stream (weight gradients) finishes after the main stream's backward pass and the join waits for it
+                lag = sorted(em.elapsed_time(es) for em, es in join_trace)
+                res["side_stream_lag_at_join_ms_median_max"] = [round(lag[len(lag) // 2], 3), round(lag[-1], 3)]
+            if train:
+                res["step_host_fwd_bwd_rest_ms"] = [[round((phase_marks[2 * i] - host_marks[i]) * 1e3, 2),
+                                                      round((phase_marks[2 * i + 1] - phase_marks[2 * i]) * 1e3, 2),
+                                                      round((host_marks[i + 1] - phase_marks[2 * i + 1]) * 1e3, 2)] for i in range(args.steps)][:6]
         if not args.no_cpu_baseline and world == 1 and args.config == 2:   # rank 0 at N=1 only (bench contract)
             try:
                 res["cpu_baseline"] = cpu_baseline(state0, 1)

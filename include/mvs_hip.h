@@ -247,6 +247,16 @@ int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int 
                      int stride, hipStream_t stream);
 int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
                      int stride, hipStream_t stream);
+/* Weight gradients of up to 8 layers in ONE launch + one reduction launch (the training extractor's backward pass: replaces the
+ * weight half of the convolution_backward nodes autograd builds for jdacs/models/module.py:18 `self.conv` of every ConvBnReLU of
+ * jdacs/models/mvsnet.py:21-31 and for mvsnet.py:32 `self.feature`).  shapes[n][8] = N, H, W, Cin, Cout, ks, stride,
+ * w_channels_last; x[i] [N,H,W,Cin], gy[i] [N,Ho,Wo,Cout] (NHWC, pad ks/2); gw[i] is written as [Cout][Cin][ks][ks], or as
+ * [Cout][ks][ks][Cin] when w_channels_last (the memory of a channels_last nn.Conv2d weight).  Served layers: 3x3 stride 1 with
+ * 3 / 8 / 16 -> <= 16 or 32 -> <= 32 channels, 5x5 stride 2 with 8 -> <= 16 or 16 -> <= 32, Cout % 4 == 0.
+ * mvs_conv2d_wgrad_batch_workspace_floats: size of ws for these shapes, or -1 if a layer is not served. */
+long long mvs_conv2d_wgrad_batch_workspace_floats(int n, const int* shapes);
+int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws, const int* shapes,
+                           hipStream_t stream);
 
 /* ---- geometric-consistency filter on the path's depth maps ---------------------------------------------
  * Replaces reproject_with_depth + check_geometric_consistency (jdacs/eval.py:169-224) for ALL source views of one

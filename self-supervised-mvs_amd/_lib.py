@@ -59,6 +59,8 @@ SIGNATURES = {
     "mvs_conv2d_pack_weights_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), _s]),
     "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_wgrad_batch_workspace_floats": (_ll, [_i, C.POINTER(_i)]),
+    "mvs_conv2d_wgrad_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _f, C.POINTER(_i), _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),
     "mvs_depth_hypo": (_i, [_f, _f, _i, _i, _i, _f, _f, _s]),
     "mvs_geo_consistency": (_i, [_f, C.POINTER(C.c_void_p), _f, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _s]),
@@ -95,7 +97,7 @@ class MvsLib:
         training step that nobody reads).  tstream: the torch stream the kernel is enqueued on when that is not the current one
         (the HIP-event brackets of a KernelTimer go on that stream)."""
         prof = self.profiler
-        if prof is not None:
+        if prof is not None and (prof.names is None or name in prof.names):
             if not isinstance(tag, str):
                 tag = tag[0] % tuple(tag[1:])
             if prof.wants(name, tag):
@@ -144,8 +146,9 @@ class KernelTimer:
     """HIP-event timing of individual C-ABI calls on the stream they are launched on.
     ``only``: None = every call, or a set of call names / tags."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, names=None):
         self.only = only
+        self.names = names      # entry-point names worth looking at (None: all): calls of other names skip even the tag formatting
         self.events = {}
 
     def wants(self, name, tag):

@@ -453,6 +453,236 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_wide_kernel(const flo
     }
 }
 
+// ---- weight gradients of ALL layers of an extractor in one launch (round 4) ---------------------------------------------------
+// The per-layer kernel above (and the library's) pays a launch, a fill of the accumulation buffer and an under-filled GPU for every
+// one of FeatureNet's eight small layers: 0.40 ms of library kernels + 13 zero fills per config-2 step for 9.2 GFLOP / 0.25 GB
+// (profiles/r04_final_rocprofv3_kernel_stats_c2.csv: igemm_wrw_* + SubTensorOpWithScalar1d).  Here every layer is a range of
+// workgroups of ONE launch (the layers' activations and output gradients are all alive at the end of the extractor's backward
+// pass), followed by ONE reduction launch.  GEMM view per layer: M = (tap, ci) rows, N = co, K = output positions; a workgroup
+// owns `tpw` consecutive 32-wide position tiles, stages the input halo and the output-gradient tile in LDS (dense copies: the LDS
+// pixel stride IS the channel count, so a halo row is one contiguous run of global memory) with the next tile's loads in flight
+// during the MFMA loop; the four waves split the tile's POSITIONS (and, for the two widest layers, the rows in two halves), so a
+// k-step costs MTW + NB LDS reads for MTW * NB MFMAs; partial sums of the waves meet in LDS, one partial image per workgroup.
+struct Wg2Layer {
+    const float* x;      // [N,Hi,Wi,CX]
+    const float* g;      // [N,Ho,Wo,CG]
+    float* part;         // [nwg][ROWSP][CGP]
+    float* gw;           // [CG][CX][ks][ks], or [CG][ks][ks][CX] when wcl
+    int N, Hi, Wi, Ho, Wo, CX, CG;
+    int cfg, nth, ntw, ntiles, tpw;   // instantiation, tiles, tiles per workgroup
+    int wg0, nwg;                     // this layer's workgroups in the main launch
+    int rb0, nrb;                     // this layer's blocks in the reduction launch
+    int rowsp, cgp, nt, wcl;
+};
+constexpr int WG2_MAX_LAYERS = 8;
+struct Wg2Batch {
+    Wg2Layer l[WG2_MAX_LAYERS];
+    int n;
+};
+
+template <int KS_, int S_, int CX_, int NB_, int TH_, int MSPLIT_>
+struct Wg2Cfg {
+    static constexpr int KS = KS_, S = S_, CX = CX_, NB = NB_, TH = TH_, MSPLIT = MSPLIT_;
+    static constexpr int TW = 32, P = KS / 2, RH = (TH - 1) * S + KS, RW = (TW - 1) * S + KS, NT = KS * KS;
+    static constexpr int ROWS = NT * CX, MTT = (ROWS + 15) / 16, MTW = (MTT + MSPLIT - 1) / MSPLIT, KW = 4 / MSPLIT;
+    // LDS strides: a half-wave's A read covers 16 channels of 2 consecutive positions, its B read 16 output channels of 2
+    // positions -> a position stride of 32 floats would put both positions on the same banks: 48 there
+    static constexpr int NPOS = TH * TW, XP = CX == 32 ? 48 : CX, CGP = NB * 16, GP = NB == 2 ? 48 : 16;
+    static constexpr int XT = (RH * RW * XP + 3) / 4 * 4, GT = NPOS * GP, ROWSP = MTT * 16;
+    static constexpr int LDS = XT + GT > ROWSP * CGP ? XT + GT : ROWSP * CGP;
+    static constexpr int COST = (NPOS / 4) * MTT * NB + 96;    // MFMAs of a tile + its staging, in MFMA units (host: work split)
+};
+using Wg2A = Wg2Cfg<3, 1, 3, 1, 8, 1>;     // 3 -> <= 16   (27 rows)
+using Wg2B = Wg2Cfg<3, 1, 8, 1, 8, 1>;     // 8 -> <= 16
+using Wg2C = Wg2Cfg<5, 2, 8, 1, 4, 1>;     // 8 -> <= 16, 5x5 stride 2
+using Wg2D = Wg2Cfg<3, 1, 16, 1, 8, 1>;    // 16 -> <= 16
+using Wg2E = Wg2Cfg<5, 2, 16, 2, 4, 2>;    // 16 -> <= 32, 5x5 stride 2
+using Wg2F = Wg2Cfg<3, 1, 32, 2, 4, 2>;    // 32 -> <= 32
+constexpr int wg2_max(int a, int b) { return a > b ? a : b; }
+constexpr int WG2_LDS = wg2_max(wg2_max(wg2_max(Wg2A::LDS, Wg2B::LDS), wg2_max(Wg2C::LDS, Wg2D::LDS)), wg2_max(Wg2E::LDS, Wg2F::LDS));
+
+template <class C>
+__device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __restrict__ lds) {
+    constexpr int KS = C::KS, S = C::S, CX = C::CX, NB = C::NB, TW = C::TW, RW = C::RW, XP = C::XP, GP = C::GP, MTW = C::MTW;
+    constexpr bool VEC = CX % 4 == 0;
+    constexpr int CQ = VEC ? CX / 4 : 1;
+    constexpr int XN = VEC ? C::RH * RW * CQ : C::RH * RW * CX;     // staging items of the halo: float4 / float
+    constexpr int XIT = (XN + 255) / 256;
+    constexpr int GQ = C::CGP / 4, GN = C::NPOS * GQ, GIT = (GN + 255) / 256;
+    float* __restrict__ xt = lds;
+    float* __restrict__ gt = lds + C::XT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l15 = lane & 15;
+    const int mg = wave % C::MSPLIT, kg = wave / C::MSPLIT;
+    // this wave's m-tiles mg * MTW .. + MTW - 1; row -> (tap = row / CX, ci = row % CX); rows past the layer's read offset 0 and
+    // are never written out
+    int rowoff[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int row = 16 * (mg * MTW + m) + l15;
+        const bool ok = row < C::ROWS;
+        const int tap = ok ? row / CX : 0, ci = ok ? row % CX : 0;
+        rowoff[m] = ((tap / KS) * RW + tap % KS) * XP + ci;
+    }
+    f32x4 acc[MTW][NB];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xv[VEC ? XIT : 1];
+    float xs[VEC ? 1 : XIT];
+    float4 gv[GIT];
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int tw = t % L.ntw; t /= L.ntw;
+        const int th = t % L.nth;
+        const int n = t / L.nth;
+        const int oy0 = th * C::TH, ox0 = tw * TW, iy0 = oy0 * S - C::P, ix0 = ox0 * S - C::P;
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int i = tid + 256 * k;
+            if (VEC) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < XN) {
+                    const int px = i / CQ, cq = i % CQ, iy = iy0 + px / RW, ix = ix0 + px % RW;
+                    if (iy >= 0 && iy < L.Hi && ix >= 0 && ix < L.Wi)
+                        v = *reinterpret_cast<const float4*>(L.x + (((size_t)n * L.Hi + iy) * L.Wi + ix) * CX + 4 * cq);
+                }
+                xv[k] = v;
+            } else {
+                float v = 0.f;
+                if (i < XN) {
+                    const int ry = i / (RW * CX), rem = i % (RW * CX), iy = iy0 + ry, ix = ix0 + rem / CX;
+                    if (iy >= 0 && iy < L.Hi && ix >= 0 && ix < L.Wi) v = L.x[(((size_t)n * L.Hi + iy) * L.Wi + ix0) * CX + rem];
+                }
+                xs[k] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GIT; ++k) {
+            const int i = tid + 256 * k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < GN) {
+                const int p = i / GQ, c4 = 4 * (i % GQ), oy = oy0 + p / TW, ox = ox0 + p % TW;
+                if (c4 < L.CG && oy < L.Ho && ox < L.Wo)
+                    v = *reinterpret_cast<const float4*>(L.g + (((size_t)n * L.Ho + oy) * L.Wo + ox) * L.CG + c4);
+            }
+            gv[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < XIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < XN) {
+                if (VEC) *reinterpret_cast<float4*>(&xt[(i / CQ) * XP + 4 * (i % CQ)]) = xv[k];
+                else xt[i] = xs[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < GN) *reinterpret_cast<float4*>(&gt[(i / GQ) * GP + 4 * (i % GQ)]) = gv[k];
+        }
+    };
+    const int t0 = wgl * L.tpw, t1 = t0 + L.tpw < L.ntiles ? t0 + L.tpw : L.ntiles;
+    if (t0 < t1) load_tile(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();            // the previous tile's MFMA loop has read the LDS images
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);     // in flight during the MFMA loop
+#pragma unroll 2
+        for (int ks = kg; ks < C::NPOS / 4; ks += C::KW) {
+            const int p = 4 * ks + kq;
+            const int posoff = ((p / TW) * S * RW + (p % TW) * S) * XP;
+            float bv[NB], av[MTW];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = gt[p * GP + nb * 16 + l15];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) av[m] = xt[posoff + rowoff[m]];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[m][nb] = MVS_MFMA_16x16x4(av[m], bv[nb], acc[m][nb]);
+        }
+    }
+    // the waves' partial sums meet in LDS (k-group after k-group: fixed order), then one coalesced partial image per workgroup
+    // D: column = lane & 15 (co), row = 4 (lane >> 4) + r of the m-tile
+    float* __restrict__ red = lds;
+    for (int k = 0; k < C::KW; ++k) {
+        __syncthreads();
+        if (kg == k) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int mt = mg * MTW + m;
+                if (mt >= C::MTT) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* __restrict__ d = &red[(16 * mt + 4 * kq + r) * C::CGP + nb * 16 + l15];
+                        *d = k == 0 ? acc[m][nb][r] : *d + acc[m][nb][r];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    float4* __restrict__ out = reinterpret_cast<float4*>(L.part + (size_t)wgl * C::ROWSP * C::CGP);
+    for (int i = tid; i < C::ROWSP * C::CGP / 4; i += 256) out[i] = reinterpret_cast<const float4*>(red)[i];
+}
+
+__global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
+    __shared__ __attribute__((aligned(16))) float lds[WG2_LDS];
+    int li = 0;
+    while (li + 1 < b.n && (int)blockIdx.x >= b.l[li].wg0 + b.l[li].nwg) ++li;
+    const Wg2Layer& L = b.l[li];
+    const int wgl = blockIdx.x - L.wg0;
+    switch (L.cfg) {
+        case 0: wg2_body<Wg2A>(L, wgl, lds); break;
+        case 1: wg2_body<Wg2B>(L, wgl, lds); break;
+        case 2: wg2_body<Wg2C>(L, wgl, lds); break;
+        case 3: wg2_body<Wg2D>(L, wgl, lds); break;
+        case 4: wg2_body<Wg2E>(L, wgl, lds); break;
+        default: wg2_body<Wg2F>(L, wgl, lds); break;
+    }
+}
+
+// gw = sum over the layer's partial images, fixed order: a workgroup owns 16 consecutive elements of the partial-image layout, its
+// 16 x 16 threads = (element, slice) walk the images slice, slice + 16, ... (as conv2d_wgrad_reduce_wide_kernel), all layers in
+// one launch
+__global__ __launch_bounds__(256) void conv2d_wgrad_batch_reduce_kernel(Wg2Batch b) {
+    __shared__ float red[16][17];
+    int li = 0;
+    while (li + 1 < b.n && (int)blockIdx.x >= b.l[li].rb0 + b.l[li].nrb) ++li;
+    const Wg2Layer& L = b.l[li];
+    const int n = L.rowsp * L.cgp;
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - L.rb0) * 16 + el;
+    const size_t stride = (size_t)n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        const float* __restrict__ part = L.part;
+        int p = slice;
+        for (; p + 48 < L.nwg; p += 64) {
+            const float a0 = part[(size_t)p * stride + e], a1 = part[(size_t)(p + 16) * stride + e];
+            const float a2 = part[(size_t)(p + 32) * stride + e], a3 = part[(size_t)(p + 48) * stride + e];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; p < L.nwg; p += 16) s0 += part[(size_t)p * stride + e];
+    }
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && e < n) {
+        const int co = e % L.cgp, row = e / L.cgp, ci = row % L.CX, tap = row / L.CX;
+        if (co < L.CG && tap < L.nt) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][el];
+            L.gw[L.wcl ? ((size_t)co * L.nt + tap) * L.CX + ci : ((size_t)co * L.CX + ci) * L.nt + tap] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -701,4 +931,88 @@ extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, floa
                            nb * 16, gw, Cin, ci0, co0);
         }
     return mvs_check_launch("conv2d_wgrad_reduce");
+}
+
+// ---- all layers' weight gradients in one launch -------------------------------------------------------------------------------
+int g_conv2d_wgrad_batch_groups = 1024;   // tuning knob "wgrad2d_batch": workgroups of the batched weight gradient, shared out by work
+
+struct Wg2Static { int ks, stride, cx, cgmax, th, rowsp, cgp, cost; };
+template <class C>
+static Wg2Static wg2_static() { return {C::KS, C::S, C::CX, C::CGP, C::TH, C::ROWSP, C::CGP, C::COST}; }
+static const Wg2Static* wg2_table() {
+    static const Wg2Static t[6] = {wg2_static<Wg2A>(), wg2_static<Wg2B>(), wg2_static<Wg2C>(), wg2_static<Wg2D>(), wg2_static<Wg2E>(),
+                                   wg2_static<Wg2F>()};
+    return t;
+}
+// shapes[n][8] = N, H, W, Cin, Cout, ks, stride, w_channels_last.  Fills everything of the batch except the pointers; -> workspace
+// floats, or -1 when a layer has no instantiation (3x3 stride 1 with 3 / 8 / 16 -> <= 16 or 32 -> <= 32 channels, 5x5 stride 2
+// with 8 -> <= 16 or 16 -> <= 32; output channels a multiple of 4)
+static long long wg2_plan(int n, const int* shapes, Wg2Batch& b) {
+    if (n < 1 || n > WG2_MAX_LAYERS || !shapes) return -1;
+    const Wg2Static* tab = wg2_table();
+    double cost[WG2_MAX_LAYERS], total = 0.0;
+    b.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int* s = shapes + 8 * i;
+        Wg2Layer& L = b.l[i];
+        L = Wg2Layer{};
+        L.N = s[0]; L.Hi = s[1]; L.Wi = s[2]; L.CX = s[3]; L.CG = s[4];
+        const int ks = s[5], stride = s[6];
+        L.wcl = s[7] ? 1 : 0;
+        if (L.N < 1 || L.Hi < 1 || L.Wi < 1 || (L.CG & 3) || L.CG < 4) return -1;
+        if ((long long)L.N * L.Hi * L.Wi * (L.CX > L.CG ? L.CX : L.CG) >= (1LL << 31)) return -1;
+        L.cfg = -1;
+        for (int c = 0; c < 6; ++c)
+            if (tab[c].ks == ks && tab[c].stride == stride && tab[c].cx == L.CX && L.CG <= tab[c].cgmax) { L.cfg = c; break; }
+        if (L.cfg < 0) return -1;
+        const Wg2Static& T = tab[L.cfg];
+        L.Ho = stride == 1 ? L.Hi : (L.Hi - 1) / 2 + 1; L.Wo = stride == 1 ? L.Wi : (L.Wi - 1) / 2 + 1;
+        L.nth = mvs_cdiv(L.Ho, T.th); L.ntw = mvs_cdiv(L.Wo, 32); L.ntiles = L.N * L.nth * L.ntw;
+        L.rowsp = T.rowsp; L.cgp = T.cgp; L.nt = ks * ks;
+        cost[i] = (double)L.ntiles * T.cost;
+        total += cost[i];
+    }
+    const int budget = g_conv2d_wgrad_batch_groups < n ? n : (g_conv2d_wgrad_batch_groups > 4096 ? 4096 : g_conv2d_wgrad_batch_groups);
+    long long floats = 0;
+    int wg = 0, rb = 0;
+    for (int i = 0; i < n; ++i) {
+        Wg2Layer& L = b.l[i];
+        int want = (int)(budget * cost[i] / total + 0.5);
+        if (want < 1) want = 1;
+        if (want > L.ntiles) want = L.ntiles;
+        L.tpw = mvs_cdiv(L.ntiles, want);
+        L.nwg = mvs_cdiv(L.ntiles, L.tpw);
+        L.wg0 = wg; wg += L.nwg;
+        L.nrb = mvs_cdiv(L.rowsp * L.cgp, 16);
+        L.rb0 = rb; rb += L.nrb;
+        floats += (long long)L.nwg * L.rowsp * L.cgp;
+    }
+    return floats;
+}
+
+extern "C" long long mvs_conv2d_wgrad_batch_workspace_floats(int n, const int* shapes) {
+    Wg2Batch b;
+    return wg2_plan(n, shapes, b);
+}
+
+// gw[i] = weight gradient of layer i (x[i] [N,H,W,Cin], gy[i] [N,Ho,Wo,Cout], pad ks/2), written in the layout shapes[i][7] names
+extern "C" int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws,
+                                      const int* shapes, hipStream_t stream) {
+    MVS_REQUIRE(x && gy && gw && ws && shapes, MVS_ERR_NULL, "conv2d_wgrad_batch: null pointer argument");
+    Wg2Batch b;
+    const long long floats = wg2_plan(n, shapes, b);
+    MVS_REQUIRE(floats >= 0, MVS_ERR_UNSUPPORTED, "conv2d_wgrad_batch: %d layers, or a layer shape without an instantiation", n);
+    float* part = ws;
+    for (int i = 0; i < n; ++i) {
+        MVS_REQUIRE(x[i] && gy[i] && gw[i], MVS_ERR_NULL, "conv2d_wgrad_batch: null pointer for layer %d", i);
+        Wg2Layer& L = b.l[i];
+        L.x = x[i]; L.g = gy[i]; L.gw = gw[i]; L.part = part;
+        part += (size_t)L.nwg * L.rowsp * L.cgp;
+    }
+    const Wg2Layer& last = b.l[n - 1];
+    MVS_LAUNCH(conv2d_wgrad_batch_kernel, dim3(last.wg0 + last.nwg), dim3(256), 0, stream, b);
+    int rc = mvs_check_launch("conv2d_wgrad_batch");
+    if (rc) return rc;
+    MVS_LAUNCH(conv2d_wgrad_batch_reduce_kernel, dim3(last.rb0 + last.nrb), dim3(256), 0, stream, b);
+    return mvs_check_launch("conv2d_wgrad_batch_reduce");
 }

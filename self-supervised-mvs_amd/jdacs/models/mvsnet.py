@@ -4,12 +4,14 @@
 Hot path (HIP): plane-sweep variance volume (mvsnet.py:120-136 + module.py:105-140), CostRegNet
 (mvsnet.py:37-74), softmax + depth regression + confidence (mvsnet.py:141-151).
 FeatureNet / RefineNet are 2-D CNNs outside the path and stay stock PyTorch (MIOpen)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...nn3d import batched_bn_counters
+from ...nn3d import batched_bn_counters, count_batch
 from .module import ALIGN_CORNERS, ConvBnReLU, ConvBnReLU3D, DeconvBnReLU3D, ProbConv3d, conv2d_maybe_hip, hip_conv2d_serves
 
 
@@ -25,6 +27,8 @@ _REG_DECODER = (("conv7", 64, 32, "conv4"), ("conv9", 32, 16, "conv2"), ("conv11
 class FeatureNet(nn.Module):
     """mvsnet.py:17-34 -- 2-D CNN, 3 -> 32 channels at 1/4 resolution (stock PyTorch convolutions)."""
 
+    one_node = os.environ.get("MVS_FEATURE_ONE_NODE", "1") != "0"   # training: the extractor as one autograd node (ops.FeatureExtractorFn)
+
     def __init__(self):
         super().__init__()
         self.inplanes = 32
@@ -37,6 +41,16 @@ class FeatureNet(nn.Module):
         blocks = [getattr(self, name) for name, *_ in _FEATURE_LAYERS]
         packed = [None] * len(blocks)
         if blocks[0].hip_train_forward_serves(x) and all(hip_conv2d_serves(m.conv, x) for m in blocks):
+            if self.one_node and not ConvBnReLU.split_bwd and not ConvBnReLU.hip_wgrad and self.feature.bias is not None:
+                # the whole extractor as ONE autograd node (ops.FeatureExtractorFn): same kernels, a third of the host work
+                cfg, params = [], []
+                for m in blocks:
+                    for _ in range(groups):
+                        count_batch(m.bn, True)
+                    cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
+                    params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+                params += [self.feature.weight, self.feature.bias]
+                return ops.FeatureExtractorFn.apply(x, groups, tuple(cfg), *params)
             # training through csrc/conv2d.hip: the weight images of all blocks in ONE launch (channels-last parameters read as they are)
             packed = ops.pack_conv2d_weights([m.conv.weight for m in blocks], [m.conv.stride[0] for m in blocks], x)
         for m, ws in zip(blocks, packed):

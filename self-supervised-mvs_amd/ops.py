@@ -513,8 +513,16 @@ def _side_stream(dev):
     return pool[k]
 
 
+JOIN_TRACE = None        # diagnostics (bench.py --step-events): a list -> (main-stream event, side-stream event) recorded right before each join
+
+
 def _join_side(main, idx) -> None:
     for sd in _SIDE_STREAMS.get(idx, ()):
+        if JOIN_TRACE is not None:
+            em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            em.record(main)
+            es.record(sd)
+            JOIN_TRACE.append((em, es))
         main.wait_stream(sd)
 _WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses whose backward node has not run yet}
 _WEIGHT_MULTI = {}      # device index -> {weight data_ptr} that had > 1 outstanding use at some point (until all of them have run)
@@ -964,6 +972,98 @@ def _maybe_on_side_stream(fn, weight, inputs):
     return out
 
 
+# training extractor (FeatureExtractorFn): all layers' weight gradients through csrc/conv2d.hip's one-launch kernel (MVS_FEATURE_WGRAD_BATCH=0:
+# the library's per-layer weight gradients)
+FEATURE_WGRAD_BATCH = os.environ.get("MVS_FEATURE_WGRAD_BATCH", "1") != "0"
+
+
+class FeatureExtractorFn(torch.autograd.Function):
+    """A chain of 2-D ConvBnReLU blocks closed by a plain convolution with bias -- FeatureNet (jdacs/models/mvsnet.py:17-34) -- in
+    TRAINING as ONE autograd node: the same kernels in the same order as the per-block graph (conv2d.hip forward with BatchNorm's
+    statistics in its epilogue, apply pass; backward: reduce + apply, csrc/conv2d.hip or the library's input gradient per
+    ``cfg``, the library's weight gradient), without 14 Function.apply round trips forward and 15 autograd nodes backward on the
+    launch thread (the host enqueues a config-2 step in ~4 ms against ~5.4 ms of GPU time: the headroom is what keeps the step
+    GPU-bound on a slower host).
+
+    ``cfg``: per block (stride, padding, eps, momentum, hip_dgrad).  ``params``: per block conv weight, gamma, beta, running_mean,
+    running_var; then the closing convolution's weight and bias.  ``groups`` equal chunks of the batch keep their own BatchNorm
+    statistics (the views of a sample: mvsnet.py:115 calls the extractor once per view)."""
+
+    @staticmethod
+    def forward(ctx, x, groups, cfg, *params):
+        lib = _lib_for(x)
+        n = len(cfg)
+        x = as_cl2(x)
+        ws_, gammas, betas = [params[5 * i] for i in range(n)], [params[5 * i + 1] for i in range(n)], [params[5 * i + 2] for i in range(n)]
+        fw, fb = params[5 * n], params[5 * n + 1]
+        packed = pack_conv2d_weights(ws_, [c[0] for c in cfg], x)
+        acts, raws, statss, slots_b = [x], [], [], []
+        for i, (stride, padding, eps, momentum, hip_dgrad) in enumerate(cfg):
+            raw, slots = conv2d_forward(acts[-1], ws_[i], None, stride, want_stats=True, groups=groups, packed_ws=packed[i])
+            c = raw.shape[1]
+            (sb,) = stat_slots(x, groups, bn_nslots(lib, c), c, 1)
+            y, stats = bn_relu_fwd_slots(raw, slots, gammas[i], betas[i], params[5 * i + 3], params[5 * i + 4], eps, momentum, None, True, groups)
+            acts.append(y)
+            raws.append(raw)
+            statss.append(stats)
+            slots_b.append(sb)
+        out = torch.ops.aten.convolution(acts[-1], fw, fb, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        ctx.cfg, ctx.groups, ctx.slots_used = cfg, groups, False
+        ctx.save_for_backward(fw, *ws_, *acts, *raws, *statss, *slots_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cfg, groups = ctx.cfg, ctx.groups
+        n = len(cfg)
+        sv = ctx.saved_tensors
+        fw, ws_ = sv[0], sv[1:1 + n]
+        acts = sv[1 + n:2 + 2 * n]
+        raws, statss, slots_b = sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n], sv[2 + 4 * n:2 + 5 * n]
+        if ctx.slots_used:
+            slots_b = [torch.zeros_like(t) for t in slots_b]
+        ctx.slots_used = True
+        need = ctx.needs_input_grad              # [x, groups, cfg, *params]
+        bwd = torch.ops.aten.convolution_backward
+        grads = [None] * (5 * n + 2)
+        gout = as_cl2(gout)
+        # weight gradients: all eight layers in ONE launch at the end (csrc/conv2d.hip conv2d_wgrad_batch_kernel; every layer's
+        # input and output gradient is alive until then), unless a layer has no instantiation / FEATURE_WGRAD_BATCH is off ->
+        # the library's, layer by layer
+        batch = (FEATURE_WGRAD_BATCH and all(need[3 + 5 * i] for i in range(n + 1)) and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))
+                 and conv2d_wgrad_batch_serves(list(acts), list(ws_) + [fw], [c[0] for c in cfg] + [1]))
+        draws = [None] * n
+        if batch:
+            g = bwd(gout, acts[n], fw, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if need[3 + 5 * n + 1]:
+                grads[5 * n + 1] = gout.sum((0, 2, 3))
+        else:
+            g, gfw, gfb = bwd(gout, acts[n], fw, [fw.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                              [True, bool(need[3 + 5 * n]), bool(need[3 + 5 * n + 1])])
+            grads[5 * n], grads[5 * n + 1] = gfw, gfb
+        for i in range(n - 1, -1, -1):
+            stride, padding, eps, momentum, hip_dgrad = cfg[i]
+            draw, grads[5 * i + 1], grads[5 * i + 2] = bn_relu_bwd_slots(g, raws[i], statss[i], slots_b[i], False, True, groups)
+            draws[i] = draw
+            w = ws_[i]
+            want_x = i > 0 or need[0]
+            if want_x and hip_dgrad:
+                g = conv2d_dgrad(draw, w, tuple(acts[i].shape), stride)
+                want_x = False
+            want_w = bool(need[3 + 5 * i]) and not batch
+            if want_x or want_w:
+                gx, gw, _ = bwd(draw, acts[i], w, None, [stride, stride], [padding, padding], [1, 1], False, [0, 0], 1,
+                                [bool(want_x), want_w, False])
+                if want_x:
+                    g = gx
+                grads[5 * i] = gw
+        if batch:
+            gws = conv2d_wgrad_batch(list(acts), draws + [gout], list(ws_) + [fw], [c[0] for c in cfg] + [1])
+            for i in range(n + 1):
+                grads[5 * i] = gws[i]
+        return (g if need[0] else None, None, None) + tuple(grads)
+
+
 class BnReLUFn(torch.autograd.Function):
     """BatchNorm (+ReLU) over the channel dim of a channels-last tensor [B,C,H,W] / [B,C,D,H,W] with the same
     HIP kernels as the 3-D regulariser (statistic slots -> ONE apply pass that finishes them in its prologue; backward: one
@@ -1239,6 +1339,60 @@ def pack_conv2d_weights(weights, strides, like):
     lib.call("mvs_conv2d_pack_weights_batch", n, _ptr_array(ptrs), _ptr_array(views), (C.c_int * (4 * n))(*shapes),
              (C.c_int * n)(*wcl), _stream(like))
     return views
+
+
+def _wgrad_batch_shapes(xs, weights, strides):
+    shapes = []
+    for x, wt, st in zip(xs, weights, strides):
+        n, cin, h, w = x.shape
+        cout, cin_w, ks, ks2 = wt.shape
+        if cin_w != cin or ks != ks2:
+            raise ValueError("weight shape %s does not match %d input channels" % (tuple(wt.shape), cin))
+        if wt.is_contiguous():
+            wcl = 0
+        elif wt.is_contiguous(memory_format=CL2):
+            wcl = 1
+        else:
+            return None
+        shapes += [n, h, w, cin, cout, ks, st, wcl]
+    return shapes
+
+
+_WGRAD_BATCH_PLANS = {}
+
+
+def conv2d_wgrad_batch_serves(xs, weights, strides) -> bool:
+    """csrc/conv2d.hip's one-launch weight gradient has an instantiation for every one of these layers (<= 8 of them)"""
+    if not (0 < len(xs) <= 8):
+        return False
+    shapes = _wgrad_batch_shapes(xs, weights, strides)
+    if shapes is None:
+        return False
+    return _wgrad_batch_plan(_lib_for(xs[0]), tuple(shapes))[0] >= 0
+
+
+def _wgrad_batch_plan(lib, key):
+    ent = _WGRAD_BATCH_PLANS.get((id(lib), key))
+    if ent is None:
+        arr = (C.c_int * len(key))(*key)
+        ent = _WGRAD_BATCH_PLANS[(id(lib), key)] = (int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", len(key) // 8, arr)), arr)
+    return ent
+
+
+def conv2d_wgrad_batch(xs, gys, weights, strides):
+    """Weight gradients of several Conv2d layers (x_i channels-last [N,Cin,H,W], gy_i channels-last [N,Cout,Ho,Wo], pad k//2) in
+    ONE launch + one reduction launch; -> gradients with the shape AND memory layout of `weights` (contiguous or channels-last
+    parameters alike, so autograd's AccumulateGrad takes them over without a copy)."""
+    lib = _lib_for(xs[0])
+    xs, gys = [as_cl2(t) for t in xs], [as_cl2(t) for t in gys]
+    shapes = _wgrad_batch_shapes(xs, weights, strides)
+    nfl, arr = _wgrad_batch_plan(lib, tuple(shapes)) if shapes is not None else (-1, None)
+    if nfl < 0:
+        raise ValueError("conv2d_wgrad_batch: a layer of %s is not served" % ([tuple(w.shape) for w in weights],))
+    ws = torch.empty(nfl, dtype=torch.float32, device=xs[0].device)
+    gws = [torch.empty_like(w) for w in weights]       # preserve_format: the parameter's strides
+    lib.call("mvs_conv2d_wgrad_batch", len(xs), _ptr_array(xs), _ptr_array(gys), _ptr_array(gws), _p(ws), arr, _stream(xs[0]))
+    return gws
 
 
 def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1, packed_ws=None):

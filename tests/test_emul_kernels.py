@@ -1332,6 +1332,43 @@ def test_conv2d_wgrad_wide_reduction(emul_lib, cin, cout, ks, stride, hw):
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
 
 
+WGRAD_BATCH_LAYERS = [  # (Cin, Cout, ks, stride, weight channels-last): the six instantiations of conv2d_wgrad_batch_kernel
+    (3, 8, 3, 1, False), (8, 8, 3, 1, True), (8, 16, 5, 2, False), (16, 16, 3, 1, True), (16, 32, 5, 2, True), (32, 32, 3, 1, False)]
+
+
+@pytest.mark.parametrize("budget,hw", [(6, (9, 70)), (40, (13, 37))])
+def test_conv2d_weight_gradients_of_all_layers_in_one_launch(emul_lib, budget, hw):
+    """mvs_conv2d_wgrad_batch: FeatureNet's layer shapes (jdacs/models/mvsnet.py:21-32) as ONE launch + one reduction launch vs
+    ATen's weight gradients; ragged tiles in both directions, two images, several tiles per workgroup (budget 6: one workgroup per
+    layer walks all its tiles) and one tile per workgroup, contiguous and channels-last parameter layouts."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(budget)
+    xs, gys, ws, refs, strides = [], [], [], [], []
+    for cin, cout, ks, stride, wcl in WGRAD_BATCH_LAYERS:
+        x = torch.randn(2, cin, *hw, generator=g).contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(cout, cin, ks, ks, requires_grad=True)
+        y = F.conv2d(x, w, stride=stride, padding=ks // 2)
+        gy = torch.randn(y.shape, generator=g).contiguous(memory_format=torch.channels_last)
+        y.backward(gy)
+        xs.append(x); gys.append(gy); refs.append(w.grad); strides.append(stride)
+        ws.append(w.detach().contiguous(memory_format=torch.channels_last) if wcl else w.detach())
+    assert ops.conv2d_wgrad_batch_serves(xs, ws, strides)
+    emul_lib.call("mvs_set_tuning", b"wgrad2d_batch", budget)
+    ops._WGRAD_BATCH_PLANS.clear()
+    try:
+        gws = ops.conv2d_wgrad_batch(xs, gys, ws, strides)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"wgrad2d_batch", 1024)
+        ops._WGRAD_BATCH_PLANS.clear()
+    for gw, ref, w, cfg in zip(gws, refs, ws, WGRAD_BATCH_LAYERS):
+        assert gw.shape == ref.shape and gw.stride() == w.stride(), cfg
+        assert float((gw - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max())), cfg
+    # a layer without an instantiation is reported, not computed
+    assert not ops.conv2d_wgrad_batch_serves([torch.zeros(1, 12, 8, 8)], [torch.zeros(8, 12, 3, 3)], [1])
+    with pytest.raises(ValueError):
+        ops.conv2d_wgrad_batch([torch.zeros(1, 12, 8, 8)], [torch.zeros(1, 8, 8, 8)], [torch.zeros(8, 12, 3, 3)], [1])
+
+
 @pytest.mark.parametrize("dims,xcd", [((4, 4, 18), 1), ((5, 6, 16), 0), ((3, 9, 33), 1)])
 def test_conv_cout8_weight_gradient_two_chunks_per_workgroup(emul_lib, dims, xcd):
     """Knob wgrad8_nch = 2 (conv0, mvsnet.py:40: 32 -> 8): one workgroup stages the X halo of BOTH 16-channel chunks and the output

@@ -1063,6 +1063,70 @@ def test_featurenet_training_hip_forward_with_fused_statistics(dev):
     assert not bad and not badbuf, (bad, badbuf)
 
 
+def test_conv2d_weight_gradients_one_launch_at_featurenet_size(dev):
+    """mvs_conv2d_wgrad_batch at BASELINE config 2's FeatureNet shapes (3 views of 512x640, mvsnet.py:21-32): all eight weight
+    gradients from ONE launch + one reduction vs ATen's convolution_backward, parameters channels-last (as bench.py holds them) and
+    contiguous; fp32 sums over up to 983 040 positions -> relative L1 1e-4."""
+    from mvs_amd import ops
+    layers = ((3, 8, 3, 1, 512, 640), (8, 8, 3, 1, 512, 640), (8, 16, 5, 2, 512, 640), (16, 16, 3, 1, 256, 320), (16, 16, 3, 1, 256, 320),
+              (16, 32, 5, 2, 256, 320), (32, 32, 3, 1, 128, 160), (32, 32, 3, 1, 128, 160))
+    g = torch.Generator().manual_seed(21)
+    xs, gys, ws, sts, refs = [], [], [], [], []
+    bwd = torch.ops.aten.convolution_backward
+    for i, (cin, cout, ks, st, h, w) in enumerate(layers):
+        x = torch.randn(3, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(cout, cin, ks, ks, generator=g) * 0.1).to(dev)
+        if i % 2 == 0:
+            wt = wt.contiguous(memory_format=torch.channels_last)
+        ho, wo = (h, w) if st == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
+        gy = torch.randn(3, cout, ho, wo, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        refs.append(bwd(gy, x, wt, None, [st, st], [ks // 2, ks // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+        xs.append(x); gys.append(gy); ws.append(wt); sts.append(st)
+    assert ops.conv2d_wgrad_batch_serves(xs, ws, sts)
+    gws = ops.conv2d_wgrad_batch(xs, gys, ws, sts)
+    torch.cuda.synchronize()
+    for gw, ref, wt, cfg in zip(gws, refs, ws, layers):
+        assert gw.stride() == wt.stride(), cfg
+        assert rel_l1(gw, ref) < 1e-4, (cfg, rel_l1(gw, ref))
+
+
+def test_featurenet_training_one_autograd_node_equals_per_block_graph(dev):
+    """ops.FeatureExtractorFn (the training extractor as one autograd node, FeatureNet.one_node) launches the same kernels as the
+    per-block graph of Conv2dSplitBwdFn / BnReLUFn nodes: outputs, every parameter gradient, running statistics and
+    num_batches_tracked agree (statistics are summed with atomics -> not bit-identical), two steps in a row, 3 views 64x96; the
+    input gradient too."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(14)
+    a = FeatureNet().to(dev).train()
+    b = copy.deepcopy(a).train()
+    xa = torch.randn(3, 3, 64, 96, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = xa.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    old, old_async, old_fused = FeatureNet.one_node, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
+    try:
+        ops.set_async_wgrad(False)
+        for step in range(2):
+            FeatureNet.one_node = True
+            ya = a(xa, 3)
+            assert type(ya.grad_fn).__name__.startswith("FeatureExtractorFn"), type(ya.grad_fn).__name__
+            ya.square().mean().backward()
+            FeatureNet.one_node = False
+            yb = b(xb, 3)
+            assert not type(yb.grad_fn).__name__.startswith("FeatureExtractorFn")
+            yb.square().mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        FeatureNet.one_node = old
+        ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED = old_async, old_fused
+    assert float((ya - yb).abs().max()) < 1e-5 * max(1.0, float(yb.abs().max()))
+    assert rel_l1(xa.grad, xb.grad) < 1e-4
+    bad = {k: rel_l1(p.grad, q.grad) for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()) if not rel_l1(p.grad, q.grad) < 1e-4}
+    badbuf = [k for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers())
+              if not (torch.allclose(u, v, rtol=1e-5, atol=1e-6) if u.dtype.is_floating_point else bool((u == v).all()))]
+    assert not bad and not badbuf, (bad, badbuf)
+
+
 def test_featurenet_eval_folded_batchnorm_vs_stock(dev):
     """Inference FeatureNet (eval mode, no_grad): BatchNorm folded into the csrc/conv2d.hip convolutions (ConvBnReLU.fold_eval,
     the default) vs the unfolded path (MIOpen convolution + BatchNorm kernel) and vs the oracle's stock modules, 3 views 128x160

@@ -42,6 +42,7 @@ def main():
     bwd = torch.ops.aten.convolution_backward
     print("%-8s %-14s %10s %10s   (ms, median of %d)" % ("layer", "pass", "conv2d.hip", "library", args.reps))
     tot = {}
+    keep = []
     for name, cin, cout, ks, st, h, w in LAYERS:
         x = torch.randn(3, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(cout, cin, ks, ks, generator=g) * 0.1).to(dev)
@@ -49,6 +50,7 @@ def main():
         pad = ks // 2
         y = torch.ops.aten.convolution(x, wcl, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
         gy = torch.randn_like(y)
+        keep.append((name, x, gy, wcl, st))
         with torch.no_grad():
             rows = [("forward", lambda: ops.conv2d_forward(x, wt, None, st),
                      lambda: torch.ops.aten.convolution(x, wcl, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1))]
@@ -65,6 +67,18 @@ def main():
                 print("%-8s %-14s %10.4f %10.4f   %d>%d k%d s%d %dx%d" % (name, what, a, b, cin, cout, ks, st, h, w), flush=True)
     for what, (a, b) in tot.items():
         print("%-8s %-14s %10.4f %10.4f" % ("TOTAL", what, a, b))
+    # all eight weight gradients as ONE launch + one reduction (ops.conv2d_wgrad_batch), whole batch and layer by layer
+    xs, gys, ws, sts = [k[1] for k in keep], [k[2] for k in keep], [k[3] for k in keep], [k[4] for k in keep]
+    with torch.no_grad():
+        for budget in (512, 768, 1024, 1536, 2048):
+            ops._lib_for(xs[0]).call("mvs_set_tuning", b"wgrad2d_batch", budget)
+            ops._WGRAD_BATCH_PLANS.clear()
+            print("BATCH    weight grad    %10.4f   (8 layers, one launch + one reduction, %d workgroups)"
+                  % (timeit(lambda: ops.conv2d_wgrad_batch(xs, gys, ws, sts), args.reps), budget), flush=True)
+        ops._lib_for(xs[0]).call("mvs_set_tuning", b"wgrad2d_batch", 1024)
+        ops._WGRAD_BATCH_PLANS.clear()
+        for i, k in enumerate(keep):
+            print("%-8s batch-of-one   %10.4f" % (k[0], timeit(lambda: ops.conv2d_wgrad_batch(xs[i:i + 1], gys[i:i + 1], ws[i:i + 1], sts[i:i + 1]), args.reps)), flush=True)
 
 
 if __name__ == "__main__":
