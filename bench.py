@@ -326,7 +326,7 @@ def main():
                     help="after the timed region: cProfile of --steps more steps on the launch thread, top entries written to this file")
     ap.add_argument("--wgrad-streams", type=int, default=1,
                     help="side streams the regulariser's weight gradients are dealt to round-robin (ops.set_wgrad_streams)")
-    ap.add_argument("--side-priority", type=str, default="default", choices=["default", "low"],
+    ap.add_argument("--side-priority", type=str, default="default", choices=["default", "low", "high"],
                     help="priority of the weight-gradient side stream (ops.set_side_stream_priority)")
     ap.add_argument("--defer-join", type=int, default=1,
                     help="1: join the regulariser's side-stream weight gradients at the end of the backward pass (this loop has no "
@@ -525,8 +525,19 @@ def main():
             step = eager_step
             torch.cuda.synchronize()
     roctx = _ROCTX   # rocprofv3 --selected-regions: collect the timed region only (no MIOpen find noise)
+    # the cyclic garbage collector is kept out of the timed steps (an autograd step allocates ~10^4 Python objects; a generation-2
+    # collection landing inside a step stalls the launch thread for 5-10 ms -- profiles/r04_run11: one 11.7 ms step among 4.0 ms ones);
+    # one collection here, automatic collection back on after the region.  Reference counting frees everything as usual.
+    # BEFORE the warm-up steps, not between them and the timed region: a full collection takes the launch thread tens of
+    # milliseconds, the GPU drains and idles meanwhile, and the first timed steps then run at ramping clocks on an empty queue
+    # (profiles/r04_run16: 7.4 / 5.65 / 5.45 / 5.32 ms for the first four timed steps against 5.26 in steady state).
+    import gc
+    gc.collect()
+    gc.disable()
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    t_warm = time.perf_counter() - t_warm
     # live HIP-event timing of the roofline kernels over the timed region, on the launch stream
     work, tagmap = algorithmic_work(args.config)
     dom_key = DOMINANT.get(args.config) if (args.region_timers == "dominant" and DOMINANT.get(args.config) in tagmap) else None
@@ -545,13 +556,9 @@ def main():
                 self.rows.append((time.perf_counter(), name, tag))
                 return False
         host_trace = lib.profiler = HostTrace()
-    # the cyclic garbage collector is kept out of the timed steps (an autograd step allocates ~10^4 Python objects; a generation-2
-    # collection landing inside a step stalls the launch thread for 5-10 ms -- profiles/r04_run11: one 11.7 ms step among 4.0 ms ones);
-    # one collection before the region, automatic collection back on after it.  Reference counting frees everything as usual.
-    import gc
-    gc.collect()
-    gc.disable()
+    t_gap = time.perf_counter()
     barrier()
+    t_gap = time.perf_counter() - t_gap
     if roctx is not None:
         roctx.roctxProfilerResume(0)
     t0 = time.perf_counter()
@@ -650,6 +657,9 @@ def main():
                 def setter(on, base=args.side_priority):
                     other = "default" if base == "low" else "low"
                     _ops.set_side_stream_priority(other if on else base)
+            elif spec == "side_high":
+                def setter(on, base=args.side_priority):
+                    _ops.set_side_stream_priority("high" if on else base)
             elif spec == "split_bwd":
                 def setter(on, base=ConvBnReLU.split_bwd):
                     ConvBnReLU.split_bwd = (not base) if on else base
@@ -777,6 +787,7 @@ def main():
             with open("gpurun_out/host_trace.json", "w") as f:
                 json.dump({"marks": host_marks, "rows": host_trace.rows}, f)
         if step_events:
+            res["warmup_enqueue_ms"], res["opening_barrier_wait_ms"] = round(t_warm * 1e3, 2), round(t_gap * 1e3, 2)
             res["step_gpu_ms"] = [round(a.elapsed_time(b), 3) for a, b in zip(step_events, step_events[1:])]
             res["step_host_ms"] = [round((b - a) * 1e3, 3) for a, b in zip(host_marks, host_marks[1:])]
             if train and join_trace:

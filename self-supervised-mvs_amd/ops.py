@@ -484,8 +484,8 @@ def set_side_stream_priority(which: str) -> None:
     main stream's kernels -- the critical path -- are dispatched first and the weight gradients fill what is left; "default": the
     priority of an ordinary stream.  Drops the existing pool (new streams are made on demand)."""
     global _SIDE_PRIORITY
-    if which not in ("low", "default"):
-        raise ValueError("side stream priority must be 'low' or 'default'")
+    if which not in ("low", "default", "high"):
+        raise ValueError("side stream priority must be 'low', 'default' or 'high'")
     _SIDE_PRIORITY = which
     for idx, pool in _SIDE_STREAMS.items():
         for sd in pool:
@@ -498,6 +498,11 @@ def _new_side_stream(dev):
         try:
             least = torch.cuda.Stream.priority_range()[0]     # (least, greatest): numerically larger = lower priority
             return torch.cuda.Stream(device=dev, priority=least)
+        except Exception:
+            pass
+    if _SIDE_PRIORITY == "high":
+        try:
+            return torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[1])
         except Exception:
             pass
     return torch.cuda.Stream(device=dev)
