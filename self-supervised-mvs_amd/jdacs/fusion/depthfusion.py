@@ -179,7 +179,11 @@ def read_p_file(path):
 def fusibile_cameras(P_list):
     """Camera_cu fields of cameraGeometryUtils.h:310-440 for transformP = false, cam_scale = 1 -> (cams [V,32] float32, f):
     every P decomposed into K, R, C (decomposeProjectionMatrix); P rebuilt as K_0 [R | -R C] with the FIRST camera's K; M_inv;
-    the camera centre from the minors of the rebuilt P.  Layout of a row: P[12], M_inv[9], P[:,3] [3], C[3], 5 unused."""
+    the camera centre from the minors of the rebuilt P.  Layout of a row: P[12], M_inv[9], P[:,3] [3], C[3], 5 unused.
+    Two host-side conventions differ from cv::decomposeProjectionMatrix and are no-ops for the .P files the pipeline itself writes
+    (write_gipuma_cam: K [R | t] with K[2,2] = 1, det R = +1): K is normalised by K[2,2] and (K, R) change sign together when
+    det R < 0; a P file scaled by s != 1 would give the program's own decomposition K[2,2] = s.  Colours: the images are decoded by
+    PIL, the program uses cv::imread -- for .jpg inputs the two decoders may differ by +-1 per channel (the tests use .png)."""
     from scipy.linalg import rq
     Ks, Rts = [], []
     for P in P_list:

@@ -139,7 +139,32 @@ def _folded(self):
     return cache[1]
 
 
+def _drop_fold(self):
+    """forget the folded weights (call after changing parameters through `.data`, which does not bump their version counters)"""
+    self.__dict__.pop("_fold_cache", None)
+
+
+def _train(self, mode=True):
+    self.__dict__.pop("_fold_cache", None)
+    return nn.Module.train(self, mode)
+
+
+def _apply_and_drop(self, fn, *args, **kwargs):
+    self.__dict__.pop("_fold_cache", None)          # .to() / .cuda() / .half(): new parameter tensors
+    return nn.Module._apply(self, fn, *args, **kwargs)
+
+
+def _getstate(self):
+    state = dict(self.__dict__)                      # deepcopy / pickle: the cache is derived data
+    state.pop("_fold_cache", None)
+    return state
+
+
 ConvBnReLU._folded = _folded
+ConvBnReLU.refold = _drop_fold
+ConvBnReLU.train = _train
+ConvBnReLU._apply = _apply_and_drop
+ConvBnReLU.__getstate__ = _getstate
 
 
 def homo_warping(src_fea, src_proj, ref_proj, depth_values, align_corners=None):

@@ -161,7 +161,7 @@ class MVSNet(nn.Module):
 
         # step 2. homography warp + variance cost volume: ONE fused HIP kernel, volume written once
         with torch.no_grad():
-            rot, trans = ops.relative_projections(src_projs, ref_proj)   # module.py:116-118 for all source views, one launch
+            rot, trans = ops.relative_projections(src_projs, ref_proj, like=ref_feature)   # module.py:116-118 for all source views, one launch
         if self.storage_dtype == torch.bfloat16 and (self.training or torch.is_grad_enabled()):
             raise RuntimeError("MVSNet.storage_dtype = bfloat16 is the inference path: call .eval() and run under torch.no_grad()")
         volume_variance = ops.plane_sweep_variance(ref_feature, src_features, rot, trans, depth_values,

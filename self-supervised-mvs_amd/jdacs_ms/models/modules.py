@@ -87,7 +87,7 @@ def proj_cost(settings, ref_feature, src_feature, level, ref_in, src_in, ref_ex,
     reference's in-place alias quirk (both running sums start from ref^2, App. A Q2).  One fused kernel."""
     nsrc = settings.nsrc
     with torch.no_grad():   # modules.py:71-80 for all source views: one launch
-        rot, trans = ops.relative_projections([_ms_proj(src_in[:, s], src_ex[:, s]) for s in range(nsrc)], _ms_proj(ref_in, ref_ex))
+        rot, trans = ops.relative_projections([_ms_proj(src_in[:, s], src_ex[:, s]) for s in range(nsrc)], _ms_proj(ref_in, ref_ex), like=ref_feature)
     ac = ALIGN_CORNERS if align_corners is None else align_corners
     return ops.plane_sweep_variance(ref_feature, [src_feature[s][level] for s in range(nsrc)], rot, trans,
                                     depth_hypos, align_corners=ac, ms_alias=True)

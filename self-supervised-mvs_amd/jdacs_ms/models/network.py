@@ -121,7 +121,7 @@ class CVPMVSNet(nn.Module):
         depth_hypos = calSweepingDepthHypo(ref_in_ms[:, -1], src_in_ms[:, 0, -1], ref_ex, src_ex, depth_min, depth_max)
         with torch.no_grad():   # modules.py:71-80 for all source views: one launch
             rot, trans = ops.relative_projections([_ms_proj(src_in_ms[:, i, -1], src_ex[:, i]) for i in range(a.nsrc)],
-                                                  _ms_proj(ref_in_ms[:, -1], ref_ex))
+                                                  _ms_proj(ref_in_ms[:, -1], ref_ex), like=ref_fp[-1])
         cost_volume = ops.plane_sweep_variance(ref_fp[-1], [fp[-1] for fp in src_fps], rot, trans, depth_hypos,
                                                align_corners=self.align_corners, ms_alias=True)
         cost_reg = self.cost_reg_refine(cost_volume)

@@ -81,23 +81,30 @@ def relative_projection(src_proj: torch.Tensor, ref_proj: torch.Tensor):
     return proj[:, :3, :3], proj[:, :3, 3]
 
 
-def relative_projections(src_projs, ref_proj: torch.Tensor):
+def relative_projections(src_projs, ref_proj: torch.Tensor, like: Optional[torch.Tensor] = None):
     """rot [B,NS,3,3] / trans [B,NS,3] of src_projs[s] @ inverse(ref_proj) for ALL source views in one launch
     (``mvs_relative_projection``: fp64 Gauss-Jordan + product per (sample, view)) instead of one LU inverse + matmul + slices
-    per view (jdacs/models/module.py:116-118 runs once per source view: ~10 tiny launches, 91 us of the training step)."""
+    per view (jdacs/models/module.py:116-118 runs once per source view: ~10 tiny launches, 91 us of the training step).
+    ``like``: the feature map the result will be used with -- cameras that live elsewhere (CPU-resident cameras next to GPU
+    features: the reference's `.cuda()` calls are the caller's business) are copied to its device first, so the result is
+    always where the plane-sweep kernel reads it."""
     ns = len(src_projs)
     b = ref_proj.shape[0]
+    if tuple(ref_proj.shape) != (b, 4, 4) or any(tuple(p.shape) != (b, 4, 4) for p in src_projs):
+        raise ValueError("relative_projections: need NS x [B,4,4] and [B,4,4], got %s and %s"
+                         % ([tuple(p.shape) for p in src_projs], tuple(ref_proj.shape)))
+    dev = like.device if like is not None else ref_proj.device
+    if ref_proj.device != dev or any(p.device != dev for p in src_projs):
+        ref_proj, src_projs = ref_proj.to(dev), [p.to(dev) for p in src_projs]
     # the kernel computes in fp64 from fp32 inputs; float64 / half matrices are cast first (the reference's lines are dtype
-    # agnostic), and matrices that do not live on the library's device (CPU-resident cameras next to GPU features) take the
-    # reference's own host lines instead of raising
-    if ref_proj.device.type != _lib.get().device_type:
+    # agnostic).  Matrices (and features) that do not live on the library's device -- the CPU emulation build aside, that is a
+    # CPU tensor handed to the GPU build -- take the reference's own host lines and stay where they are.
+    if dev.type != _lib.get().device_type:
         rts = [relative_projection(p, ref_proj) for p in src_projs]
         return torch.stack([r for r, _ in rts], 1).float(), torch.stack([t for _, t in rts], 1).float()
     src = torch.stack([p.to(torch.float32) for p in src_projs], 1).contiguous()
     ref = ref_proj.to(torch.float32).contiguous()
     lib = _lib_for(ref)
-    if src.shape != (b, ns, 4, 4) or ref.shape != (b, 4, 4):
-        raise ValueError("relative_projections: need NS x [B,4,4] and [B,4,4], got %s and %s" % (tuple(src.shape), tuple(ref.shape)))
     rot = torch.empty((b, ns, 3, 3), dtype=torch.float32, device=ref.device)
     trans = torch.empty((b, ns, 3), dtype=torch.float32, device=ref.device)
     lib.call("mvs_relative_projection", _p(src), _p(ref), b, ns, _p(rot), _p(trans), _stream(ref))
@@ -562,6 +569,17 @@ def _note_weight_use(weight: torch.Tensor) -> None:
         n = uses[weight.data_ptr()] = uses.get(weight.data_ptr(), 0) + 1
         if n > 1:
             _WEIGHT_MULTI.setdefault(idx, set()).add(weight.data_ptr())
+
+
+def reset_weight_uses() -> None:
+    """Forget the outstanding forward uses (per weight) the side-stream rules count.  A forward pass whose weight-gradient
+    backward never runs (a train-mode validation pass without no_grad, autograd.grad w.r.t. inputs only, an exception) leaves a
+    count behind and that weight then stays on the synchronous path -- safe, but slower; a training loop that does such passes
+    calls this at the start of an iteration (no backward pass may be open)."""
+    if _BWD_OPEN:
+        raise RuntimeError("reset_weight_uses() inside a backward pass")
+    _WEIGHT_USES.clear()
+    _WEIGHT_MULTI.clear()
 
 
 def _weight_use_done(idx: int, ptr: int) -> None:

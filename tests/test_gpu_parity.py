@@ -296,6 +296,26 @@ def test_relative_projections_one_launch(dev):
 
 
 
+def test_cpu_resident_cameras_next_to_gpu_images(dev):
+    """proj_matrices left on the CPU while imgs / depth_values are on the GPU (the reference moves every tensor with .cuda() in
+    its loop; a caller of the drop-in may not): ops.relative_projections copies the cameras to the feature maps' device and the
+    depth map equals the all-GPU call (the earlier host fallback handed a host pointer to the plane-sweep kernel)."""
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    from mvs_amd.synthetic import synthetic_mvsnet_inputs
+    torch.manual_seed(2)
+    net = MVSNet(refine=False).to(dev).eval()
+    imgs, proj, dv = synthetic_mvsnet_inputs(1, 3, 64, 96, 16, seed=5)
+    with torch.no_grad():
+        a = net(imgs.to(dev), proj.to(dev), dv.to(dev))["depth"]
+        b = net(imgs.to(dev), proj, dv.to(dev))["depth"]
+    assert b.device == a.device and torch.equal(a, b)
+    from mvs_amd import ops
+    rot, trans = ops.relative_projections([proj[:, 1], proj[:, 2]], proj[:, 0], like=imgs.to(dev))
+    assert rot.device.type == "cuda" and trans.device.type == "cuda"
+    with pytest.raises(ValueError):
+        ops.relative_projections([proj[:, 1, :3]], proj[:, 0])
+
+
 def test_golden_homo_warping_and_proj_cost(dev):
     from mvs_amd import ops
     from mvs_amd.jdacs.models.module import homo_warping

@@ -411,3 +411,37 @@ def test_folded_eval_batchnorm_cache_follows_parameter_updates():
         m.load_state_dict(sd, strict=False)
         w3, b3 = m._folded()
         assert float((F.conv2d(x, w3, b3, padding=1) - m.bn(m.conv(x))).abs().max()) < 1e-5
+
+
+def test_folded_batchnorm_cache_is_derived_data():
+    """the eval-mode folded (conv, BatchNorm) weights are dropped by train(), by .to()/.double() and are not carried by
+    deepcopy / pickle; refold() drops them by hand (parameter updates through .data do not bump the version counters)."""
+    import copy
+    import pickle
+    from mvs_amd.jdacs.models.module import ConvBnReLU
+    m = ConvBnReLU(3, 8).eval()
+    with torch.no_grad():
+        w0, _ = m._folded()
+    assert "_fold_cache" in m.__dict__
+    assert "_fold_cache" not in copy.deepcopy(m).__dict__
+    assert "_fold_cache" not in pickle.loads(pickle.dumps(m)).__dict__
+    m.train()
+    assert "_fold_cache" not in m.__dict__
+    m.eval()
+    with torch.no_grad():
+        m._folded()
+        m.conv.weight.data.mul_(2.0)          # invisible to the (data_ptr, version) key
+        assert torch.equal(m._folded()[0], w0)
+        m.refold()
+        assert torch.allclose(m._folded()[0], 2.0 * w0)
+    m.double()
+    assert "_fold_cache" not in m.__dict__
+
+
+def test_reset_weight_uses_forgets_forward_passes_without_backward():
+    from mvs_amd import ops
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    ops._WEIGHT_USES.setdefault(0, {})[w.data_ptr()] = 2
+    ops._WEIGHT_MULTI.setdefault(0, set()).add(w.data_ptr())
+    ops.reset_weight_uses()
+    assert not ops._WEIGHT_USES and not ops._WEIGHT_MULTI
