@@ -494,12 +494,18 @@ struct Wg2Cfg {
 };
 using Wg2A = Wg2Cfg<3, 1, 3, 1, 8, 1>;     // 3 -> <= 16   (27 rows)
 using Wg2B = Wg2Cfg<3, 1, 8, 1, 8, 1>;     // 8 -> <= 16
-using Wg2C = Wg2Cfg<5, 2, 8, 1, 4, 1>;     // 8 -> <= 16, 5x5 stride 2
+using Wg2C = Wg2Cfg<5, 2, 8, 1, 4, 2>;     // 8 -> <= 16, 5x5 stride 2 (13 m-tiles: rows in two halves)
 using Wg2D = Wg2Cfg<3, 1, 16, 1, 8, 1>;    // 16 -> <= 16
 using Wg2E = Wg2Cfg<5, 2, 16, 2, 4, 2>;    // 16 -> <= 32, 5x5 stride 2
 using Wg2F = Wg2Cfg<3, 1, 32, 2, 4, 2>;    // 32 -> <= 32
+// Two launch classes: one kernel for all six would give every workgroup the widest layers' 250 registers and 72 KB of LDS, i.e. 2
+// waves per SIMD, while a tile's MFMA loop (1-2 us) is shorter than the latency of the next tile's loads: the narrow layers --
+// which hold 5 of FeatureNet's 8 layers and most of its positions -- ran 3x above their MFMA time (profiles/r04_run28_*).  Class 0
+// (A-D: <= 16 input channels) needs ~110 registers and 38 KB.
 constexpr int wg2_max(int a, int b) { return a > b ? a : b; }
-constexpr int WG2_LDS = wg2_max(wg2_max(wg2_max(Wg2A::LDS, Wg2B::LDS), wg2_max(Wg2C::LDS, Wg2D::LDS)), wg2_max(Wg2E::LDS, Wg2F::LDS));
+constexpr int WG2_LDS0 = wg2_max(wg2_max(Wg2A::LDS, Wg2B::LDS), wg2_max(Wg2C::LDS, Wg2D::LDS));
+constexpr int WG2_LDS1 = wg2_max(Wg2E::LDS, Wg2F::LDS);
+MVS_HD inline int wg2_class(int cfg) { return cfg >= 4 ? 1 : 0; }
 
 template <class C>
 __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __restrict__ lds) {
@@ -531,12 +537,21 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
     float4 xv[VEC ? XIT : 1];
     float xs[VEC ? 1 : XIT];
     float4 gv[GIT];
+    // the layer's scalars once, in registers: read through the kernel-argument reference they were re-fetched (a scalar load and
+    // a wait) in front of every bounds test of the staging loads.  The loads stay CONDITIONAL (zero-initialised register, load
+    // under the bounds test): unconditional loads from clamped addresses with the zeroing as a select -- after the load or at the
+    // LDS store -- made hipcc keep the prefetched tile in scratch memory and wait for every load ahead of the MFMA loop.
+    const float* __restrict__ gx = L.x;
+    const float* __restrict__ gg = L.g;
+    const int Hi = L.Hi, Wi = L.Wi, Ho = L.Ho, Wo = L.Wo, CG = L.CG, ntw = L.ntw, nth = L.nth;
     auto load_tile = [&](int tile) {
         int t = tile;
-        const int tw = t % L.ntw; t /= L.ntw;
-        const int th = t % L.nth;
-        const int n = t / L.nth;
+        const int tw = t % ntw; t /= ntw;
+        const int th = t % nth;
+        const int n = t / nth;
         const int oy0 = th * C::TH, ox0 = tw * TW, iy0 = oy0 * S - C::P, ix0 = ox0 * S - C::P;
+        const float* __restrict__ xn = gx + (size_t)n * Hi * Wi * CX;
+        const float* __restrict__ gn = gg + (size_t)n * Ho * Wo * CG;
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
@@ -544,15 +559,15 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < XN) {
                     const int px = i / CQ, cq = i % CQ, iy = iy0 + px / RW, ix = ix0 + px % RW;
-                    if (iy >= 0 && iy < L.Hi && ix >= 0 && ix < L.Wi)
-                        v = *reinterpret_cast<const float4*>(L.x + (((size_t)n * L.Hi + iy) * L.Wi + ix) * CX + 4 * cq);
+                    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+                        v = *reinterpret_cast<const float4*>(xn + ((size_t)iy * Wi + ix) * CX + 4 * cq);
                 }
                 xv[k] = v;
             } else {
                 float v = 0.f;
                 if (i < XN) {
                     const int ry = i / (RW * CX), rem = i % (RW * CX), iy = iy0 + ry, ix = ix0 + rem / CX;
-                    if (iy >= 0 && iy < L.Hi && ix >= 0 && ix < L.Wi) v = L.x[(((size_t)n * L.Hi + iy) * L.Wi + ix0) * CX + rem];
+                    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = xn[((size_t)iy * Wi + ix0) * CX + rem];
                 }
                 xs[k] = v;
             }
@@ -563,13 +578,12 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < GN) {
                 const int p = i / GQ, c4 = 4 * (i % GQ), oy = oy0 + p / TW, ox = ox0 + p % TW;
-                if (c4 < L.CG && oy < L.Ho && ox < L.Wo)
-                    v = *reinterpret_cast<const float4*>(L.g + (((size_t)n * L.Ho + oy) * L.Wo + ox) * L.CG + c4);
+                if (c4 < CG && oy < Ho && ox < Wo) v = *reinterpret_cast<const float4*>(gn + ((size_t)oy * Wo + ox) * CG + c4);
             }
             gv[k] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int) {
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
@@ -584,15 +598,17 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
             if (i < GN) *reinterpret_cast<float4*>(&gt[(i / GQ) * GP + 4 * (i % GQ)]) = gv[k];
         }
     };
-    const int t0 = wgl * L.tpw, t1 = t0 + L.tpw < L.ntiles ? t0 + L.tpw : L.ntiles;
+    const int tpw = L.tpw, ntiles = L.ntiles;
+    const int t0 = wgl * tpw, t1 = t0 + tpw < ntiles ? t0 + tpw : ntiles;
     if (t0 < t1) load_tile(t0);
     for (int tile = t0; tile < t1; ++tile) {
         __syncthreads();            // the previous tile's MFMA loop has read the LDS images
-        store_tile();
+        store_tile(tile);
         __syncthreads();
         if (tile + 1 < t1) load_tile(tile + 1);     // in flight during the MFMA loop
 #pragma unroll 2
-        for (int ks = kg; ks < C::NPOS / 4; ks += C::KW) {
+        for (int j = 0; j < C::NPOS / 4 / C::KW; ++j) {
+            const int ks = kg + j * C::KW;
             const int p = 4 * ks + kq;
             const int posoff = ((p / TW) * S * RW + (p % TW) * S) * XP;
             float bv[NB], av[MTW];
@@ -631,19 +647,25 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
     for (int i = tid; i < C::ROWSP * C::CGP / 4; i += 256) out[i] = reinterpret_cast<const float4*>(red)[i];
 }
 
+template <int CLS>
 __global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
-    __shared__ __attribute__((aligned(16))) float lds[WG2_LDS];
-    int li = 0;
-    while (li + 1 < b.n && (int)blockIdx.x >= b.l[li].wg0 + b.l[li].nwg) ++li;
+    __shared__ __attribute__((aligned(16))) float lds[CLS == 0 ? WG2_LDS0 : WG2_LDS1];
+    int li = -1;
+    for (int i = 0; i < b.n; ++i)
+        if (wg2_class(b.l[i].cfg) == CLS && (int)blockIdx.x >= b.l[i].wg0 && (int)blockIdx.x < b.l[i].wg0 + b.l[i].nwg) li = i;
+    if (li < 0) return;
     const Wg2Layer& L = b.l[li];
     const int wgl = blockIdx.x - L.wg0;
-    switch (L.cfg) {
-        case 0: wg2_body<Wg2A>(L, wgl, lds); break;
-        case 1: wg2_body<Wg2B>(L, wgl, lds); break;
-        case 2: wg2_body<Wg2C>(L, wgl, lds); break;
-        case 3: wg2_body<Wg2D>(L, wgl, lds); break;
-        case 4: wg2_body<Wg2E>(L, wgl, lds); break;
-        default: wg2_body<Wg2F>(L, wgl, lds); break;
+    if (CLS == 0) {
+        switch (L.cfg) {
+            case 0: wg2_body<Wg2A>(L, wgl, lds); break;
+            case 1: wg2_body<Wg2B>(L, wgl, lds); break;
+            case 2: wg2_body<Wg2C>(L, wgl, lds); break;
+            default: wg2_body<Wg2D>(L, wgl, lds); break;
+        }
+    } else {
+        if (L.cfg == 4) wg2_body<Wg2E>(L, wgl, lds);
+        else wg2_body<Wg2F>(L, wgl, lds);
     }
 }
 
@@ -934,7 +956,7 @@ extern "C" int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, floa
 }
 
 // ---- all layers' weight gradients in one launch -------------------------------------------------------------------------------
-int g_conv2d_wgrad_batch_groups = 1024;   // tuning knob "wgrad2d_batch": workgroups of the batched weight gradient, shared out by work
+int g_conv2d_wgrad_batch_groups = 2048;   // tuning knob "wgrad2d_batch": workgroups of the batched weight gradient (both launches together), shared out by work; FeatureNet at config 2: 0.185 / 0.180 / 0.176 / 0.174 / 0.176 ms at 1024 / 1536 / 2048 / 3072 / 4096 (profiles/r04_run29_*)
 
 struct Wg2Static { int ks, stride, cx, cgmax, th, rowsp, cgp, cost; };
 template <class C>
@@ -974,7 +996,7 @@ static long long wg2_plan(int n, const int* shapes, Wg2Batch& b) {
     }
     const int budget = g_conv2d_wgrad_batch_groups < n ? n : (g_conv2d_wgrad_batch_groups > 4096 ? 4096 : g_conv2d_wgrad_batch_groups);
     long long floats = 0;
-    int wg = 0, rb = 0;
+    int wgc[2] = {0, 0}, rb = 0;       // workgroup ranges per launch class (conv2d_wgrad_batch_kernel<0 / 1>)
     for (int i = 0; i < n; ++i) {
         Wg2Layer& L = b.l[i];
         int want = (int)(budget * cost[i] / total + 0.5);
@@ -982,7 +1004,7 @@ static long long wg2_plan(int n, const int* shapes, Wg2Batch& b) {
         if (want > L.ntiles) want = L.ntiles;
         L.tpw = mvs_cdiv(L.ntiles, want);
         L.nwg = mvs_cdiv(L.ntiles, L.tpw);
-        L.wg0 = wg; wg += L.nwg;
+        L.wg0 = wgc[wg2_class(L.cfg)]; wgc[wg2_class(L.cfg)] += L.nwg;
         L.nrb = mvs_cdiv(L.rowsp * L.cgp, 16);
         L.rb0 = rb; rb += L.nrb;
         floats += (long long)L.nwg * L.rowsp * L.cgp;
@@ -1009,10 +1031,14 @@ extern "C" int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float*
         L.x = x[i]; L.g = gy[i]; L.gw = gw[i]; L.part = part;
         part += (size_t)L.nwg * L.rowsp * L.cgp;
     }
-    const Wg2Layer& last = b.l[n - 1];
-    MVS_LAUNCH(conv2d_wgrad_batch_kernel, dim3(last.wg0 + last.nwg), dim3(256), 0, stream, b);
+    int wgc[2] = {0, 0};
+    for (int i = 0; i < n; ++i) wgc[wg2_class(b.l[i].cfg)] += b.l[i].nwg;
+    // the wide layers first: few, long workgroups; the narrow layers' many short ones fill the GPU behind them
+    if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1>), dim3(wgc[1]), dim3(256), 0, stream, b);
+    if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0>), dim3(wgc[0]), dim3(256), 0, stream, b);
     int rc = mvs_check_launch("conv2d_wgrad_batch");
     if (rc) return rc;
+    const Wg2Layer& last = b.l[n - 1];
     MVS_LAUNCH(conv2d_wgrad_batch_reduce_kernel, dim3(last.rb0 + last.nrb), dim3(256), 0, stream, b);
     return mvs_check_launch("conv2d_wgrad_batch_reduce");
 }

@@ -806,6 +806,77 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a, const float
     }
 }
 
+// The same layer with FOUR outputs per thread (round 4, 8 input channels: the probability layer of MVSNet at full resolution).
+// The kernel above is LDS-bandwidth bound: 54 tile reads + 54 weight reads of 16 bytes per output voxel = 1.7 KB of LDS traffic per
+// voxel, 86 us at config 2 against 28 us of HBM time (142 MB).  Here a thread owns 4 outputs that are consecutive in H: the 6 input
+// rows under them are read once per (kd, kw) instead of 3 rows per output (108 reads per 4 outputs), and a weight quad is read once
+// per thread and used for all rows (54 reads per 4 outputs): 0.65 KB per voxel.  Tile 4 x 8 x 32 outputs (a wave = one W row of 32
+// x 2 H groups), halo 6 x 10 x 34 voxels kept as two 4-channel planes so the 16 lanes of a b128 read phase, consecutive in W, hit
+// 16 different bank quads (a voxel stride of 8 floats would give 2-way conflicts): 65 KB, two workgroups per CU.
+constexpr int CO1_TD = 4, CO1_TH = 8, CO1_TW = 32, CO1_RD = CO1_TD + 2, CO1_RH = CO1_TH + 2, CO1_RW = CO1_TW + 2;
+__global__ __launch_bounds__(256) void conv_cout1_h4_kernel(ConvArgs a, const float* __restrict__ w) {
+    constexpr int NR = CO1_RD * CO1_RH * CO1_RW;
+    __shared__ __attribute__((aligned(16))) float tile[2 * NR * 4];   // [channel quad][voxel][4]
+    __shared__ __attribute__((aligned(16))) float wl[27 * 8];         // [tap][ci]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % a.ntw; t /= a.ntw;
+    const int th = t % a.nth; t /= a.nth;
+    const int td = t % a.ntd; t /= a.ntd;
+    const int b = t;
+    const int qd0 = td * CO1_TD, qh0 = th * CO1_TH, qw0 = tw * CO1_TW;
+    for (int i = tid; i < 27 * 8; i += 256) wl[i] = w[(size_t)(i % 8) * 27 + i / 8];   // W[0][ci][tap]
+    stage_batched<NR * 2>(tile, tid, [&](int i, const float*& src, int& o) {
+        const int vox = i >> 1, cq = i & 1;
+        const int rw = vox % CO1_RW, rh = (vox / CO1_RW) % CO1_RH, rd = vox / (CO1_RW * CO1_RH);
+        const int id = qd0 + rd - 1, ih = qh0 + rh - 1, iw = qw0 + rw - 1;
+        o = (cq * NR + vox) * 4;
+        if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+            src = a.x + ((((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw) * 8 + 4 * cq;
+    });
+    __syncthreads();
+    const int pw = tid & 31, hg = (tid >> 5) & 1, pd = tid >> 6;
+    const int base = ((pd * CO1_RH + 4 * hg) * CO1_RW + pw) * 4;      // halo voxel under output (pd, 4 hg, pw), tap (0, 0, 0)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // (kd, kw) as a real loop of 9 trips: fully unrolled, hipcc hoists all 162 LDS reads ahead of the arithmetic (512 VGPRs + scratch)
+#pragma unroll 1
+    for (int kdw = 0; kdw < 9; ++kdw) {
+        const int kd = kdw / 3, kw = kdw % 3;
+#pragma unroll
+            for (int cq = 0; cq < 2; ++cq) {
+                float4 wv[3];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) wv[kh] = *reinterpret_cast<const float4*>(&wl[((kd * 3 + kh) * 3 + kw) * 8 + 4 * cq]);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&tile[cq * NR * 4 + base + ((kd * CO1_RH + r) * CO1_RW + kw) * 4]);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int o = r - kh;
+                        if (o >= 0 && o < 4) {
+                            acc[o] = fmaf(xv.x, wv[kh].x, acc[o]); acc[o] = fmaf(xv.y, wv[kh].y, acc[o]);
+                            acc[o] = fmaf(xv.z, wv[kh].z, acc[o]); acc[o] = fmaf(xv.w, wv[kh].w, acc[o]);
+                        }
+                    }
+                }
+            }
+    }
+    const int qd = qd0 + pd, qw = qw0 + pw;
+#pragma unroll
+    for (int o4 = 0; o4 < 4; ++o4) {
+        const int qh = qh0 + 4 * hg + o4;
+        if (qd < a.QD && qh < a.QH && qw < a.QW) {
+            const size_t o = (((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw;
+            float v = acc[o4];
+            if (a.scale) v = v * a.scale[0] + a.shift[0];
+            else if (a.shift) v = v + a.shift[0];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.skip) v += a.skip[o];
+            a.y[o] = v;
+        }
+    }
+}
+
 // dW[tap][cx] = sum_pos X[pos + tap - 1][cx] * g[pos]   (CG == 1, stride 1): thread = one (tap, cx) output
 // (two for CX == 16), persistent over tiles; X halo tile and g tile in LDS.  Partial image per workgroup
 // in the generic layout [group][27][CX][1] so conv_wgrad_reduce_kernel finishes it.
@@ -1466,6 +1537,7 @@ int g_conv_small_wgs = 384;   // tuning knob "conv_small_wgs": quarter-size tile
 int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tiles for under-filled launches (0 never, 1 auto, 2 always)
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
 int g_conv_wgrad_groups = 768;   // tuning knob "wgrad_groups": persistent workgroups of the generic weight-gradient kernels (<= 768)
+int g_conv_cout1_h4 = 1;         // tuning knob "cout1_h4": the 8 -> 1 layer with four outputs per thread (conv_cout1_h4_kernel); 0: one output per thread
 int g_conv_wgrad8_groups = 192;  // tuning knob "wgrad8_groups": ... of the CG == 8 kernel (conv0; <= 512).  On the side stream it runs under the plane-sweep backward and the 2-D extractor's backward.  While the main stream was the longer one the step was faster the less this kernel took from it (5.440 ms at 512, 5.416 at 384, 5.413 at 256, 5.400 at 128: profiles/r04_run9_*); since the extractor's weight gradients became one launch the side stream ends last (+0.05 ms at the join) and 192 is the best of 128 / 192 / 256 / 384 / 512 (5.28 / 5.23 / 5.25 / 5.24 / 5.28: profiles/r04_run25_*)
 int g_conv_wgrad8_nch = 1;       // tuning knob "wgrad8_nch": 2 = the CG == 8 weight gradient stages both 16-channel chunks of a 32-channel X in one workgroup
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
@@ -1656,7 +1728,10 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
     }
     int nblocks = B * a.ntd * a.nth * a.ntw;
     if (plan_is_cout1(p, &ep)) {
-        if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
+        if (cin == 8 && g_conv_cout1_h4) {
+            a.ntd = mvs_cdiv(a.QD, CO1_TD); a.nth = mvs_cdiv(a.QH, CO1_TH); a.ntw = mvs_cdiv(a.QW, CO1_TW);
+            MVS_LAUNCH(conv_cout1_h4_kernel, dim3(B * a.ntd * a.nth * a.ntw), dim3(256), 0, st, a, wsrc);
+        } else if (cin == 8) MVS_LAUNCH((conv_cout1_kernel<8>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         return mvs_check_launch("conv_cout1");
     }

@@ -1130,6 +1130,7 @@ extern int g_conv2d_s2_mfma;
 extern int g_conv2d_pp;
 extern int g_conv2d_wgrad_groups;
 extern int g_conv2d_wgrad_batch_groups;
+extern int g_conv_cout1_h4;
 static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows (<= 4 source views; the default), 1 = view-pair kernel with LDS atomics (what > 4 source views run).  (Round 3's projection-table form with an LDS-DMA ring measured 2.2x slower and was removed in round 4: DESIGN.md section 4, git tag r3-rejected-variants.)
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
@@ -1147,7 +1148,7 @@ extern "C" int mvs_set_tuning(const char* key, int value) {
         {"nt", &g_sweep_nt, 0, 1},           {"tile_w", &g_sweep_tile_w, 0, 256},   {"dslab", &g_sweep_dslab, 0, 1 << 20},
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"cout1_d4", &g_conv_cout1_d4, 0, 3}, {"bf16_dp", &g_conv_bf16_dp, 0, 1}, {"conv2d_pp", &g_conv2d_pp, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20}, {"wgrad2d_batch", &g_conv2d_wgrad_batch_groups, 1, 4096},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 1},
-        {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1}, {"wgrad_small", &g_conv_wgrad_small, 0, 3}, {"wgrad_groups", &g_conv_wgrad_groups, 1, 768}, {"wgrad8_groups", &g_conv_wgrad8_groups, 1, 512}, {"wgrad8_nch", &g_conv_wgrad8_nch, 1, 2},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
+        {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1}, {"wgrad_small", &g_conv_wgrad_small, 0, 3}, {"wgrad_groups", &g_conv_wgrad_groups, 1, 768}, {"wgrad8_groups", &g_conv_wgrad8_groups, 1, 512}, {"wgrad8_nch", &g_conv_wgrad8_nch, 1, 2}, {"cout1_h4", &g_conv_cout1_h4, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
         {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
     };
     for (const Knob& k : knobs)

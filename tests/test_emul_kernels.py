@@ -177,6 +177,8 @@ CONV_CASES = [
     (64, 32, 2, True, (2, 2, 4)),
     (64, 32, 1, True, (2, 3, 5)),
     (8, 1, 1, False, (4, 5, 18)),
+    (16, 1, 1, False, (4, 5, 18)),      # CVP-MVSNet's probability layer: one output per thread
+    (8, 1, 1, False, (5, 11, 37)),      # the four-outputs-per-thread form: ragged 4 x 8 x 32 tiles in all three directions
 ]
 
 
@@ -1358,7 +1360,7 @@ def test_conv2d_weight_gradients_of_all_layers_in_one_launch(emul_lib, budget, h
     try:
         gws = ops.conv2d_wgrad_batch(xs, gys, ws, strides)
     finally:
-        emul_lib.call("mvs_set_tuning", b"wgrad2d_batch", 1024)
+        emul_lib.call("mvs_set_tuning", b"wgrad2d_batch", 2048)
         ops._WGRAD_BATCH_PLANS.clear()
     for gw, ref, w, cfg in zip(gws, refs, ws, WGRAD_BATCH_LAYERS):
         assert gw.shape == ref.shape and gw.stride() == w.stride(), cfg

@@ -70,12 +70,12 @@ def main():
     # all eight weight gradients as ONE launch + one reduction (ops.conv2d_wgrad_batch), whole batch and layer by layer
     xs, gys, ws, sts = [k[1] for k in keep], [k[2] for k in keep], [k[3] for k in keep], [k[4] for k in keep]
     with torch.no_grad():
-        for budget in (512, 768, 1024, 1536, 2048):
+        for budget in (1024, 1536, 2048, 3072, 4096):
             ops._lib_for(xs[0]).call("mvs_set_tuning", b"wgrad2d_batch", budget)
             ops._WGRAD_BATCH_PLANS.clear()
             print("BATCH    weight grad    %10.4f   (8 layers, one launch + one reduction, %d workgroups)"
                   % (timeit(lambda: ops.conv2d_wgrad_batch(xs, gys, ws, sts), args.reps), budget), flush=True)
-        ops._lib_for(xs[0]).call("mvs_set_tuning", b"wgrad2d_batch", 1024)
+        ops._lib_for(xs[0]).call("mvs_set_tuning", b"wgrad2d_batch", 2048)
         ops._WGRAD_BATCH_PLANS.clear()
         for i, k in enumerate(keep):
             print("%-8s batch-of-one   %10.4f" % (k[0], timeit(lambda: ops.conv2d_wgrad_batch(xs[i:i + 1], gys[i:i + 1], ws[i:i + 1], sts[i:i + 1]), args.reps)), flush=True)
