@@ -60,6 +60,8 @@ case "$what" in
     timeout 1800 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench exit $?"; summarise gpurun_out/final_bench.json
     timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/final_bench_k.json 2> gpurun_out/final_bench_k.err
     grep "ms/step" gpurun_out/final_bench_k.err > gpurun_out/final_bench_kernel_table.txt; head -12 gpurun_out/final_bench_kernel_table.txt
+    timeout 600 python bench.py --steps 20 --warmup 5 --step-events 1 $short > gpurun_out/final_bench_step_events.json 2> gpurun_out/final_bench_se.err
+    python -c "import json; d = json.load(open('gpurun_out/final_bench_step_events.json')); print('per-step GPU ms', d['step_gpu_ms'], 'side-stream lag at the join', d.get('side_stream_lag_at_join_ms_median_max'))"
     for cfg in 3 4 5; do
       timeout 900 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 > gpurun_out/final_bench_c$cfg.json 2> gpurun_out/final_bench_c$cfg.err
       echo "config $cfg exit $?"; summarise gpurun_out/final_bench_c$cfg.json
