@@ -1389,7 +1389,7 @@ def test_conv_cout8_weight_gradient_two_chunks_per_workgroup(emul_lib, dims, xcd
             emul_lib.call("mvs_set_tuning", b"wgrad8_nch", nch)
             outs[nch] = ops.conv3d_wgrad(x, gy, tuple(w.shape), 1, False)
     finally:
-        emul_lib.call("mvs_set_tuning", b"wgrad8_nch", 1)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_nch", 2)
         emul_lib.call("mvs_set_tuning", b"xcd", 1)
     scale = max(1.0, float(w.grad.abs().max()))
     assert float((outs[2] - w.grad).abs().max()) < 1e-3 * scale

@@ -4,6 +4,7 @@
 #   bench    default bench line + per-kernel HIP-event table  prof N   rocprofv3 --kernel-trace --stats of bench.py --config N
 #   pmc      HBM traffic of the roofline kernels (tools/pmc_driver.py under rocprofv3 --pmc, separate passes)
 #   final    the closing sequence of a round: tests, smoke, default line, kernel table, configs 3-5, rocprofv3 stats of configs 2-5
+#   final2   the same without configs 4 / 5 (after a change to the training path only)
 # Outputs go to gpurun_out/ (merged back by gpurun); the ones worth keeping are copied to profiles/ by hand.
 # (The per-experiment sections of rounds 1-4 -- A/B pairs of individual knobs -- are in the git history of this file; an A/B is now
 #  `python bench.py --ab "<knob>=<value>;..."`: interleaved default / toggled runs inside one process.)
@@ -67,5 +68,15 @@ case "$what" in
       echo "config $cfg exit $?"; summarise gpurun_out/final_bench_c$cfg.json
     done
     for cfg in 2 3 4 5; do run_prof $cfg; done ;;
+  final2)   # after a change that only touches the config-2 / config-3 training path: the closing sequence without configs 4 / 5
+    run_tests
+    timeout 1800 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench exit $?"; summarise gpurun_out/final_bench.json
+    timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/final_bench_k.json 2> gpurun_out/final_bench_k.err
+    grep "ms/step" gpurun_out/final_bench_k.err > gpurun_out/final_bench_kernel_table.txt; head -12 gpurun_out/final_bench_kernel_table.txt
+    timeout 600 python bench.py --steps 20 --warmup 5 --step-events 1 $short > gpurun_out/final_bench_step_events.json 2> gpurun_out/final_bench_se.err
+    python -c "import json; d = json.load(open('gpurun_out/final_bench_step_events.json')); print('per-step GPU ms', d['step_gpu_ms'], 'side-stream lag at the join', d.get('side_stream_lag_at_join_ms_median_max'))"
+    timeout 900 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 > gpurun_out/final_bench_c3.json 2> gpurun_out/final_bench_c3.err
+    echo "config 3 exit $?"; summarise gpurun_out/final_bench_c3.json
+    for cfg in 2 3; do run_prof $cfg; done ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
