@@ -3,7 +3,8 @@
 
 Hot path (HIP): plane-sweep variance volume (mvsnet.py:120-136 + module.py:105-140), CostRegNet
 (mvsnet.py:37-74), softmax + depth regression + confidence (mvsnet.py:141-151).
-FeatureNet / RefineNet are 2-D CNNs outside the path and stay stock PyTorch (MIOpen)."""
+FeatureNet / RefineNet are 2-D CNNs next to the path: they keep the reference's parameter names and run through
+csrc/conv2d.hip where that measured faster (eval: folded BatchNorm; training: ops.FeatureExtractorFn) and the library elsewhere."""
 import os
 
 import torch
@@ -25,7 +26,7 @@ _REG_DECODER = (("conv7", 64, 32, "conv4"), ("conv9", 32, 16, "conv2"), ("conv11
 
 
 class FeatureNet(nn.Module):
-    """mvsnet.py:17-34 -- 2-D CNN, 3 -> 32 channels at 1/4 resolution (stock PyTorch convolutions)."""
+    """mvsnet.py:17-34 -- 2-D CNN, 3 -> 32 channels at 1/4 resolution; kernel choice per mode and layer: DESIGN.md section 7."""
 
     one_node = os.environ.get("MVS_FEATURE_ONE_NODE", "1") != "0"   # training: the extractor as one autograd node (ops.FeatureExtractorFn)
 
@@ -147,7 +148,7 @@ class MVSNet(nn.Module):
         proj_matrices = torch.unbind(proj_matrices, 1)
         assert len(imgs) == len(proj_matrices), "Different number of images and projection matrices"
 
-        # step 1. feature extraction (stock PyTorch)
+        # step 1. feature extraction
         if self.channels_last_features:
             # all views through the shared-weight extractor as ONE batch (3x fewer launches, no per-view
             # gradient accumulation); BatchNorm keeps the reference's per-view statistics (grouped BN kernels)
