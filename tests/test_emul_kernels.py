@@ -1334,6 +1334,59 @@ def test_conv2d_wgrad_wide_reduction(emul_lib, cin, cout, ks, stride, hw):
     assert float((gw - w.grad).abs().max()) < 1e-3 * max(1.0, float(w.grad.abs().max()))
 
 
+def _stock_extractor(net, x, groups):
+    """the reference's extractor on stock torch modules: every view through the blocks on its own (mvsnet.py:115), train mode"""
+    from mvs_amd.jdacs.models.mvsnet import _FEATURE_LAYERS
+    outs = []
+    for v in x.chunk(groups, 0):
+        for name, *_ in _FEATURE_LAYERS:
+            m = getattr(net, name)
+            v = F.relu(m.bn(m.conv(v)))
+        outs.append(net.feature(v))
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("wgrad_batch", [True, False], ids=["one_launch_wgrad", "library_wgrad"])
+def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch):
+    """ops.FeatureExtractorFn (FeatureNet in training as ONE autograd node: mvsnet.py:17-34 + module.py:15-22 for every block) on the
+    emulated kernels vs the stock modules applied view by view: output, input gradient, every parameter gradient and the
+    running statistics, 2 views of 12x40 (ragged tiles), with the one-launch weight gradients and with the library's."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet, _FEATURE_LAYERS
+    torch.manual_seed(3)
+    ref = FeatureNet().train()
+    net = copy.deepcopy(ref)
+    groups = 2
+    x = torch.randn(groups, 3, 12, 40)
+    xr = x.clone().requires_grad_(True)
+    xa = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yr = _stock_extractor(ref, xr, groups)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(4))
+    yr.backward(gy)
+    blocks = [getattr(net, name) for name, *_ in _FEATURE_LAYERS]
+    cfg, params = [], []
+    for m in blocks:
+        cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
+        params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+    params += [net.feature.weight, net.feature.bias]
+    old = ops.FEATURE_WGRAD_BATCH
+    ops.FEATURE_WGRAD_BATCH = wgrad_batch
+    try:
+        with ops.slot_scope():
+            ya = ops.FeatureExtractorFn.apply(xa, groups, tuple(cfg), *params)
+        ya.backward(gy.contiguous(memory_format=torch.channels_last))
+    finally:
+        ops.FEATURE_WGRAD_BATCH = old
+    assert float((ya - yr).abs().max()) < 1e-4 * max(1.0, float(yr.abs().max()))
+    assert float((xa.grad - xr.grad).abs().max()) < 2e-3 * max(1e-6, float(xr.grad.abs().max()))
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) < 2e-3 * max(1e-6, float(q.grad.abs().max())), k
+    for (k, u), (_, v) in zip(net.named_buffers(), ref.named_buffers()):
+        if u.dtype.is_floating_point:       # (num_batches_tracked is the module wrapper's business: FeatureNet.forward)
+            assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), k
+
+
 WGRAD_BATCH_LAYERS = [  # (Cin, Cout, ks, stride, weight channels-last): the six instantiations of conv2d_wgrad_batch_kernel
     (3, 8, 3, 1, False), (8, 8, 3, 1, True), (8, 16, 5, 2, False), (16, 16, 3, 1, True), (16, 32, 5, 2, True), (32, 32, 3, 1, False)]
 
