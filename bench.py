@@ -679,6 +679,9 @@ def main():
                 from mvs_amd.jdacs.models.mvsnet import FeatureNet as _FN
                 def setter(on, base=_FN.one_node):
                     _FN.one_node = (not base) if on else base
+            elif spec == "feature_fused_apply":
+                def setter(on, base=_ops.FEATURE_FUSED_APPLY):
+                    _ops.FEATURE_FUSED_APPLY = (not base) if on else base
             elif spec == "feature_wgrad_batch":
                 def setter(on, base=_ops.FEATURE_WGRAD_BATCH):
                     _ops.FEATURE_WGRAD_BATCH = (not base) if on else base

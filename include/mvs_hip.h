@@ -255,6 +255,19 @@ int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int 
  * 3 / 8 / 16 -> <= 16 or 32 -> <= 32 channels, 5x5 stride 2 with 8 -> <= 16 or 16 -> <= 32, Cout % 4 == 0.
  * mvs_conv2d_wgrad_batch_workspace_floats: size of ws for these shapes, or -1 if a layer is not served. */
 long long mvs_conv2d_wgrad_batch_workspace_floats(int n, const int* shapes);
+/* Consumer-side BatchNorm of the training extractor (opt-in, MVS_FEATURE_FUSED_APPLY=1): block i's `F.relu(self.bn(...))`
+ * (jdacs/models/module.py:21-22) is applied by block i+1's convolution -- forward and weight gradient -- while it stages its
+ * input, so block i has no apply pass and its normalised output exists nowhere in memory.
+ * mvs_bn_finalize_slots: the statistic slots of a block -> stats [G][4][C] (mean, invstd, scale, shift) + running statistics
+ *   (the prologue of mvs_bn_relu_fwd_slots without its elementwise pass).
+ * mvs_conv2d_fwd_stats_xf: mvs_conv2d_fwd_stats with x = the RAW output of the block in front and in_stats = that block's stats.
+ * mvs_conv2d_wgrad_batch_xf: mvs_conv2d_wgrad_batch where x[i] is raw when x_stats[i] is not null (groups of imgs_per_group images). */
+int mvs_bn_finalize_slots(const double* slots, int nslots, int G, long long Vg, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* stats, hipStream_t stream);
+int mvs_conv2d_fwd_stats_xf(const float* x, const float* in_stats, const float* w, float* y, float* ws, double* slots, int nslots,
+                            int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, int ws_packed, hipStream_t stream);
+int mvs_conv2d_wgrad_batch_xf(int n, const float* const* x, const float* const* x_stats, int imgs_per_group, const float* const* gy,
+                              float* const* gw, float* ws, const int* shapes, hipStream_t stream);
 int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws, const int* shapes,
                            hipStream_t stream);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mvs_bn_slots": (_i, [_i]),
     "mvs_bn_stats_slots": (_i, [_f, _i, _ll, _i, _f, _i, _s]),
     "mvs_bn_relu_fwd_slots": (_i, [_f, _f, _i, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _f, _i, _f, _f, _s]),
+    "mvs_bn_finalize_slots": (_i, [_f, _i, _i, _ll, _i, _f, _f, _fl, _fl, _f, _f, _f, _s]),
     "mvs_bn_bwd_reduce_slots": (_i, [_f, _f, _f, _i, _i, _ll, _i, _f, _i, _s]),
     "mvs_bn_relu_bwd_slots": (_i, [_f, _f, _f, _f, _i, _i, _i, _ll, _i, _f, _f, _f, _s]),
     "mvs_bn_eval_affine": (_i, [_f, _f, _f, _f, _fl, _i, _f, _f, _s]),
@@ -61,6 +62,9 @@ SIGNATURES = {
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad_batch_workspace_floats": (_ll, [_i, C.POINTER(_i)]),
     "mvs_conv2d_wgrad_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _f, C.POINTER(_i), _s]),
+    "mvs_conv2d_wgrad_batch_xf": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _f,
+                                       C.POINTER(_i), _s]),
+    "mvs_conv2d_fwd_stats_xf": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_depth_hypo_workspace_doubles": (_ll, [_i, _i, _i]),
     "mvs_depth_hypo": (_i, [_f, _f, _i, _i, _i, _f, _f, _s]),
     "mvs_geo_consistency": (_i, [_f, C.POINTER(C.c_void_p), _f, _i, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _s]),

@@ -292,6 +292,21 @@ extern "C" int mvs_bn_relu_fwd_slots(const float* x, const double* slots, int ns
     return mvs_check_launch("bn_relu_fwd_slots");
 }
 
+// The prologue of mvs_bn_relu_fwd_slots alone: mean / invstd / scale / shift of every group into stats [G][4][C] and the running
+// statistics, group after group -- for a block whose normalisation is applied by its CONSUMER while it stages its input
+// (mvs_conv2d_fwd_stats_xf, mvs_conv2d_wgrad_batch_xf), so that no apply pass and no normalised copy of the tensor exist.
+extern "C" int mvs_bn_finalize_slots(const double* slots, int nslots, int G, long long Vg, int C, const float* gamma, const float* beta,
+                                     float eps, float momentum, float* running_mean, float* running_var, float* stats,
+                                     hipStream_t stream) {
+    MVS_REQUIRE(slots && gamma && beta && stats, MVS_ERR_NULL, "bn_finalize_slots: null pointer argument");
+    MVS_REQUIRE(bn_c_ok(C), MVS_ERR_UNSUPPORTED, "bn: C must be 4/8/16/32/64, got %d", C);
+    MVS_REQUIRE(G >= 1 && G <= 64 && Vg > 0 && bn_slots_ok(nslots), MVS_ERR_SHAPE, "bn_finalize_slots: bad shape G=%d slots=%d", G, nslots);
+    MVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MVS_ERR_NULL, "bn_finalize_slots: running_mean and running_var go together");
+    MVS_LAUNCH(bn_fwd_slots_kernel, dim3(1, G), dim3(256), 0, stream, (const float*)nullptr, slots, nslots, C, (double)Vg, gamma, beta, eps,
+               momentum, running_mean, running_var, (const float*)nullptr, 1, stats, (float*)nullptr, (size_t)0);
+    return mvs_check_launch("bn_finalize_slots");
+}
+
 extern "C" int mvs_bn_bwd_reduce_slots(const float* dy, const float* x, const float* stats, int relu, int G, long long Vg, int C,
                                        double* slots, int nslots, hipStream_t stream) {
     MVS_REQUIRE(dy && x && stats && slots, MVS_ERR_NULL, "bn_bwd_reduce_slots: null pointer argument");

@@ -25,6 +25,8 @@ struct Conv2dArgs {
     float slope;
     double* slots;                      // STATS kernels: BatchNorm statistic slots [group][nslots][2][Cout] (fp64 atomics, bn.hip):
     int nslots, imgs_per_group;         //   (sum, sum of squares) of the workgroup's outputs -> slot row (workgroup mod nslots) of image n's group
+    const float* in_stats;              // XF kernels: x is the RAW output of the BatchNorm block in front; [group][4][Cin] (mean, invstd, scale,
+                                        //   shift: mvs_bn_finalize_slots) -- relu(x * scale + shift) is applied while the halo is staged
 };
 
 template <int KS, int S>
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(Pack2dBatch pb) 
 // STATS: the workgroup also adds the per-channel sum and sum of squares of its outputs into a BatchNorm statistic slot row of its
 // image's statistics group -- BatchNorm's statistics pass folded into the convolution that produces its input, like the 3-D
 // kernels' epilogue.  Separate instantiations: the plain kernels' code and register allocation do not change.
-template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false>
+// XF: the input is normalised on the way into LDS (consumer-side BatchNorm + ReLU: the producing block has no apply pass).  Zero
+// padding stays zero: only elements inside the image are transformed.
+template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
     static_assert(!PP || (KS == 3 && S == 1 && NB == 1), "pixel pairs: 3x3 stride 1, one column tile");
@@ -137,6 +141,15 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
         // halo tile of channels [chunk*CC, +CC): zero outside the image and beyond Cin.  All loads of a batch are issued
         // before the first LDS write (a load -> store loop serialises one memory round trip per iteration).
         constexpr int NIT = (NR * CQ + 255) / 256, BATCH = NIT < 12 ? NIT : 12;
+        float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (XF) {   // a thread stages the same channel quad in every batch (256 % CQ == 0); Cin % 4 == 0 for a BatchNorm output
+            const int c0 = chunk * CC + 4 * (tid % CQ);
+            const float* __restrict__ st = a.in_stats + (size_t)(n / a.imgs_per_group) * 4 * a.Cin;
+            if (c0 + 3 < a.Cin) {
+                xsc = *reinterpret_cast<const float4*>(st + 2 * a.Cin + c0);
+                xsh = *reinterpret_cast<const float4*>(st + 3 * a.Cin + c0);
+            }
+        }
 #pragma unroll
         for (int k0 = 0; k0 < NIT; k0 += BATCH) {
             float4 v[BATCH];
@@ -163,7 +176,19 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const int i = tid + 256 * (k0 + k);
-                if (k0 + k < NIT && i < NR * CQ) *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = v[k];
+                if (k0 + k < NIT && i < NR * CQ) {
+                    float4 o = v[k];
+                    if (XF) {
+                        const int px = i / CQ, rx = px % G::RW, ry = px / G::RW;
+                        const int iy = oy0 * S + ry - G::P, ix = ox0 * S + rx - G::P;
+                        if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) {
+                            // (multiply, then add: the apply kernel's arithmetic, csrc/bn.hip, to the bit)
+                            o.x = fmaxf(o.x * xsc.x + xsh.x, 0.f); o.y = fmaxf(o.y * xsc.y + xsh.y, 0.f);
+                            o.z = fmaxf(o.z * xsc.z + xsh.z, 0.f); o.w = fmaxf(o.w * xsc.w + xsh.w, 0.f);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(&tile[(i / CQ) * CCP + 4 * (i % CQ)]) = o;
+                }
             }
         }
         __syncthreads();
@@ -473,6 +498,8 @@ struct Wg2Layer {
     int wg0, nwg;                     // this layer's workgroups in the main launch
     int rb0, nrb;                     // this layer's blocks in the reduction launch
     int rowsp, cgp, nt, wcl;
+    const float* xstats; // XF kernels, or null: x is the RAW output of the BatchNorm block in front, [group][4][CX] (mean, invstd, scale, shift);
+    int ipg;             //   relu(x * scale + shift) of image n's group (n / ipg) is applied when the halo goes to LDS
 };
 constexpr int WG2_MAX_LAYERS = 8;
 struct Wg2Batch {
@@ -507,7 +534,7 @@ constexpr int WG2_LDS0 = wg2_max(wg2_max(Wg2A::LDS, Wg2B::LDS), wg2_max(Wg2C::LD
 constexpr int WG2_LDS1 = wg2_max(Wg2E::LDS, Wg2F::LDS);
 MVS_HD inline int wg2_class(int cfg) { return cfg >= 4 ? 1 : 0; }
 
-template <class C>
+template <class C, bool XF>
 __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __restrict__ lds) {
     constexpr int KS = C::KS, S = C::S, CX = C::CX, NB = C::NB, TW = C::TW, RW = C::RW, XP = C::XP, GP = C::GP, MTW = C::MTW;
     constexpr bool VEC = CX % 4 == 0;
@@ -544,6 +571,9 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
     const float* __restrict__ gx = L.x;
     const float* __restrict__ gg = L.g;
     const int Hi = L.Hi, Wi = L.Wi, Ho = L.Ho, Wo = L.Wo, CG = L.CG, ntw = L.ntw, nth = L.nth;
+    const float* __restrict__ xst = XF ? L.xstats : nullptr;
+    const int ipg = XF ? L.ipg : 1;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);   // of the tile held in xv
     auto load_tile = [&](int tile) {
         int t = tile;
         const int tw = t % ntw; t /= ntw;
@@ -552,6 +582,11 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
         const int oy0 = th * C::TH, ox0 = tw * TW, iy0 = oy0 * S - C::P, ix0 = ox0 * S - C::P;
         const float* __restrict__ xn = gx + (size_t)n * Hi * Wi * CX;
         const float* __restrict__ gn = gg + (size_t)n * Ho * Wo * CG;
+        if (XF && VEC && xst) {   // this thread's channel quad is the same for all its items (256 % CQ == 0)
+            const float* __restrict__ st = xst + (size_t)(n / ipg) * 4 * CX + 4 * (tid % CQ);
+            xsc = *reinterpret_cast<const float4*>(st + 2 * CX);
+            xsh = *reinterpret_cast<const float4*>(st + 3 * CX);
+        }
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
@@ -583,13 +618,25 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
             gv[k] = v;
         }
     };
-    auto store_tile = [&](int) {
+    auto store_tile = [&](int tile) {
+        int t = tile;
+        const int tw = t % ntw; t /= ntw;
+        const int iy0 = (t % nth) * C::TH * S - C::P, ix0 = tw * TW * S - C::P;
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
             if (i < XN) {
-                if (VEC) *reinterpret_cast<float4*>(&xt[(i / CQ) * XP + 4 * (i % CQ)]) = xv[k];
-                else xt[i] = xs[k];
+                if (VEC) {
+                    float4 o = xv[k];
+                    if (XF && xst) {   // zero padding stays zero: only positions inside the image are normalised
+                        const int px = i / CQ, iy = iy0 + px / RW, ix = ix0 + px % RW;
+                        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+                            o.x = fmaxf(o.x * xsc.x + xsh.x, 0.f); o.y = fmaxf(o.y * xsc.y + xsh.y, 0.f);
+                            o.z = fmaxf(o.z * xsc.z + xsh.z, 0.f); o.w = fmaxf(o.w * xsc.w + xsh.w, 0.f);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(&xt[(i / CQ) * XP + 4 * (i % CQ)]) = o;
+                } else xt[i] = xs[k];
             }
         }
 #pragma unroll
@@ -647,7 +694,7 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
     for (int i = tid; i < C::ROWSP * C::CGP / 4; i += 256) out[i] = reinterpret_cast<const float4*>(red)[i];
 }
 
-template <int CLS>
+template <int CLS, bool XF>
 __global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
     __shared__ __attribute__((aligned(16))) float lds[CLS == 0 ? WG2_LDS0 : WG2_LDS1];
     int li = -1;
@@ -658,14 +705,14 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
     const int wgl = blockIdx.x - L.wg0;
     if (CLS == 0) {
         switch (L.cfg) {
-            case 0: wg2_body<Wg2A>(L, wgl, lds); break;
-            case 1: wg2_body<Wg2B>(L, wgl, lds); break;
-            case 2: wg2_body<Wg2C>(L, wgl, lds); break;
-            default: wg2_body<Wg2D>(L, wgl, lds); break;
+            case 0: wg2_body<Wg2A, false>(L, wgl, lds); break;     // 3 input channels: an image, never a normalised tensor
+            case 1: wg2_body<Wg2B, XF>(L, wgl, lds); break;
+            case 2: wg2_body<Wg2C, XF>(L, wgl, lds); break;
+            default: wg2_body<Wg2D, XF>(L, wgl, lds); break;
         }
     } else {
-        if (L.cfg == 4) wg2_body<Wg2E>(L, wgl, lds);
-        else wg2_body<Wg2F>(L, wgl, lds);
+        if (L.cfg == 4) wg2_body<Wg2E, XF>(L, wgl, lds);
+        else wg2_body<Wg2F, XF>(L, wgl, lds);
     }
 }
 
@@ -739,6 +786,11 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
 
 template <int KS, int S, int CC>
 static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
+    if (a.slots && a.in_stats) {
+        if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true, true>), grid, dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true, true>), grid, dim3(256), 0, st, a);
+        return;
+    }
     if (a.slots) {
         if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true>), grid, dim3(256), 0, st, a);
         else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true>), grid, dim3(256), 0, st, a);
@@ -761,9 +813,10 @@ static void c2_fwd_pack_plan(int Cin, int Cout, int ks, int stride, Pack2dItem& 
 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
                         int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
-                        double* slots = nullptr, int nslots = 0, int imgs_per_group = 1, int ws_packed = 0) {
+                        double* slots = nullptr, int nslots = 0, int imgs_per_group = 1, int ws_packed = 0,
+                        const float* in_stats = nullptr) {
     Conv2dArgs a = {};
-    a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group;
+    a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group; a.in_stats = in_stats;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
     a.os = 1; a.py = 0; a.px = 0; a.YH = a.Ho; a.YW = a.Wo;
@@ -777,7 +830,10 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
             MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
-        if (slots) {
+        if (slots && in_stats) {
+            MVS_REQUIRE(cc == 8, MVS_ERR_UNSUPPORTED, "conv2d: a normalised input has a multiple of 4 channels, got %d", Cin);
+            MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true, true>), gridp, dim3(256), 0, st, a);
+        } else if (slots) {
             if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true, true>), gridp, dim3(256), 0, st, a);
             else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true>), gridp, dim3(256), 0, st, a);
         } else if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true>), gridp, dim3(256), 0, st, a);
@@ -830,6 +886,21 @@ extern "C" int mvs_conv2d_fwd_stats(const float* x, const float* w, float* y, fl
     MVS_REQUIRE(G >= 1 && N % G == 0 && nslots >= 1 && nslots <= 256 && (nslots & (nslots - 1)) == 0, MVS_ERR_SHAPE,
                 "conv2d_fwd_stats: %d images do not split into %d groups, or bad slot count %d", N, G, nslots);
     return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, slots, nslots, N / G, ws_packed);
+}
+
+// The same with x = the RAW output of the BatchNorm + ReLU block in front (its statistics finished by mvs_bn_finalize_slots into
+// in_stats [G][4][Cin]): relu(x * scale + shift) of x's own group is applied while the halo tile is staged -- the producing block
+// needs no apply pass (jdacs/models/module.py:21-22 `F.relu(self.bn(self.conv(x)))` of block i fused into block i+1's `self.conv`).
+extern "C" int mvs_conv2d_fwd_stats_xf(const float* x, const float* in_stats, const float* w, float* y, float* ws, double* slots,
+                                       int nslots, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, int ws_packed,
+                                       hipStream_t stream) {
+    int rc = c2_check("conv2d_fwd_stats_xf", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && in_stats && (w || ws_packed) && y && ws && slots, MVS_ERR_NULL, "conv2d_fwd_stats_xf: null pointer argument");
+    MVS_REQUIRE(G >= 1 && N % G == 0 && nslots >= 1 && nslots <= 256 && (nslots & (nslots - 1)) == 0, MVS_ERR_SHAPE,
+                "conv2d_fwd_stats_xf: %d images do not split into %d groups, or bad slot count %d", N, G, nslots);
+    MVS_REQUIRE((Cin & 3) == 0, MVS_ERR_UNSUPPORTED, "conv2d_fwd_stats_xf: input channels must be a multiple of 4, got %d", Cin);
+    return c2_run_igemm(x, w, nullptr, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, slots, nslots, N / G, ws_packed, in_stats);
 }
 
 // Forward weight images of n layers in ONE launch: w[n] (parameter tensors [Cout][Cin][ks][ks], or channels-last in memory when
@@ -1017,28 +1088,56 @@ extern "C" long long mvs_conv2d_wgrad_batch_workspace_floats(int n, const int* s
     return wg2_plan(n, shapes, b);
 }
 
-// gw[i] = weight gradient of layer i (x[i] [N,H,W,Cin], gy[i] [N,Ho,Wo,Cout], pad ks/2), written in the layout shapes[i][7] names
-extern "C" int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws,
-                                      const int* shapes, hipStream_t stream) {
+// gw[i] = weight gradient of layer i (x[i] [N,H,W,Cin], gy[i] [N,Ho,Wo,Cout], pad ks/2), written in the layout shapes[i][7] names.
+// x_stats (or null) / imgs_per_group: see mvs_conv2d_wgrad_batch_xf.
+static int wg2_run(int n, const float* const* x, const float* const* x_stats, int imgs_per_group, const float* const* gy,
+                   float* const* gw, float* ws, const int* shapes, hipStream_t stream) {
     MVS_REQUIRE(x && gy && gw && ws && shapes, MVS_ERR_NULL, "conv2d_wgrad_batch: null pointer argument");
     Wg2Batch b;
     const long long floats = wg2_plan(n, shapes, b);
     MVS_REQUIRE(floats >= 0, MVS_ERR_UNSUPPORTED, "conv2d_wgrad_batch: %d layers, or a layer shape without an instantiation", n);
     float* part = ws;
+    bool any_xf = false;
     for (int i = 0; i < n; ++i) {
         MVS_REQUIRE(x[i] && gy[i] && gw[i], MVS_ERR_NULL, "conv2d_wgrad_batch: null pointer for layer %d", i);
         Wg2Layer& L = b.l[i];
         L.x = x[i]; L.g = gy[i]; L.gw = gw[i]; L.part = part;
+        L.xstats = x_stats ? x_stats[i] : nullptr; L.ipg = imgs_per_group;
+        if (L.xstats) {
+            MVS_REQUIRE((L.CX & 3) == 0 && imgs_per_group >= 1 && L.N % imgs_per_group == 0, MVS_ERR_SHAPE,
+                        "conv2d_wgrad_batch_xf: layer %d: %d channels / %d images in groups of %d", i, L.CX, L.N, imgs_per_group);
+            any_xf = true;
+        }
         part += (size_t)L.nwg * L.rowsp * L.cgp;
     }
     int wgc[2] = {0, 0};
     for (int i = 0; i < n; ++i) wgc[wg2_class(b.l[i].cfg)] += b.l[i].nwg;
     // the wide layers first: few, long workgroups; the narrow layers' many short ones fill the GPU behind them
-    if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1>), dim3(wgc[1]), dim3(256), 0, stream, b);
-    if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0>), dim3(wgc[0]), dim3(256), 0, stream, b);
+    if (any_xf) {
+        if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1, true>), dim3(wgc[1]), dim3(256), 0, stream, b);
+        if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0, true>), dim3(wgc[0]), dim3(256), 0, stream, b);
+    } else {
+        if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1, false>), dim3(wgc[1]), dim3(256), 0, stream, b);
+        if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0, false>), dim3(wgc[0]), dim3(256), 0, stream, b);
+    }
     int rc = mvs_check_launch("conv2d_wgrad_batch");
     if (rc) return rc;
     const Wg2Layer& last = b.l[n - 1];
     MVS_LAUNCH(conv2d_wgrad_batch_reduce_kernel, dim3(last.rb0 + last.nrb), dim3(256), 0, stream, b);
     return mvs_check_launch("conv2d_wgrad_batch_reduce");
+}
+
+extern "C" int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws,
+                                      const int* shapes, hipStream_t stream) {
+    return wg2_run(n, x, nullptr, 1, gy, gw, ws, shapes, stream);
+}
+
+// The same where x[i] may be the RAW output of the BatchNorm + ReLU block in front of layer i: x_stats[i] [G][4][Cin] (mean, invstd,
+// scale, shift of that block, mvs_bn_finalize_slots; null = x[i] is used as it is), groups of imgs_per_group images -- the layer's
+// input relu(x * scale + shift) is formed while the halo is staged (the forward pass did the same: mvs_conv2d_fwd_stats_xf), so
+// the normalised activation exists nowhere in memory.
+extern "C" int mvs_conv2d_wgrad_batch_xf(int n, const float* const* x, const float* const* x_stats, int imgs_per_group,
+                                         const float* const* gy, float* const* gw, float* ws, const int* shapes, hipStream_t stream) {
+    MVS_REQUIRE(x_stats, MVS_ERR_NULL, "conv2d_wgrad_batch_xf: null pointer argument");
+    return wg2_run(n, x, x_stats, imgs_per_group, gy, gw, ws, shapes, stream);
 }

@@ -649,6 +649,18 @@ def bn_relu_fwd_slots(x, slots, gamma, beta, running_mean, running_var, eps, mom
     return y, stats
 
 
+def bn_finalize_slots(slots, gamma, beta, running_mean, running_var, eps, momentum, count_per_group):
+    """stats [groups, 4, C] (mean, invstd, scale, shift) + running-statistics update from the statistic slots [groups, nslots, 2, C]
+    of a tensor with `count_per_group` elements per channel and group -- bn_relu_fwd_slots without its elementwise pass (the
+    consumer applies the normalisation while it stages its input: conv2d_forward(in_stats=...), conv2d_wgrad_batch(x_stats=...))."""
+    lib = _lib_for(gamma)
+    groups, nslots, _, c = slots.shape
+    stats = torch.empty((groups, 4, c), dtype=torch.float32, device=gamma.device)
+    lib.call("mvs_bn_finalize_slots", _p(slots), nslots, groups, int(count_per_group), c, _p(gamma), _p(beta), float(eps), float(momentum),
+             _p(running_mean), _p(running_var), _p(stats), _stream(gamma))
+    return stats
+
+
 def bn_relu_bwd_slots(gy, x, stats, slots, have_stats, relu=True, groups=1):
     """BatchNorm(+ReLU) backward: (dx, dgamma, dbeta).  have_stats: the slots already hold (sum dyh, sum dyh*xhat) -- an
     input-gradient epilogue wrote them (conv3d_dgrad(bn=...)); otherwise one reduction pass over (gy, x) fills them first."""
@@ -998,6 +1010,11 @@ def _maybe_on_side_stream(fn, weight, inputs):
 # training extractor (FeatureExtractorFn): all layers' weight gradients through csrc/conv2d.hip's one-launch kernel (MVS_FEATURE_WGRAD_BATCH=0:
 # the library's per-layer weight gradients)
 FEATURE_WGRAD_BATCH = os.environ.get("MVS_FEATURE_WGRAD_BATCH", "1") != "0"
+# opt-in: consumer-side BatchNorm + ReLU in the training extractor -- 6 of its 7 apply passes and their outputs go away.  Built at the
+# end of round 4, parity-tested on the emulated kernels and on the GPU; ONE measurement (profiles/r04_run32_*): 5.2535 -> 5.2311 ms per
+# config-2 step, less than the ~60 us of apply passes it removes (the normalising weight-gradient kernel of the 32-channel layers
+# needs 272 registers: one wave per SIMD) -- not the default until that is trimmed and re-measured
+FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "0") == "1"
 
 
 class FeatureExtractorFn(torch.autograd.Function):
@@ -1020,19 +1037,33 @@ class FeatureExtractorFn(torch.autograd.Function):
         ws_, gammas, betas = [params[5 * i] for i in range(n)], [params[5 * i + 1] for i in range(n)], [params[5 * i + 2] for i in range(n)]
         fw, fb = params[5 * n], params[5 * n + 1]
         packed = pack_conv2d_weights(ws_, [c[0] for c in cfg], x)
+        # FEATURE_FUSED_APPLY: block i's BatchNorm + ReLU is applied by block i+1's convolution (forward AND weight gradient) while it
+        # stages its input -- no apply pass and no normalised copy for blocks 0 .. n-2; the last block's output is materialised for the
+        # closing (library) convolution.  Needs the one-launch weight gradients in the backward pass.
+        fused = bool(FEATURE_FUSED_APPLY and FEATURE_WGRAD_BATCH and n >= 2 and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_)))
         acts, raws, statss, slots_b = [x], [], [], []
         for i, (stride, padding, eps, momentum, hip_dgrad) in enumerate(cfg):
-            raw, slots = conv2d_forward(acts[-1], ws_[i], None, stride, want_stats=True, groups=groups, packed_ws=packed[i])
+            if fused and i > 0:
+                raw, slots = conv2d_forward(raws[-1], ws_[i], None, stride, want_stats=True, groups=groups, packed_ws=packed[i], in_stats=statss[-1])
+            else:
+                raw, slots = conv2d_forward(acts[-1], ws_[i], None, stride, want_stats=True, groups=groups, packed_ws=packed[i])
             c = raw.shape[1]
             (sb,) = stat_slots(x, groups, bn_nslots(lib, c), c, 1)
-            y, stats = bn_relu_fwd_slots(raw, slots, gammas[i], betas[i], params[5 * i + 3], params[5 * i + 4], eps, momentum, None, True, groups)
-            acts.append(y)
+            if fused and i < n - 1:
+                stats = bn_finalize_slots(slots, gammas[i], betas[i], params[5 * i + 3], params[5 * i + 4], eps, momentum,
+                                          raw.numel() // c // groups)
+            else:
+                y, stats = bn_relu_fwd_slots(raw, slots, gammas[i], betas[i], params[5 * i + 3], params[5 * i + 4], eps, momentum, None, True, groups)
+                acts.append(y)
             raws.append(raw)
             statss.append(stats)
             slots_b.append(sb)
         out = torch.ops.aten.convolution(acts[-1], fw, fb, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
-        ctx.cfg, ctx.groups, ctx.slots_used = cfg, groups, False
-        ctx.save_for_backward(fw, *ws_, *acts, *raws, *statss, *slots_b)
+        ctx.cfg, ctx.groups, ctx.slots_used, ctx.fused = cfg, groups, False, fused
+        if fused:       # acts = [x, y_last]
+            ctx.save_for_backward(fw, *ws_, acts[0], acts[-1], *raws, *statss, *slots_b)
+        else:
+            ctx.save_for_backward(fw, *ws_, *acts, *raws, *statss, *slots_b)
         return out
 
     @staticmethod
@@ -1041,8 +1072,16 @@ class FeatureExtractorFn(torch.autograd.Function):
         n = len(cfg)
         sv = ctx.saved_tensors
         fw, ws_ = sv[0], sv[1:1 + n]
-        acts = sv[1 + n:2 + 2 * n]
-        raws, statss, slots_b = sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n], sv[2 + 4 * n:2 + 5 * n]
+        if ctx.fused:
+            # the input of block i > 0 is relu(bn(raws[i-1])): never materialised; the library's input gradient only looks at its shape
+            x0, y_last = sv[1 + n], sv[2 + n]
+            raws, statss, slots_b = sv[3 + n:3 + 2 * n], sv[3 + 2 * n:3 + 3 * n], sv[3 + 3 * n:3 + 4 * n]
+            acts = [x0] + list(raws[:n - 1]) + [y_last]
+            x_stats = [None] + list(statss[:n - 1]) + [None]
+        else:
+            acts = sv[1 + n:2 + 2 * n]
+            raws, statss, slots_b = sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n], sv[2 + 4 * n:2 + 5 * n]
+            x_stats = None
         if ctx.slots_used:
             slots_b = [torch.zeros_like(t) for t in slots_b]
         ctx.slots_used = True
@@ -1053,8 +1092,11 @@ class FeatureExtractorFn(torch.autograd.Function):
         # weight gradients: all eight layers in ONE launch at the end (csrc/conv2d.hip conv2d_wgrad_batch_kernel; every layer's
         # input and output gradient is alive until then), unless a layer has no instantiation / FEATURE_WGRAD_BATCH is off ->
         # the library's, layer by layer
-        batch = (FEATURE_WGRAD_BATCH and all(need[3 + 5 * i] for i in range(n + 1)) and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))
+        batch = ((FEATURE_WGRAD_BATCH or ctx.fused) and all(need[3 + 5 * i] for i in range(n + 1)) and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))
                  and conv2d_wgrad_batch_serves(list(acts), list(ws_) + [fw], [c[0] for c in cfg] + [1]))
+        if ctx.fused and not batch:
+            raise RuntimeError("mvs_amd: FEATURE_FUSED_APPLY needs every convolution weight to require a gradient and a one-launch "
+                               "weight-gradient instantiation for every layer (the normalised activations were not kept)")
         draws = [None] * n
         if batch:
             g = bwd(gout, acts[n], fw, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
@@ -1081,7 +1123,7 @@ class FeatureExtractorFn(torch.autograd.Function):
                     g = gx
                 grads[5 * i] = gw
         if batch:
-            gws = conv2d_wgrad_batch(list(acts), draws + [gout], list(ws_) + [fw], [c[0] for c in cfg] + [1])
+            gws = conv2d_wgrad_batch(list(acts), draws + [gout], list(ws_) + [fw], [c[0] for c in cfg] + [1], x_stats, groups)
             for i in range(n + 1):
                 grads[5 * i] = gws[i]
         return (g if need[0] else None, None, None) + tuple(grads)
@@ -1402,10 +1444,11 @@ def _wgrad_batch_plan(lib, key):
     return ent
 
 
-def conv2d_wgrad_batch(xs, gys, weights, strides):
+def conv2d_wgrad_batch(xs, gys, weights, strides, x_stats=None, groups=1):
     """Weight gradients of several Conv2d layers (x_i channels-last [N,Cin,H,W], gy_i channels-last [N,Cout,Ho,Wo], pad k//2) in
     ONE launch + one reduction launch; -> gradients with the shape AND memory layout of `weights` (contiguous or channels-last
-    parameters alike, so autograd's AccumulateGrad takes them over without a copy)."""
+    parameters alike, so autograd's AccumulateGrad takes them over without a copy).  x_stats: per layer None or the [groups,4,Cin]
+    statistics of the BatchNorm + ReLU block whose RAW output x_i is (the layer's input is normalised while it is staged)."""
     lib = _lib_for(xs[0])
     xs, gys = [as_cl2(t) for t in xs], [as_cl2(t) for t in gys]
     shapes = _wgrad_batch_shapes(xs, weights, strides)
@@ -1414,15 +1457,29 @@ def conv2d_wgrad_batch(xs, gys, weights, strides):
         raise ValueError("conv2d_wgrad_batch: a layer of %s is not served" % ([tuple(w.shape) for w in weights],))
     ws = torch.empty(nfl, dtype=torch.float32, device=xs[0].device)
     gws = [torch.empty_like(w) for w in weights]       # preserve_format: the parameter's strides
+    if x_stats is not None and any(t is not None for t in x_stats):
+        n_img = xs[0].shape[0]
+        if n_img % groups or any(x.shape[0] != n_img for x in xs):
+            raise ValueError("conv2d_wgrad_batch: %d images do not split into %d groups" % (n_img, groups))
+        st = (C.c_void_p * len(xs))()
+        for i, (t, x) in enumerate(zip(x_stats, xs)):
+            if t is not None:
+                if tuple(t.shape) != (groups, 4, x.shape[1]) or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("conv2d_wgrad_batch: x_stats[%d] %s does not match %d groups of [4,%d]" % (i, tuple(t.shape), groups, x.shape[1]))
+                st[i] = t.data_ptr()
+        lib.call("mvs_conv2d_wgrad_batch_xf", len(xs), _ptr_array(xs), st, n_img // groups, _ptr_array(gys), _ptr_array(gws), _p(ws), arr,
+                 _stream(xs[0]))
+        return gws
     lib.call("mvs_conv2d_wgrad_batch", len(xs), _ptr_array(xs), _ptr_array(gys), _ptr_array(gws), _p(ws), arr, _stream(xs[0]))
     return gws
 
 
-def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1, packed_ws=None):
+def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_stats=False, groups=1, packed_ws=None, in_stats=None):
     """x [N,Cin,H,W] (channels_last), weight [Cout,Cin,k,k], pad k//2 -> y [N,Cout,Ho,Wo] (channels_last);
     negative_slope: LeakyReLU fused after the bias.  want_stats (no bias / activation): -> (y, slots [groups,nslots,2,Cout] fp64),
     the BatchNorm statistics of y summed by the convolution's epilogue, the N images being `groups` equal chunks (BnReLUFn's
-    ``slots``)."""
+    ``slots``).  in_stats [groups,4,Cin] (with want_stats): x is the RAW output of the BatchNorm + ReLU block in front and
+    relu(x * scale + shift) is applied while the kernel stages it (bn_finalize_slots made the statistics)."""
     lib = _lib_for(x)
     x = as_cl2(x)
     n, cin, h, w = x.shape
@@ -1432,14 +1489,21 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
     ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
     ws = _c2_ws(lib, 0, n, h, w, cin, cout, ks, stride, x) if packed_ws is None else packed_ws
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=CL2)
-    if packed_ws is not None and not want_stats:
-        raise ValueError("conv2d_forward: packed_ws serves the want_stats (training) form")
+    if (packed_ws is not None or in_stats is not None) and not want_stats:
+        raise ValueError("conv2d_forward: packed_ws / in_stats serve the want_stats (training) form")
     if want_stats:
         if bias is not None or negative_slope is not None:
             raise ValueError("conv2d_forward: statistics are those of the plain convolution (no bias / activation)")
         if n % groups:
             raise ValueError("conv2d_forward: %d images do not split into %d statistics groups" % (n, groups))
         (slots,) = stat_slots(x, groups, bn_nslots(lib, cout), cout, 1)
+        if in_stats is not None:
+            if tuple(in_stats.shape) != (groups, 4, cin) or in_stats.dtype != torch.float32 or not in_stats.is_contiguous():
+                raise ValueError("conv2d_forward: in_stats %s does not match %d groups of [4,%d]" % (tuple(in_stats.shape), groups, cin))
+            lib.call("mvs_conv2d_fwd_stats_xf", _p(x), _p(in_stats), _p(weight.contiguous() if packed_ws is None else weight), _p(y), _p(ws),
+                     _p(slots), slots.shape[1], groups, n, h, w, cin, cout, ks, stride, int(packed_ws is not None), _stream(x),
+                     tag="fwd2d_stats_xf:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+            return y, slots
         lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous() if packed_ws is None else weight), _p(y), _p(ws), _p(slots),
                  slots.shape[1], groups, n, h, w, cin, cout, ks, stride, int(packed_ws is not None), _stream(x),
                  tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))

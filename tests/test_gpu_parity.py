@@ -1147,6 +1147,42 @@ def test_featurenet_training_one_autograd_node_equals_per_block_graph(dev):
     assert not bad and not badbuf, (bad, badbuf)
 
 
+def test_featurenet_training_consumer_side_batchnorm(dev):
+    """Opt-in ops.FEATURE_FUSED_APPLY: BatchNorm + ReLU of block i applied inside block i+1's convolution and weight gradient
+    (mvs_bn_finalize_slots, mvs_conv2d_fwd_stats_xf, mvs_conv2d_wgrad_batch_xf; no apply pass, no normalised copy for six of the
+    seven blocks) against the default one-node path: outputs, input gradient, parameter gradients, running statistics; two steps."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(15)
+    a = FeatureNet().to(dev).train()
+    b = copy.deepcopy(a).train()
+    xa = torch.randn(3, 3, 72, 104, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = xa.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    old, old_async, old_fused = ops.FEATURE_FUSED_APPLY, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
+    try:
+        ops.set_async_wgrad(False)
+        for step in range(2):
+            ops.FEATURE_FUSED_APPLY = True
+            ya = a(xa, 3)
+            assert ya.grad_fn.fused
+            ya.square().mean().backward()
+            ops.FEATURE_FUSED_APPLY = False
+            yb = b(xb, 3)
+            assert not yb.grad_fn.fused
+            yb.square().mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.FEATURE_FUSED_APPLY = old
+        ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED = old_async, old_fused
+    assert float((ya - yb).abs().max()) < 1e-5 * max(1.0, float(yb.abs().max()))
+    assert rel_l1(xa.grad, xb.grad) < 1e-4
+    bad = {k: rel_l1(p.grad, q.grad) for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()) if not rel_l1(p.grad, q.grad) < 1e-4}
+    badbuf = [k for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers())
+              if not (torch.allclose(u, v, rtol=1e-5, atol=1e-6) if u.dtype.is_floating_point else bool((u == v).all()))]
+    assert not bad and not badbuf, (bad, badbuf)
+
+
 def test_featurenet_eval_folded_batchnorm_vs_stock(dev):
     """Inference FeatureNet (eval mode, no_grad): BatchNorm folded into the csrc/conv2d.hip convolutions (ConvBnReLU.fold_eval,
     the default) vs the unfolded path (MIOpen convolution + BatchNorm kernel) and vs the oracle's stock modules, 3 views 128x160
