@@ -5,6 +5,7 @@
 #   pmc      HBM traffic of the roofline kernels (tools/pmc_driver.py under rocprofv3 --pmc, separate passes)
 #   final    the closing sequence of a round: tests, smoke, default line, kernel table, configs 3-5, rocprofv3 stats of configs 2-5
 #   final2   the same without configs 4 / 5 (after a change to the training path only)
+#   next     first session of the next round: the opt-in consumer-side BatchNorm of the 2-D extractor and two balance knobs, 8 A/B pairs each
 # Outputs go to gpurun_out/ (merged back by gpurun); the ones worth keeping are copied to profiles/ by hand.
 # (The per-experiment sections of rounds 1-4 -- A/B pairs of individual knobs -- are in the git history of this file; an A/B is now
 #  `python bench.py --ab "<knob>=<value>;..."`: interleaved default / toggled runs inside one process.)
@@ -78,5 +79,10 @@ case "$what" in
     timeout 900 python bench.py --config 3 --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 > gpurun_out/final_bench_c3.json 2> gpurun_out/final_bench_c3.err
     echo "config 3 exit $?"; summarise gpurun_out/final_bench_c3.json
     for cfg in 2 3; do run_prof $cfg; done ;;
+  next)     # first session of round 5: what round 4 built last and measured once
+    run_tests
+    timeout 900 python bench.py --steps 20 --warmup 5 --step-events 1 $short --ab "feature_fused_apply;wgrad2d_batch=3072;wgrad8_groups=224" --ab-reps 8 \
+        > gpurun_out/next_bench.json 2> gpurun_out/next_bench.err; echo "bench exit $?"; summarise gpurun_out/next_bench.json
+    timeout 600 python tools/bench_conv2d.py > gpurun_out/conv2d_layers.log 2>&1; grep -v Warn gpurun_out/conv2d_layers.log | tail -16 ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
