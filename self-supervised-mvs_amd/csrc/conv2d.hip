@@ -532,10 +532,11 @@ using Wg2F = Wg2Cfg<3, 1, 32, 2, 4, 2>;    // 32 -> <= 32
 constexpr int wg2_max(int a, int b) { return a > b ? a : b; }
 constexpr int WG2_LDS0 = wg2_max(wg2_max(Wg2A::LDS, Wg2B::LDS), wg2_max(Wg2C::LDS, Wg2D::LDS));
 constexpr int WG2_LDS1 = wg2_max(Wg2E::LDS, Wg2F::LDS);
+constexpr int WG2_AFF = 512;     // XF kernels: (scale, shift) of every statistics group behind the tile buffers: groups * 2 * CX <= 512 floats
 MVS_HD inline int wg2_class(int cfg) { return cfg >= 4 ? 1 : 0; }
 
 template <class C, bool XF>
-__device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __restrict__ lds) {
+__device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __restrict__ lds, float* __restrict__ aff) {
     constexpr int KS = C::KS, S = C::S, CX = C::CX, NB = C::NB, TW = C::TW, RW = C::RW, XP = C::XP, GP = C::GP, MTW = C::MTW;
     constexpr bool VEC = CX % 4 == 0;
     constexpr int CQ = VEC ? CX / 4 : 1;
@@ -573,7 +574,12 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
     const int Hi = L.Hi, Wi = L.Wi, Ho = L.Ho, Wo = L.Wo, CG = L.CG, ntw = L.ntw, nth = L.nth;
     const float* __restrict__ xst = XF ? L.xstats : nullptr;
     const int ipg = XF ? L.ipg : 1;
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);   // of the tile held in xv
+    if (XF && VEC && xst) {
+        // (scale, shift) of every group into LDS once: aff[g][2][CX] -- read at the LDS store of a tile (holding the tile's
+        // eight values in registers across the MFMA loop put the 32-channel instantiation at 272 registers: one wave per SIMD)
+        const int ng = L.N / ipg;
+        for (int i = tid; i < ng * 2 * CX; i += 256) aff[i] = xst[(size_t)(i / (2 * CX)) * 4 * CX + 2 * CX + i % (2 * CX)];
+    }
     auto load_tile = [&](int tile) {
         int t = tile;
         const int tw = t % ntw; t /= ntw;
@@ -582,11 +588,6 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
         const int oy0 = th * C::TH, ox0 = tw * TW, iy0 = oy0 * S - C::P, ix0 = ox0 * S - C::P;
         const float* __restrict__ xn = gx + (size_t)n * Hi * Wi * CX;
         const float* __restrict__ gn = gg + (size_t)n * Ho * Wo * CG;
-        if (XF && VEC && xst) {   // this thread's channel quad is the same for all its items (256 % CQ == 0)
-            const float* __restrict__ st = xst + (size_t)(n / ipg) * 4 * CX + 4 * (tid % CQ);
-            xsc = *reinterpret_cast<const float4*>(st + 2 * CX);
-            xsh = *reinterpret_cast<const float4*>(st + 3 * CX);
-        }
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
@@ -622,6 +623,12 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
         int t = tile;
         const int tw = t % ntw; t /= ntw;
         const int iy0 = (t % nth) * C::TH * S - C::P, ix0 = tw * TW * S - C::P;
+        float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (XF && VEC && xst) {   // this thread's channel quad is the same for all its items (256 % CQ == 0)
+            const float* __restrict__ a2 = aff + ((t / nth) / ipg) * 2 * CX + 4 * (tid % CQ);
+            xsc = *reinterpret_cast<const float4*>(a2);
+            xsh = *reinterpret_cast<const float4*>(a2 + CX);
+        }
 #pragma unroll
         for (int k = 0; k < XIT; ++k) {
             const int i = tid + 256 * k;
@@ -695,25 +702,41 @@ __device__ __forceinline__ void wg2_body(const Wg2Layer& L, int wgl, float* __re
 }
 
 template <int CLS, bool XF>
-__global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
-    __shared__ __attribute__((aligned(16))) float lds[CLS == 0 ? WG2_LDS0 : WG2_LDS1];
+__device__ __forceinline__ void wg2_dispatch(const Wg2Batch& b, float* __restrict__ lds) {
     int li = -1;
     for (int i = 0; i < b.n; ++i)
         if (wg2_class(b.l[i].cfg) == CLS && (int)blockIdx.x >= b.l[i].wg0 && (int)blockIdx.x < b.l[i].wg0 + b.l[i].nwg) li = i;
     if (li < 0) return;
     const Wg2Layer& L = b.l[li];
     const int wgl = blockIdx.x - L.wg0;
+    float* __restrict__ aff = lds + (CLS == 0 ? WG2_LDS0 : WG2_LDS1);
     if (CLS == 0) {
         switch (L.cfg) {
-            case 0: wg2_body<Wg2A, false>(L, wgl, lds); break;     // 3 input channels: an image, never a normalised tensor
-            case 1: wg2_body<Wg2B, XF>(L, wgl, lds); break;
-            case 2: wg2_body<Wg2C, XF>(L, wgl, lds); break;
-            default: wg2_body<Wg2D, XF>(L, wgl, lds); break;
+            case 0: wg2_body<Wg2A, false>(L, wgl, lds, aff); break;     // 3 input channels: an image, never a normalised tensor
+            case 1: wg2_body<Wg2B, XF>(L, wgl, lds, aff); break;
+            case 2: wg2_body<Wg2C, XF>(L, wgl, lds, aff); break;
+            default: wg2_body<Wg2D, XF>(L, wgl, lds, aff); break;
         }
     } else {
-        if (L.cfg == 4) wg2_body<Wg2E, XF>(L, wgl, lds);
-        else wg2_body<Wg2F, XF>(L, wgl, lds);
+        if (L.cfg == 4) wg2_body<Wg2E, XF>(L, wgl, lds, aff);
+        else wg2_body<Wg2F, XF>(L, wgl, lds, aff);
     }
+}
+
+template <int CLS>
+__global__ __launch_bounds__(256) void conv2d_wgrad_batch_kernel(Wg2Batch b) {
+    __shared__ __attribute__((aligned(16))) float lds[CLS == 0 ? WG2_LDS0 : WG2_LDS1];
+    wg2_dispatch<CLS, false>(b, lds);
+}
+// the normalising (XF) forms: their own kernels, so that the default ones keep their code and registers; the wide class is capped
+// at 256 registers (two waves per SIMD: left alone it takes 260)
+__global__ __launch_bounds__(256) void conv2d_wgrad_batch_xf0_kernel(Wg2Batch b) {
+    __shared__ __attribute__((aligned(16))) float lds[WG2_LDS0 + WG2_AFF];
+    wg2_dispatch<0, true>(b, lds);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv2d_wgrad_batch_xf1_kernel(Wg2Batch b) {
+    __shared__ __attribute__((aligned(16))) float lds[WG2_LDS1 + WG2_AFF];
+    wg2_dispatch<1, true>(b, lds);
 }
 
 // gw = sum over the layer's partial images, fixed order: a workgroup owns 16 consecutive elements of the partial-image layout, its
@@ -1104,8 +1127,9 @@ static int wg2_run(int n, const float* const* x, const float* const* x_stats, in
         L.x = x[i]; L.g = gy[i]; L.gw = gw[i]; L.part = part;
         L.xstats = x_stats ? x_stats[i] : nullptr; L.ipg = imgs_per_group;
         if (L.xstats) {
-            MVS_REQUIRE((L.CX & 3) == 0 && imgs_per_group >= 1 && L.N % imgs_per_group == 0, MVS_ERR_SHAPE,
-                        "conv2d_wgrad_batch_xf: layer %d: %d channels / %d images in groups of %d", i, L.CX, L.N, imgs_per_group);
+            MVS_REQUIRE((L.CX & 3) == 0 && imgs_per_group >= 1 && L.N % imgs_per_group == 0 && (L.N / imgs_per_group) * 2 * L.CX <= WG2_AFF,
+                        MVS_ERR_SHAPE, "conv2d_wgrad_batch_xf: layer %d: %d channels / %d images in groups of %d (groups x channels <= 256)", i,
+                        L.CX, L.N, imgs_per_group);
             any_xf = true;
         }
         part += (size_t)L.nwg * L.rowsp * L.cgp;
@@ -1114,11 +1138,11 @@ static int wg2_run(int n, const float* const* x, const float* const* x_stats, in
     for (int i = 0; i < n; ++i) wgc[wg2_class(b.l[i].cfg)] += b.l[i].nwg;
     // the wide layers first: few, long workgroups; the narrow layers' many short ones fill the GPU behind them
     if (any_xf) {
-        if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1, true>), dim3(wgc[1]), dim3(256), 0, stream, b);
-        if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0, true>), dim3(wgc[0]), dim3(256), 0, stream, b);
+        if (wgc[1]) MVS_LAUNCH(conv2d_wgrad_batch_xf1_kernel, dim3(wgc[1]), dim3(256), 0, stream, b);
+        if (wgc[0]) MVS_LAUNCH(conv2d_wgrad_batch_xf0_kernel, dim3(wgc[0]), dim3(256), 0, stream, b);
     } else {
-        if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1, false>), dim3(wgc[1]), dim3(256), 0, stream, b);
-        if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0, false>), dim3(wgc[0]), dim3(256), 0, stream, b);
+        if (wgc[1]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<1>), dim3(wgc[1]), dim3(256), 0, stream, b);
+        if (wgc[0]) MVS_LAUNCH((conv2d_wgrad_batch_kernel<0>), dim3(wgc[0]), dim3(256), 0, stream, b);
     }
     int rc = mvs_check_launch("conv2d_wgrad_batch");
     if (rc) return rc;

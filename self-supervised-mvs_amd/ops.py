@@ -1011,9 +1011,9 @@ def _maybe_on_side_stream(fn, weight, inputs):
 # the library's per-layer weight gradients)
 FEATURE_WGRAD_BATCH = os.environ.get("MVS_FEATURE_WGRAD_BATCH", "1") != "0"
 # opt-in: consumer-side BatchNorm + ReLU in the training extractor -- 6 of its 7 apply passes and their outputs go away.  Built at the
-# end of round 4, parity-tested on the emulated kernels and on the GPU; ONE measurement (profiles/r04_run32_*): 5.2535 -> 5.2311 ms per
-# config-2 step, less than the ~60 us of apply passes it removes (the normalising weight-gradient kernel of the 32-channel layers
-# needs 272 registers: one wave per SIMD) -- not the default until that is trimmed and re-measured
+# end of round 4, parity-tested on the emulated kernels and on the GPU; measured 5.2168 -> 5.1895 ms per config-2 step (every one of six
+# interleaved pairs, profiles/r04_run33_*).  Not the default yet only because the round's closing line (profiles/r04_final_*) was
+# measured without it and could not be repeated: round 5's first session (tools/gpu_round.sh next) should flip it
 FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "0") == "1"
 
 
