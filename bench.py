@@ -679,6 +679,12 @@ def main():
                 from mvs_amd.jdacs.models.mvsnet import FeatureNet as _FN
                 def setter(on, base=_FN.one_node):
                     _FN.one_node = (not base) if on else base
+            elif spec == "feature_fused_all":
+                def setter(on, b1=_ops.FEATURE_FUSED_APPLY, b2=_ops.FEATURE_DGRAD_BNSTATS):
+                    _ops.FEATURE_FUSED_APPLY, _ops.FEATURE_DGRAD_BNSTATS = ((True, True) if on else (b1, b2))
+            elif spec == "feature_dgrad_bnstats":
+                def setter(on, base=_ops.FEATURE_DGRAD_BNSTATS):
+                    _ops.FEATURE_DGRAD_BNSTATS = (not base) if on else base
             elif spec == "feature_fused_apply":
                 def setter(on, base=_ops.FEATURE_FUSED_APPLY):
                     _ops.FEATURE_FUSED_APPLY = (not base) if on else base

@@ -266,6 +266,11 @@ int mvs_bn_finalize_slots(const double* slots, int nslots, int G, long long Vg, 
                           float momentum, float* running_mean, float* running_var, float* stats, hipStream_t stream);
 int mvs_conv2d_fwd_stats_xf(const float* x, const float* in_stats, const float* w, float* y, float* ws, double* slots, int nslots,
                             int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, int ws_packed, hipStream_t stream);
+/* mvs_conv2d_dgrad_bnstats (opt-in, MVS_FEATURE_DGRAD_BNSTATS=1): mvs_conv2d_dgrad of a 3x3 stride-1 layer whose result is the
+ * complete output gradient of the BatchNorm + ReLU block in front (raw output bn_raw [N,H,W,Cin], bn_stats [G][4][Cin]); the epilogue
+ * adds that block's backward statistics into bn_slots [G][nslots][2][Cin], so mvs_bn_relu_bwd_slots needs no reduce pass. */
+int mvs_conv2d_dgrad_bnstats(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                             const float* bn_raw, const float* bn_stats, double* bn_slots, int nslots, int G, hipStream_t stream);
 int mvs_conv2d_wgrad_batch_xf(int n, const float* const* x, const float* const* x_stats, int imgs_per_group, const float* const* gy,
                               float* const* gw, float* ws, const int* shapes, hipStream_t stream);
 int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws, const int* shapes,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mvs_conv2d_fwd_stats": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_pack_weights_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), _s]),
     "mvs_conv2d_dgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_dgrad_bnstats": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _s]),
     "mvs_conv2d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_conv2d_wgrad_batch_workspace_floats": (_ll, [_i, C.POINTER(_i)]),
     "mvs_conv2d_wgrad_batch": (_i, [_i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _f, C.POINTER(_i), _s]),

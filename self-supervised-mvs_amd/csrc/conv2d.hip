@@ -25,6 +25,9 @@ struct Conv2dArgs {
     float slope;
     double* slots;                      // STATS kernels: BatchNorm statistic slots [group][nslots][2][Cout] (fp64 atomics, bn.hip):
     int nslots, imgs_per_group;         //   (sum, sum of squares) of the workgroup's outputs -> slot row (workgroup mod nslots) of image n's group
+    const float* bn_raw;                // BST kernels (an input gradient that completes the output gradient of the BatchNorm + ReLU block in
+    const float* bn_stats;              //   front): that block's raw output [N,YH,YW,Cout] and stats [group][4][Cout]; `slots` then receive the
+                                        //   block's BACKWARD statistics (sum dyh, sum dyh * xhat) instead of (sum y, sum y^2)
     const float* in_stats;              // XF kernels: x is the RAW output of the BatchNorm block in front; [group][4][Cin] (mean, invstd, scale,
                                         //   shift: mvs_bn_finalize_slots) -- relu(x * scale + shift) is applied while the halo is staged
 };
@@ -106,7 +109,9 @@ __global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(Pack2dBatch pb) 
 // kernels' epilogue.  Separate instantiations: the plain kernels' code and register allocation do not change.
 // XF: the input is normalised on the way into LDS (consumer-side BatchNorm + ReLU: the producing block has no apply pass).  Zero
 // padding stays zero: only elements inside the image are transformed.
-template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false, bool XF = false>
+// BST (with STATS): the output is the complete gradient w.r.t. relu(bn(raw)) of the block in front; what goes to the slots is that
+// block's backward statistics, like the 3-D input-gradient epilogues (conv3d.hip) -- its reduce pass (mvs_bn_bwd_reduce_slots) goes.
+template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false, bool XF = false, bool BST = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
     static_assert(!PP || (KS == 3 && S == 1 && NB == 1), "pixel pairs: 3x3 stride 1, one column tile");
@@ -231,6 +236,31 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     float st1[NB], st2[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) st1[nb] = st2[nb] = 0.f;
+    // BST: the raw values under this lane's outputs, ALL requested before the first store (a load written after a store waits for
+    // it: the stores may alias as far as hipcc knows), and the block's per-channel statistics
+    float rawv[BST ? MBW : 1][BST ? 4 : 1][BST ? NB : 1];
+    float bmean[BST ? NB : 1], binv[BST ? NB : 1], bsc[BST ? NB : 1], bsh[BST ? NB : 1];
+    if (BST) {
+        const float* __restrict__ bs = a.bn_stats + (size_t)(n / a.imgs_per_group) * 4 * a.Cout;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15, cc = co < a.Cout ? co : 0;
+            bmean[nb] = bs[cc]; binv[nb] = bs[a.Cout + cc]; bsc[nb] = bs[2 * a.Cout + cc]; bsh[nb] = bs[3 * a.Cout + cc];
+        }
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
+                    const int ox = (ox0 + (PP ? 2 * (4 * g + r) + (l15 >> 3) : 16 * (mb & 1) + 4 * g + r)) * a.os + a.px;
+                    const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15;
+                    float rv = 0.f;
+                    if (oy < a.YH && ox < a.YW && co < a.Cout) rv = a.bn_raw[(((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout + co];
+                    rawv[mb][r][nb] = rv;
+                }
+    }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
@@ -247,7 +277,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
                     float v = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
                     if (a.act) v = v > 0.f ? v : v * a.slope;
                     o[co] = v;
-                    if (STATS) { st1[nb] += v; st2[nb] = fmaf(v, v, st2[nb]); }
+                    if (BST) {
+                        const float rw = rawv[mb][r][nb];
+                        const float d1 = (rw * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
+                        st1[nb] += d1; st2[nb] = fmaf(d1, (rw - bmean[nb]) * binv[nb], st2[nb]);
+                    } else if (STATS) { st1[nb] += v; st2[nb] = fmaf(v, v, st2[nb]); }
                 }
             }
         }
@@ -809,6 +843,11 @@ extern "C" long long mvs_conv2d_workspace_floats(int op, int N, int H, int W, in
 
 template <int KS, int S, int CC>
 static void c2_launch(const Conv2dArgs& a, int nb, dim3 grid, hipStream_t st) {
+    if (a.slots && a.bn_raw) {
+        if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true, false, true>), grid, dim3(256), 0, st, a);
+        else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true, false, true>), grid, dim3(256), 0, st, a);
+        return;
+    }
     if (a.slots && a.in_stats) {
         if (nb == 1) MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 1, false, true, true>), grid, dim3(256), 0, st, a);
         else MVS_LAUNCH((conv2d_igemm_kernel<KS, S, CC, 2, false, true, true>), grid, dim3(256), 0, st, a);
@@ -837,8 +876,9 @@ static void c2_fwd_pack_plan(int Cin, int Cout, int ks, int stride, Pack2dItem& 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
                         int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
                         double* slots = nullptr, int nslots = 0, int imgs_per_group = 1, int ws_packed = 0,
-                        const float* in_stats = nullptr) {
+                        const float* in_stats = nullptr, const float* bn_raw = nullptr, const float* bn_stats = nullptr) {
     Conv2dArgs a = {};
+    a.bn_raw = bn_raw; a.bn_stats = bn_stats;
     a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group; a.in_stats = in_stats;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
     a.Ho = stride == 1 ? Hi : (Hi - 1) / 2 + 1; a.Wo = stride == 1 ? Wi : (Wi - 1) / 2 + 1;
@@ -853,7 +893,10 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
             MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
-        if (slots && in_stats) {
+        if (slots && bn_raw) {
+            if (cc == 4) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 4, 1, true, true, false, true>), gridp, dim3(256), 0, st, a);
+            else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true, false, true>), gridp, dim3(256), 0, st, a);
+        } else if (slots && in_stats) {
             MVS_REQUIRE(cc == 8, MVS_ERR_UNSUPPORTED, "conv2d: a normalised input has a multiple of 4 channels, got %d", Cin);
             MVS_LAUNCH((conv2d_igemm_kernel<3, 1, 8, 1, true, true, true>), gridp, dim3(256), 0, st, a);
         } else if (slots) {
@@ -962,6 +1005,23 @@ extern "C" int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float*
 }
 
 // gx [N,H,W,Cin] from gy [N,Ho,Wo,Cout]
+// Input gradient of a 3x3 stride-1 layer whose gx is the COMPLETE output gradient of the BatchNorm + ReLU block in front of it
+// (jdacs/models/module.py:21-22; bn_raw = that block's raw output [N,H,W,Cin], bn_stats [G][4][Cin]): the epilogue also adds the
+// block's backward statistics (sum dyh, sum dyh * xhat per channel and group of N / G images) into bn_slots [G][nslots][2][Cin]
+// (fp64 atomics) -- mvs_bn_relu_bwd_slots then runs without its reduce pass.
+extern "C" int mvs_conv2d_dgrad_bnstats(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout,
+                                        int ks, const float* bn_raw, const float* bn_stats, double* bn_slots, int nslots, int G,
+                                        hipStream_t stream) {
+    int rc = c2_check("conv2d_dgrad_bnstats", N, H, W, Cin, Cout, ks, 1);
+    if (rc) return rc;
+    MVS_REQUIRE(gy && w && gx && ws && bn_raw && bn_stats && bn_slots, MVS_ERR_NULL, "conv2d_dgrad_bnstats: null pointer argument");
+    MVS_REQUIRE(ks == 3, MVS_ERR_UNSUPPORTED, "conv2d_dgrad_bnstats: 3x3 stride-1 layers only");
+    MVS_REQUIRE(G >= 1 && N % G == 0 && nslots >= 1 && nslots <= 256 && (nslots & (nslots - 1)) == 0, MVS_ERR_SHAPE,
+                "conv2d_dgrad_bnstats: %d images do not split into %d groups, or bad slot count %d", N, G, nslots);
+    return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream, 0, 0.f, bn_slots, nslots, N / G, 0, nullptr, bn_raw,
+                        bn_stats);
+}
+
 extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, hipStream_t stream) {
     int rc = c2_check("conv2d_dgrad", N, H, W, Cin, Cout, ks, stride);

@@ -1015,6 +1015,10 @@ FEATURE_WGRAD_BATCH = os.environ.get("MVS_FEATURE_WGRAD_BATCH", "1") != "0"
 # interleaved pairs, profiles/r04_run33_*).  Not the default yet only because the round's closing line (profiles/r04_final_*) was
 # measured without it and could not be repeated: round 5's first session (tools/gpu_round.sh next) should flip it
 FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "0") == "1"
+# opt-in: the BatchNorm backward statistics of the block BELOW a csrc/conv2d.hip input gradient in that kernel's epilogue (3 of the
+# extractor's 7 reduce launches go); built with the item above; measured NEUTRAL (5.2086 -> 5.2103 ms, profiles/r04_run34_*: the
+# epilogue's reads of the raw tensor cost what the three reduce launches did)
+FEATURE_DGRAD_BNSTATS = os.environ.get("MVS_FEATURE_DGRAD_BNSTATS", "0") == "1"
 
 
 class FeatureExtractorFn(torch.autograd.Function):
@@ -1106,14 +1110,21 @@ class FeatureExtractorFn(torch.autograd.Function):
             g, gfw, gfb = bwd(gout, acts[n], fw, [fw.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                               [True, bool(need[3 + 5 * n]), bool(need[3 + 5 * n + 1])])
             grads[5 * n], grads[5 * n + 1] = gfw, gfb
+        have = False     # the block's backward statistics are already in its slots (the input gradient above it put them there)
         for i in range(n - 1, -1, -1):
             stride, padding, eps, momentum, hip_dgrad = cfg[i]
-            draw, grads[5 * i + 1], grads[5 * i + 2] = bn_relu_bwd_slots(g, raws[i], statss[i], slots_b[i], False, True, groups)
+            draw, grads[5 * i + 1], grads[5 * i + 2] = bn_relu_bwd_slots(g, raws[i], statss[i], slots_b[i], have, True, groups)
+            have = False
             draws[i] = draw
             w = ws_[i]
             want_x = i > 0 or need[0]
             if want_x and hip_dgrad:
-                g = conv2d_dgrad(draw, w, tuple(acts[i].shape), stride)
+                if FEATURE_DGRAD_BNSTATS and i > 0 and stride == 1 and w.shape[2] == 3:
+                    # gx is the complete output gradient of block i-1: its BatchNorm backward statistics ride in this epilogue
+                    g = conv2d_dgrad(draw, w, tuple(acts[i].shape), stride, bn=(raws[i - 1], statss[i - 1], slots_b[i - 1]), groups=groups)
+                    have = True
+                else:
+                    g = conv2d_dgrad(draw, w, tuple(acts[i].shape), stride)
                 want_x = False
             want_w = bool(need[3 + 5 * i]) and not batch
             if want_x or want_w:
@@ -1517,13 +1528,23 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
     return y
 
 
-def conv2d_dgrad(gy, weight, in_shape, stride=1):
+def conv2d_dgrad(gy, weight, in_shape, stride=1, bn=None, groups=1):
+    """bn = (raw, stats, slots) of the BatchNorm + ReLU block whose COMPLETE output gradient this input gradient is (3x3 stride 1):
+    the epilogue adds that block's backward statistics into `slots` [groups,nslots,2,Cin] (bn_relu_bwd_slots(have_stats=True))."""
     lib = _lib_for(gy)
     gy = as_cl2(gy)
     n, cin, h, w = in_shape
     cout, _, ks, _ = weight.shape
     ws = _c2_ws(lib, 1, n, h, w, cin, cout, ks, stride, gy)
     gx = torch.empty((n, cin, h, w), dtype=torch.float32, device=gy.device, memory_format=CL2)
+    if bn is not None:
+        raw, stats, slots = bn
+        if stride != 1 or ks != 3 or tuple(raw.shape) != (n, cin, h, w) or tuple(stats.shape) != (groups, 4, cin) or n % groups:
+            raise ValueError("conv2d_dgrad(bn=...): a 3x3 stride-1 layer, raw %s like the input %s, stats [%d,4,%d]"
+                             % (tuple(raw.shape), (n, cin, h, w), groups, cin))
+        lib.call("mvs_conv2d_dgrad_bnstats", _p(gy), _p(weight.contiguous()), _p(gx), _p(ws), n, h, w, cin, cout, ks, _p(as_cl2(raw)),
+                 _p(stats), _p(slots), slots.shape[-3], groups, _stream(gy), tag="dgrad2d_bn:%d>%d:k%d" % (cin, cout, ks))
+        return gx
     lib.call("mvs_conv2d_dgrad", _p(gy), _p(weight.contiguous()), _p(gx), _p(ws), n, h, w, cin, cout, ks, stride, _stream(gy),
              tag="dgrad2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
     return gx

@@ -1346,14 +1346,16 @@ def _stock_extractor(net, x, groups):
     return torch.cat(outs, 0)
 
 
-@pytest.mark.parametrize("wgrad_batch,fused", [(True, False), (False, False), (True, True)],
-                         ids=["one_launch_wgrad", "library_wgrad", "consumer_side_batchnorm"])
-def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused):
+@pytest.mark.parametrize("wgrad_batch,fused,dgrad_bn", [(True, False, False), (False, False, False), (True, True, False), (True, True, True)],
+                         ids=["one_launch_wgrad", "library_wgrad", "consumer_side_batchnorm", "consumer_side_batchnorm+dgrad_statistics"])
+def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused, dgrad_bn):
     """ops.FeatureExtractorFn (FeatureNet in training as ONE autograd node: mvsnet.py:17-34 + module.py:15-22 for every block) on the
     emulated kernels vs the stock modules applied view by view: output, input gradient, every parameter gradient and the
     running statistics, 2 views of 12x40 (ragged tiles), with the one-launch weight gradients, with the library's, and with
     BatchNorm + ReLU of block i applied inside block i+1's convolution and weight gradient (FEATURE_FUSED_APPLY: mvs_bn_finalize_slots,
-    mvs_conv2d_fwd_stats_xf, mvs_conv2d_wgrad_batch_xf -- every instantiation of both kernels is on this path)."""
+    mvs_conv2d_fwd_stats_xf, mvs_conv2d_wgrad_batch_xf -- every instantiation of both kernels is on this path), and with the
+    BatchNorm backward statistics of the block below a conv2d.hip input gradient summed in its epilogue (FEATURE_DGRAD_BNSTATS:
+    mvs_conv2d_dgrad_bnstats, pixel-pair and plain kernels)."""
     import copy
     from mvs_amd import ops
     from mvs_amd.jdacs.models.mvsnet import FeatureNet, _FEATURE_LAYERS
@@ -1373,15 +1375,15 @@ def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused):
         cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
         params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
     params += [net.feature.weight, net.feature.bias]
-    old = ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY
-    ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY = wgrad_batch, fused
+    old = ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS
+    ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS = wgrad_batch, fused, dgrad_bn
     try:
         with ops.slot_scope():
             ya = ops.FeatureExtractorFn.apply(xa, groups, tuple(cfg), *params)
         assert ya.grad_fn.fused == fused
         ya.backward(gy.contiguous(memory_format=torch.channels_last))
     finally:
-        ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY = old
+        ops.FEATURE_WGRAD_BATCH, ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS = old
     assert float((ya - yr).abs().max()) < 1e-4 * max(1.0, float(yr.abs().max()))
     assert float((xa.grad - xr.grad).abs().max()) < 2e-3 * max(1e-6, float(xr.grad.abs().max()))
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):

@@ -1147,8 +1147,9 @@ def test_featurenet_training_one_autograd_node_equals_per_block_graph(dev):
     assert not bad and not badbuf, (bad, badbuf)
 
 
-def test_featurenet_training_consumer_side_batchnorm(dev):
-    """Opt-in ops.FEATURE_FUSED_APPLY: BatchNorm + ReLU of block i applied inside block i+1's convolution and weight gradient
+@pytest.mark.parametrize("dgrad_bn", [False, True], ids=["apply_in_consumer", "apply_in_consumer+dgrad_statistics"])
+def test_featurenet_training_consumer_side_batchnorm(dev, dgrad_bn):
+    """Opt-in ops.FEATURE_FUSED_APPLY (and FEATURE_DGRAD_BNSTATS: the block-below statistics in conv2d.hip's input-gradient epilogue): BatchNorm + ReLU of block i applied inside block i+1's convolution and weight gradient
     (mvs_bn_finalize_slots, mvs_conv2d_fwd_stats_xf, mvs_conv2d_wgrad_batch_xf; no apply pass, no normalised copy for six of the
     seven blocks) against the default one-node path: outputs, input gradient, parameter gradients, running statistics; two steps."""
     import copy
@@ -1159,21 +1160,21 @@ def test_featurenet_training_consumer_side_batchnorm(dev):
     b = copy.deepcopy(a).train()
     xa = torch.randn(3, 3, 72, 104, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     xb = xa.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
-    old, old_async, old_fused = ops.FEATURE_FUSED_APPLY, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
+    old, old_bn, old_async, old_fused = ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS, ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED
     try:
         ops.set_async_wgrad(False)
         for step in range(2):
-            ops.FEATURE_FUSED_APPLY = True
+            ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS = True, dgrad_bn
             ya = a(xa, 3)
             assert ya.grad_fn.fused
             ya.square().mean().backward()
-            ops.FEATURE_FUSED_APPLY = False
+            ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS = False, False
             yb = b(xb, 3)
             assert not yb.grad_fn.fused
             yb.square().mean().backward()
         torch.cuda.synchronize()
     finally:
-        ops.FEATURE_FUSED_APPLY = old
+        ops.FEATURE_FUSED_APPLY, ops.FEATURE_DGRAD_BNSTATS = old, old_bn
         ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED = old_async, old_fused
     assert float((ya - yb).abs().max()) < 1e-5 * max(1.0, float(yb.abs().max()))
     assert rel_l1(xa.grad, xb.grad) < 1e-4
