@@ -1010,11 +1010,12 @@ def _maybe_on_side_stream(fn, weight, inputs):
 # training extractor (FeatureExtractorFn): all layers' weight gradients through csrc/conv2d.hip's one-launch kernel (MVS_FEATURE_WGRAD_BATCH=0:
 # the library's per-layer weight gradients)
 FEATURE_WGRAD_BATCH = os.environ.get("MVS_FEATURE_WGRAD_BATCH", "1") != "0"
-# opt-in: consumer-side BatchNorm + ReLU in the training extractor -- 6 of its 7 apply passes and their outputs go away.  Built at the
-# end of round 4, parity-tested on the emulated kernels and on the GPU; measured 5.2168 -> 5.1895 ms per config-2 step (every one of six
-# interleaved pairs, profiles/r04_run33_*).  Not the default yet only because the round's closing line (profiles/r04_final_*) was
-# measured without it and could not be repeated: round 5's first session (tools/gpu_round.sh next) should flip it
-FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "0") == "1"
+# consumer-side BatchNorm + ReLU in the training extractor -- 6 of its 7 apply passes and their outputs go away.  Built at the end of
+# round 4, parity-tested on the emulated kernels and on the GPU (incl. the full-size config-2 / config-3 steps against the oracle);
+# measured 5.2168 -> 5.1895 and 5.2086 -> 5.1804 ms per config-2 step, every one of 6 + 5 interleaved pairs (profiles/r04_run33_*,
+# r04_run34_*).  ON by default since the round's very last commit -- AFTER the closing line of profiles/r04_final_* (5.238 ms), which
+# was measured without it.  MVS_FEATURE_FUSED_APPLY=0 restores the apply passes.
+FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "1") != "0"
 # opt-in: the BatchNorm backward statistics of the block BELOW a csrc/conv2d.hip input gradient in that kernel's epilogue (3 of the
 # extractor's 7 reduce launches go); built with the item above; measured NEUTRAL (5.2086 -> 5.2103 ms, profiles/r04_run34_*: the
 # epilogue's reads of the raw tensor cost what the three reduce launches did)
