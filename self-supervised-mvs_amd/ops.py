@@ -1045,7 +1045,9 @@ class FeatureExtractorFn(torch.autograd.Function):
         # FEATURE_FUSED_APPLY: block i's BatchNorm + ReLU is applied by block i+1's convolution (forward AND weight gradient) while it
         # stages its input -- no apply pass and no normalised copy for blocks 0 .. n-2; the last block's output is materialised for the
         # closing (library) convolution.  Needs the one-launch weight gradients in the backward pass.
-        fused = bool(FEATURE_FUSED_APPLY and FEATURE_WGRAD_BATCH and n >= 2 and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_)))
+        # (the normalising weight-gradient kernel keeps every group's scale / shift in 512 floats of LDS: groups x channels <= 256)
+        fused = bool(FEATURE_FUSED_APPLY and FEATURE_WGRAD_BATCH and n >= 2 and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))
+                     and groups * max(w.shape[1] for w in ws_) <= 256 and all(need for need in ctx.needs_input_grad[3::5][:n + 1]))
         acts, raws, statss, slots_b = [x], [], [], []
         for i, (stride, padding, eps, momentum, hip_dgrad) in enumerate(cfg):
             if fused and i > 0:

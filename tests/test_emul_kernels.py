@@ -1395,6 +1395,39 @@ def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused, d
             assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), k
 
 
+def test_training_extractor_with_a_frozen_weight_keeps_its_activations(emul_lib):
+    """A convolution weight that needs no gradient (fine-tuning with a frozen layer): the node does not take the consumer-side
+    BatchNorm path (whose backward has no normalised activations to hand to the library's per-layer weight gradients) and the
+    other parameters still get the stock gradients."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet, _FEATURE_LAYERS
+    torch.manual_seed(5)
+    ref = FeatureNet().train()
+    net = copy.deepcopy(ref)
+    for m in (ref, net):
+        m.conv3.conv.weight.requires_grad_(False)
+    x = torch.randn(1, 3, 8, 36)
+    yr = _stock_extractor(ref, x, 1)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(6))
+    yr.backward(gy)
+    blocks = [getattr(net, name) for name, *_ in _FEATURE_LAYERS]
+    cfg, params = [], []
+    for m in blocks:
+        cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
+        params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+    params += [net.feature.weight, net.feature.bias]
+    assert ops.FEATURE_FUSED_APPLY and ops.FEATURE_WGRAD_BATCH       # the defaults
+    with ops.slot_scope():
+        ya = ops.FeatureExtractorFn.apply(x.contiguous(memory_format=torch.channels_last), 1, tuple(cfg), *params)
+    assert not ya.grad_fn.fused
+    ya.backward(gy.contiguous(memory_format=torch.channels_last))
+    assert net.conv3.conv.weight.grad is None
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert float((p.grad - q.grad).abs().max()) < 2e-3 * max(1e-6, float(q.grad.abs().max())), k
+
+
 WGRAD_BATCH_LAYERS = [  # (Cin, Cout, ks, stride, weight channels-last): the six instantiations of conv2d_wgrad_batch_kernel
     (3, 8, 3, 1, False), (8, 8, 3, 1, True), (8, 16, 5, 2, False), (16, 16, 3, 1, True), (16, 32, 5, 2, True), (32, 32, 3, 1, False)]
 
