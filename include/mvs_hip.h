@@ -43,6 +43,7 @@ int mvs_is_emulation(void);         /* 0 in the product library */
  * "conv_split", "conv_small", "conv_small_wgs", "tr2pw", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups".
  * Process-wide, not part of the data path's contract. */
 int mvs_set_tuning(const char* key, int value);
+int mvs_get_tuning(const char* key, int* value);   /* the knob's current value (a freshly loaded library: its default) */
 
 /* ---- K1/K2: homography warp + variance cost volume -------------------------------------------
  * Replaces homo_warping + the sum / sum-of-squares / variance chain:

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mvs_last_error": (C.c_char_p, []),
     "mvs_is_emulation": (_i, []),
     "mvs_set_tuning": (_i, [C.c_char_p, _i]),
+    "mvs_get_tuning": (_i, [C.c_char_p, C.POINTER(_i)]),
     "mvs_plane_sweep_variance_fwd": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_plane_sweep_variance_fwd_bf16": (_i, [_f, C.POINTER(C.c_void_p), _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _s]),
     "mvs_conv3d_bf16_workspace_bytes": (_ll, [_i] * 4),

@@ -98,3 +98,23 @@ def test_error_convention_of_every_entry_point():
     # unknown tuning key
     with pytest.raises(ValueError, match="unknown key"):
         lib.call("mvs_set_tuning", b"zz_no_such_knob", 1)
+
+
+def test_default_tuning_table_matches_the_library():
+    """_lib.DEFAULT_TUNING (what `bench.py --ab key=value` restores after a toggled run, and what MVS_TUNING overrides) against the
+    values a freshly loaded library reports through mvs_get_tuning: a knob whose compiled default moved without the table makes
+    every later A/B "default" run something else."""
+    import ctypes as C
+    from mvs_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = _lib.MvsLib()       # a fresh handle: the same process-wide globals, which no test leaves changed
+    bad = {}
+    for key, want in _lib.DEFAULT_TUNING.items():
+        got = C.c_int(-12345)
+        lib.call("mvs_get_tuning", key.encode(), C.byref(got))
+        if got.value != want:
+            bad[key] = (got.value, want)
+    assert not bad, "library default != _lib.DEFAULT_TUNING: %r" % bad
+    with pytest.raises(ValueError, match="unknown key"):
+        lib.call("mvs_get_tuning", b"no_such_knob", C.byref(C.c_int()))
