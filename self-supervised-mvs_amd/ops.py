@@ -1451,11 +1451,12 @@ def conv2d_wgrad_batch_serves(xs, weights, strides) -> bool:
 
 
 def _wgrad_batch_plan(lib, key):
-    ent = _WGRAD_BATCH_PLANS.get((id(lib), key))
-    if ent is None:
-        arr = (C.c_int * len(key))(*key)
-        ent = _WGRAD_BATCH_PLANS[(id(lib), key)] = (int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", len(key) // 8, arr)), arr)
-    return ent
+    """(workspace floats, the shapes as a C array).  Only the array is cached: the size depends on the library's "wgrad2d_batch" knob
+    and is asked for on every call (a stale, smaller size after a knob change would let the kernel write past the workspace)."""
+    arr = _WGRAD_BATCH_PLANS.get(key)
+    if arr is None:
+        arr = _WGRAD_BATCH_PLANS[key] = (C.c_int * len(key))(*key)
+    return int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", len(key) // 8, arr)), arr
 
 
 def conv2d_wgrad_batch(xs, gys, weights, strides, x_stats=None, groups=1):
