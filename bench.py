@@ -331,6 +331,12 @@ def main():
     ap.add_argument("--defer-join", type=int, default=1,
                     help="1: join the regulariser's side-stream weight gradients at the end of the backward pass (this loop has no "
                          "gradient hooks); 0: inside the regulariser node (the library default)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the nccl (== RCCL) process group even at world size 1 and run the gradient bucket's all-reduce "
+                         "inside every step: RCCL init + one ncclAllReduce of the flat bucket execute on a 1-GPU box")
+    ap.add_argument("--sustained", type=int, default=0,
+                    help="after everything else: this many MORE steps in the headline's mode with the garbage collector ON, reported "
+                         "as ms_per_step_sustained (never the headline)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check (tests, no GPU needed): start the ranks, all-reduce one number over gloo, print it, exit")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -370,7 +376,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    rank, world, local = mdist.init_from_env("nccl")
+    rank, world, local = mdist.init_from_env("nccl", force=args.force_collective)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
@@ -433,6 +439,7 @@ def main():
         if train:
             # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
             bucket = mdist.FlatGradBucket(net.parameters(), flatten_params=True)
+            bucket.force_collective = bool(args.force_collective)
             # capturable: the step counter lives on the GPU, so a captured optimizer step stays correct when replayed
             # (as 32 slices of the flat store: a fused multi-tensor optimiser runs one workgroup per tensor chunk)
             opt = torch.optim.Adam(bucket.optimizer_params(32), lr=1e-4, betas=(0.9, 0.999), fused=True, capturable=args.graph != 0)
@@ -611,7 +618,24 @@ def main():
     # the same K steps with the OTHER weight-gradient mode (the library default is synchronous: what the drop-in runs under the
     # reference's own train.py with DataParallel hooks), reported beside the headline -- never the headline itself
     ms_other_mode = None
+    ms_library_default = None
     timer3 = None
+    if train and not graph_mode and async_wgrad and defer_join:
+        # the LIBRARY default (what the drop-in under the reference's own train.py gets): side-stream weight gradients joined INSIDE
+        # the regulariser node, so every gradient autograd hands on is finished
+        _ops.set_async_wgrad(True, defer_join=False)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_library_default = float(tm.item()) / args.steps * 1e3
+        _ops.set_async_wgrad(True, defer_join=True)
     if train and not graph_mode:
         _ops.set_async_wgrad(not async_wgrad)
         for _ in range(2):
@@ -634,6 +658,22 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ms_other_mode = float(tm.item()) / args.steps * 1e3
         _ops.set_async_wgrad(async_wgrad)
+    ms_sustained = None
+    if args.sustained > 0:
+        # the headline's mode over many more steps with Python's cyclic collector ON (the 20-step headline runs with it disabled)
+        import gc as _gc
+        _gc.enable()
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.sustained):
+            step()
+        barrier()
+        tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_sustained = float(tm.item()) / args.sustained * 1e3
 
     if args.host_profile and rank == 0:
         import cProfile
@@ -798,7 +838,8 @@ def main():
                        "views": nviews, "image": [img_h, img_w], "depth_planes": ndepth,
                        "global_batch": world, "parallelism": "dp%d" % world},
             "ranks": (dist.get_world_size() if world > 1 else 1),
-            "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks" % world) if (world > 1 and train) else "none",
+            "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks%s" % (world, " (--force-collective)" if world == 1 else ""))
+            if ((world > 1 or args.force_collective) and train) else "none",
             "roofline": roof, "kernels": kernels, "final_loss": lossv,
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
@@ -807,8 +848,13 @@ def main():
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "host_enqueue_ms_per_step_median_max": [host_steps[len(host_steps) // 2], host_steps[-1]], "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
+            "ms_per_step_library_default": (ms_library_default if (async_wgrad and defer_join) else (dt / args.steps * 1e3 if async_wgrad else ms_other_mode)) if train else None,
+            "library_default_is": "side-stream weight gradients joined inside the regulariser node (MVS_ASYNC_WGRAD unset, no set_async_wgrad call)",
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }
+        if ms_sustained is not None:
+            res["ms_per_step_sustained"] = ms_sustained
+            res["sustained_steps"] = args.sustained
         if ab:
             res["ab"] = ab
         if host_trace is not None:
@@ -890,6 +936,7 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

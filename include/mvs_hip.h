@@ -256,7 +256,8 @@ int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int 
  * 3 / 8 / 16 -> <= 16 or 32 -> <= 32 channels, 5x5 stride 2 with 8 -> <= 16 or 16 -> <= 32, Cout % 4 == 0.
  * mvs_conv2d_wgrad_batch_workspace_floats: size of ws for these shapes, or -1 if a layer is not served. */
 long long mvs_conv2d_wgrad_batch_workspace_floats(int n, const int* shapes);
-/* Consumer-side BatchNorm of the training extractor (opt-in, MVS_FEATURE_FUSED_APPLY=1): block i's `F.relu(self.bn(...))`
+/* Consumer-side BatchNorm of the training extractor (the host path's default since round 4; MVS_FEATURE_FUSED_APPLY=0 restores the
+ * apply passes): block i's `F.relu(self.bn(...))`
  * (jdacs/models/module.py:21-22) is applied by block i+1's convolution -- forward and weight gradient -- while it stages its
  * input, so block i has no apply pass and its normalised output exists nowhere in memory.
  * mvs_bn_finalize_slots: the statistic slots of a block -> stats [G][4][C] (mean, invstd, scale, shift) + running statistics

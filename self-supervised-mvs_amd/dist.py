@@ -17,13 +17,22 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun env).
-    Returns (rank, world, local_rank).  backend: "nccl" (== RCCL on ROCm) on GPUs, "gloo" on CPU."""
+    Returns (rank, world, local_rank).  backend: "nccl" (== RCCL on ROCm) on GPUs, "gloo" on CPU.
+    force: create the process group at world size 1 too (bench.py --force-collective: the collective's code path -- RCCL
+    communicator set-up and one all-reduce per step -- then runs on a single-GPU box; a free loopback port is chosen if
+    MASTER_PORT is unset)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force and world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -147,10 +156,13 @@ class FlatGradBucket:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * lo:
                 p.grad = self.flat[lo:hi]
 
+    force_collective = False    # True: run the collective at world size 1 as well (bench.py --force-collective)
+
     def all_reduce(self) -> None:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
             _all_reduce_sum(self.flat)
-            self.flat.div_(dist.get_world_size())
+            if dist.get_world_size() > 1:
+                self.flat.div_(dist.get_world_size())
 
 
 def _host_staged(t: torch.Tensor) -> bool:

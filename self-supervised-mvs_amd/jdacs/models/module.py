@@ -72,10 +72,19 @@ class ConvBnReLU(nn.Module):
 
     def hip_train_forward_serves(self, x) -> bool:
         """the training path of this block through csrc/conv2d.hip with fused BatchNorm statistics (hip_fwd_train) applies to x"""
-        return (self.hip_fwd_train and not self.hip_conv and x.is_cuda and self.training and torch.is_grad_enabled()
-                and self.conv.bias is None and self.conv.groups == 1 and self.conv.dilation == (1, 1) and hip_conv2d_serves(self.conv, x)
-                and x.is_contiguous(memory_format=torch.channels_last) and self.hip_bn and self.conv.out_channels in (4, 8, 16, 32, 64)
-                and self.bn.momentum is not None)
+        return (self.block_trains_with_batch_statistics() and x.is_cuda and torch.is_grad_enabled() and hip_conv2d_serves(self.conv, x)
+                and x.is_contiguous(memory_format=torch.channels_last))
+
+    def block_trains_with_batch_statistics(self) -> bool:
+        """What the one-node extractor (ops.FeatureExtractorFn) assumes of EVERY block, not only the first: train mode on the block
+        AND its BatchNorm (a block put in .eval() for frozen-statistics fine-tuning must normalise with its running statistics, as the
+        reference's module would), an affine BatchNorm with tracked running statistics and an exponential moving average (momentum
+        None = cumulative average is the stock module's business), a bias-free ungrouped convolution, a channel count the BatchNorm
+        kernels serve.  Instance attributes win over the class-level switches."""
+        bn, c = self.bn, self.conv
+        return (self.hip_fwd_train and not self.hip_conv and self.hip_bn and self.training and bn.training and bn.affine
+                and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+                and c.bias is None and c.groups == 1 and c.dilation == (1, 1) and c.out_channels in (4, 8, 16, 32, 64))
 
     def forward(self, x, groups=1, packed_ws=None):
         """groups > 1: x holds `groups` equal batch chunks that the reference would pass through this block one

@@ -41,8 +41,12 @@ class FeatureNet(nn.Module):
         """groups: number of views stacked along the batch dim (per-view BatchNorm statistics are kept)."""
         blocks = [getattr(self, name) for name, *_ in _FEATURE_LAYERS]
         packed = [None] * len(blocks)
-        if blocks[0].hip_train_forward_serves(x) and all(hip_conv2d_serves(m.conv, x) for m in blocks):
-            if self.one_node and not ConvBnReLU.split_bwd and not ConvBnReLU.hip_wgrad and self.feature.bias is not None:
+        if (blocks[0].hip_train_forward_serves(x) and all(hip_conv2d_serves(m.conv, x) for m in blocks)
+                and all(m.block_trains_with_batch_statistics() for m in blocks)):
+            f = self.feature
+            closing_ok = (f.bias is not None and f.kernel_size == (3, 3) and f.stride == (1, 1) and f.padding == (1, 1)
+                          and f.dilation == (1, 1) and f.groups == 1)      # what FeatureExtractorFn's closing convolution assumes
+            if (self.one_node and closing_ok and not any(m.split_bwd or m.hip_wgrad for m in blocks)):
                 # the whole extractor as ONE autograd node (ops.FeatureExtractorFn): same kernels, a third of the host work
                 cfg, params = [], []
                 for m in blocks:
@@ -181,11 +185,20 @@ class MVSNet(nn.Module):
         return {"depth": refined_depth, "photometric_confidence": photometric_confidence}
 
 
+_FUSED_LOSS_MAX_PIXELS = 1 << 19      # 512 k pixels: ~25 us for the one-workgroup kernel, about what the torch launches cost
+
+
 def mvsnet_loss(depth_est, depth_gt, mask):
     """mvsnet.py:164-166: mean smooth-L1 over the pixels with mask > 0.5.  fp32 maps on the GPU: one HIP launch forward, one backward
     (ops.MaskedSmoothL1); anything else: the same value and gradient from torch ops, written without `tensor[mask]` (which
     launches nonzero + a host sync)."""
-    if depth_est.is_cuda and depth_est.dtype == torch.float32:
+    # the fused kernel is ONE workgroup walking the map (built for the 20 k pixels of a quarter-resolution map, where the torch
+    # formulation is 14 launches of pure latency); a full-resolution batch (millions of pixels) is a bandwidth problem that one CU
+    # streams slowly -- there the torch ops are the faster form (ADVICE r4).  Broadcastable gt / mask are expanded, as the torch
+    # formulation always accepted them.
+    if depth_est.is_cuda and depth_est.dtype == torch.float32 and depth_est.numel() <= _FUSED_LOSS_MAX_PIXELS:
+        if depth_gt.shape != depth_est.shape or mask.shape != depth_est.shape:
+            depth_gt, mask = torch.broadcast_to(depth_gt, depth_est.shape), torch.broadcast_to(mask, depth_est.shape)
         return ops.MaskedSmoothL1.apply(depth_est, depth_gt, mask)
     m = (mask > 0.5).to(depth_est.dtype)
     per_pixel = F.smooth_l1_loss(depth_est, depth_gt, reduction='none')

@@ -928,11 +928,15 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
         """hip_forward: the forward pass through csrc/conv2d.hip (3x3 s1 p1 / 5x5 s2 p2 on channels-last input), the backward stays
         the library's two calls.  want_stats (with hip_forward): -> (y, BatchNorm statistic slots of y for `groups` equal batch
         chunks), the slots not differentiable."""
-        if ctx.needs_input_grad[1]:
+        ctx.side_stream = bool(side_stream)   # False: the weight gradient stays on the main stream whatever set_async_wgrad says
+        # the use is counted only where backward() will settle it (_maybe_on_side_stream -> _weight_use_done): with the weight
+        # gradient pinned to the main stream or taken by csrc/conv2d.hip the count was never decremented and grew every step, and a
+        # data_ptr left in _WEIGHT_MULTI pinned whatever weight the allocator put there next to the synchronous path (ADVICE r4)
+        ctx.counted = bool(ctx.needs_input_grad[1] and ctx.side_stream and not hip_wgrad and _ASYNC_WGRAD and weight.is_cuda)
+        if ctx.counted:
             _note_weight_use(weight)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (list(stride), list(padding))
-        ctx.side_stream = bool(side_stream)   # False: the weight gradient stays on the main stream whatever set_async_wgrad says
         # per-layer choice of the backward kernels (measured per layer: profiles/r04_run9_conv2d_layers.log)
         ctx.hip_dgrad, ctx.hip_wgrad = bool(hip_dgrad), bool(hip_wgrad)
         # (the statistic slots are a second, non-differentiable output: without this autograd would hand backward() a zero-filled
@@ -949,6 +953,9 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_unused_grad_of_the_slots):
         if gy is None:
+            if ctx.counted:
+                x, weight = ctx.saved_tensors
+                _weight_use_done(weight.device.index, weight.data_ptr())
             return (None,) * 11
         x, weight = ctx.saved_tensors
         stride, padding = ctx.cfg
@@ -967,6 +974,8 @@ class Conv2dSplitBwdFn(torch.autograd.Function):
             else:
                 fn = lambda: bwd(gy, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
                 gw = _maybe_on_side_stream(fn, weight, (x, gy)) if ctx.side_stream else fn()
+                if ctx.counted and not (_ASYNC_WGRAD and x.is_cuda):     # the flag was switched off between forward and backward
+                    _weight_use_done(weight.device.index, weight.data_ptr())
         return gx, gw, None, None, None, None, None, None, None, None, None
 
 
@@ -1048,6 +1057,16 @@ class FeatureExtractorFn(torch.autograd.Function):
         # (the normalising weight-gradient kernel keeps every group's scale / shift in 512 floats of LDS: groups x channels <= 256)
         fused = bool(FEATURE_FUSED_APPLY and FEATURE_WGRAD_BATCH and n >= 2 and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))
                      and groups * max(w.shape[1] for w in ws_) <= 256 and all(need for need in ctx.needs_input_grad[3::5][:n + 1]))
+        if fused:
+            # the backward pass of the fused form HAS to take the one-launch weight gradient (the normalised activations are not
+            # kept): ask now, from the shapes alone, whether every layer has an instantiation (weight layout, < 2^31 elements, <= 8
+            # layers) -- a "no" found in backward() would be an error with the forward already done
+            shp, (bn_, _, hh, ww_) = [], x.shape
+            for (stride, padding, *_), w in zip(cfg, ws_):
+                shp.append(torch.empty((bn_, w.shape[1], hh, ww_), device="meta"))
+                hh, ww_ = (hh + 2 * padding - w.shape[2]) // stride + 1, (ww_ + 2 * padding - w.shape[3]) // stride + 1
+            shp.append(torch.empty((bn_, fw.shape[1], hh, ww_), device="meta"))
+            fused = _wgrad_batch_serves_shapes(lib, shp, list(ws_) + [fw], [c[0] for c in cfg] + [1])
         acts, raws, statss, slots_b = [x], [], [], []
         for i, (stride, padding, eps, momentum, hip_dgrad) in enumerate(cfg):
             if fused and i > 0:
@@ -1442,12 +1461,20 @@ _WGRAD_BATCH_PLANS = {}
 
 def conv2d_wgrad_batch_serves(xs, weights, strides) -> bool:
     """csrc/conv2d.hip's one-launch weight gradient has an instantiation for every one of these layers (<= 8 of them)"""
+    return _wgrad_batch_serves_shapes(_lib_for(xs[0]), xs, weights, strides)
+
+
+def _wgrad_batch_serves_shapes(lib, xs, weights, strides) -> bool:
+    """conv2d_wgrad_batch_serves from the SHAPES of xs (meta tensors will do)"""
     if not (0 < len(xs) <= 8):
         return False
-    shapes = _wgrad_batch_shapes(xs, weights, strides)
+    try:
+        shapes = _wgrad_batch_shapes(xs, weights, strides)
+    except ValueError:
+        return False
     if shapes is None:
         return False
-    return _wgrad_batch_plan(_lib_for(xs[0]), tuple(shapes))[0] >= 0
+    return _wgrad_batch_plan(lib, tuple(shapes))[0] >= 0
 
 
 def _wgrad_batch_plan(lib, key):

@@ -168,3 +168,32 @@ def test_two_ranks_real_mvsnet_equals_mean_of_per_sample_gradients():
     got = ret["flat"]
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def _forced_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    import mvs_amd  # noqa: F401
+    from mvs_amd import dist as mdist
+    r, w, _ = mdist.init_from_env("gloo", force=True)        # picks its own loopback port
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    p = torch.nn.Parameter(torch.arange(6.0))
+    bucket = mdist.FlatGradBucket([p])
+    (p * torch.arange(6.0)).sum().backward()
+    bucket.gather()
+    before = bucket.flat.clone()
+    bucket.all_reduce()                                      # world size 1, not forced: no collective
+    bucket.force_collective = True
+    bucket.all_reduce()                                      # one all_reduce(sum) over the one rank: the values stay
+    ret["same"] = bool(torch.equal(before, bucket.flat))
+    dist.destroy_process_group()
+
+
+def test_forced_collective_at_world_size_one():
+    """bench.py --force-collective: the process group and the bucket's all-reduce run at world size 1 (on the GPU box: RCCL)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_forced_worker, args=(1, 0, ret), nprocs=1, join=True)
+    assert ret["same"] is True

@@ -1,0 +1,225 @@
+"""GPU tests (-m gpu) of the EXECUTION MODES of the training step -- the things a kernel-level parity test cannot see:
+
+* the mode bench.py's headline is measured in (`ops.set_async_wgrad(True, defer_join=True)`: the regulariser hands its weight
+  gradients to autograd before the side stream has finished them, ONE join at the end of the backward pass) against the
+  synchronous mode (what `loss.backward()` of the reference means: finished gradients, /root/reference/jdacs/train.py:205),
+  at BASELINE config 2's full size and at config 3's per-GPU shape, two steps in a row, plus the two cases that must fall
+  back to the in-node join (a pre-existing .grad, a tensor hook on a weight);
+* SURVEY 8(b)'s threading contract: the reference's caller is one Python thread per GPU (nn.DataParallel's parallel_apply,
+  /root/reference/jdacs/train.py:65); here two threads drive the C ABI concurrently on two streams of ONE GPU.
+
+Determinism note.  The step is not bit-reproducible run to run in ANY mode: BatchNorm's batch sums arrive through fp64 atomics
+(1e-16 relative, almost always rounded away in fp32) and the plane-sweep backward's window write-outs are fp32 atomics.  So the
+comparison is made against the run-to-run spread of the synchronous mode itself: a tensor that reproduces bit for bit in two
+synchronous runs must be bit-identical in the deferred mode too."""
+import threading
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from mvs_amd import _lib
+    _lib._INSTANCE = None
+    assert _lib.get().raw("mvs_is_emulation") == 0
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_modes():
+    from mvs_amd import ops
+    before = (ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED, ops._DEFER_JOIN)
+    yield
+    ops._ASYNC_WGRAD, ops._ASYNC_WGRAD_FUSED, ops._DEFER_JOIN = before
+    ops.reset_weight_uses()
+
+
+def _make(dev, n, ih, iw, nd, selfsup):
+    from mvs_amd.jdacs.models.mvsnet import MVSNet
+    torch.manual_seed(3)
+    net = MVSNet(refine=False)
+    with torch.no_grad():
+        net.cost_regularization.prob.weight.mul_(50.0)
+    net = net.to(dev).train()
+    imgs, proj, dv = R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=4)
+    cams = None
+    if selfsup:
+        imgs = F.avg_pool2d(imgs.view(n, 3, ih, iw), 9, 1, 4).view(1, n, 3, ih, iw) * 4
+        K, E = R.synthetic_cameras(n, ih // 4, iw // 4, iw)
+        cams = torch.zeros(1, n, 2, 4, 4)
+        cams[:, :, 0] = E
+        cams[:, :, 1, :3, :3] = K
+        cams = cams.to(dev)
+    return net, imgs.to(dev), proj.to(dev), dv.to(dev), cams
+
+
+def _step(net, imgs, proj, dv, cams, state0, keep_grad=False):
+    """One training step's forward + loss + backward from the SAME parameters and BatchNorm buffers; -> {name: grad}."""
+    from mvs_amd.jdacs.models.mvsnet import mvsnet_loss
+    net.load_state_dict(state0)
+    if not keep_grad:
+        for p in net.parameters():
+            p.grad = None
+    out = net(imgs, proj, dv)
+    if cams is not None:
+        from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
+        loss = UnSupLoss()(imgs, cams, out["depth"])
+    else:
+        gt = torch.full_like(out["depth"], 650.0)
+        loss = mvsnet_loss(out["depth"], gt, torch.ones_like(gt))
+    loss.backward()
+    # the consumer of the gradients comes AFTER backward() returned, on the current stream: exactly what bench.py's
+    # bucket.gather() and an optimiser step do
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    torch.cuda.synchronize()
+    return grads, float(loss)
+
+
+def _compare(ref_a, ref_b, got, what):
+    """`got` against the synchronous runs ref_a / ref_b: within twice their own run-to-run spread, bit-identical where they are."""
+    n_exact = 0
+    for k in ref_a:
+        spread = float((ref_a[k] - ref_b[k]).abs().max())
+        diff = min(float((got[k] - ref_a[k]).abs().max()), float((got[k] - ref_b[k]).abs().max()))
+        scale = float(ref_a[k].abs().max())
+        assert torch.isfinite(got[k]).all(), (what, k)
+        assert diff <= 2.0 * spread + 1e-7 * scale, "%s: %s differs by %.3e (run-to-run spread of the synchronous mode %.3e, scale %.3e)" % (
+            what, k, diff, spread, scale)
+        n_exact += int(diff == 0.0)
+    return n_exact
+
+
+@pytest.mark.parametrize("n,ih,iw,nd,selfsup", [(3, 512, 640, 192, False), (5, 512, 640, 192, True)],
+                         ids=["config2_full_size", "config3_per_gpu_shape"])
+def test_deferred_side_stream_join_equals_synchronous_weight_gradients(dev, n, ih, iw, nd, selfsup):
+    """bench.py's measured mode == the synchronous mode, every parameter gradient, two steps in a row (a stale `_BWD_OPEN`
+    entry or weight-use count of step 1 would send step 2 down another path or leave it unjoined)."""
+    from mvs_amd import ops
+    net, imgs, proj, dv, cams = _make(dev, n, ih, iw, nd, selfsup)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    ops.set_async_wgrad(False, defer_join=False)
+    ref_a, loss_a = _step(net, imgs, proj, dv, cams, state0)
+    ref_b, loss_b = _step(net, imgs, proj, dv, cams, state0)
+    ops.set_async_wgrad(True, defer_join=False)            # the library default: side stream, join inside the node
+    lib_default, _ = _step(net, imgs, proj, dv, cams, state0)
+    _compare(ref_a, ref_b, lib_default, "join inside the node")
+    ops.set_async_wgrad(True, defer_join=True)             # bench.py's mode
+    exact = []
+    for rep in range(2):
+        got, loss = _step(net, imgs, proj, dv, cams, state0)
+        assert not ops._BWD_OPEN, "the end-of-backward callback did not close the pass"
+        assert abs(loss - loss_a) <= 1e-6 * abs(loss_a) + 2 * abs(loss_a - loss_b)
+        exact.append(_compare(ref_a, ref_b, got, "deferred join, step %d" % rep))
+    assert not any(ops._WEIGHT_USES.get(dev.index, {}).values()), "weight-use counts left behind"
+    reg = [k for k in ref_a if k.startswith("cost_regularization") and k.endswith("weight") and ref_a[k].dim() == 5]
+    assert len(reg) == 11
+    print("deferred join: %d / %d of %d parameter gradients bit-identical to a synchronous run" % (exact[0], exact[1], len(ref_a)))
+
+
+def test_deferred_join_falls_back_to_the_in_node_join(dev):
+    """A weight with an existing .grad (autograd ACCUMULATES into it mid-backward, on the main stream) or with a tensor hook (the
+    hook reads the gradient when it is returned) must not get an unfinished gradient: the node then joins the side stream itself.
+    The hook checks what it is handed against the synchronous run ON THE MAIN STREAM at the moment it fires."""
+    from mvs_amd import ops
+    net, imgs, proj, dv, cams = _make(dev, 3, 256, 320, 96, False)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    ops.set_async_wgrad(False, defer_join=False)
+    ref_a, _ = _step(net, imgs, proj, dv, None, state0)
+    ref_b, _ = _step(net, imgs, proj, dv, None, state0)
+    ops.set_async_wgrad(True, defer_join=True)
+    # (1) pre-existing .grad: second backward accumulates -> 2x the synchronous gradient
+    got1, _ = _step(net, imgs, proj, dv, None, state0)
+    got2, _ = _step(net, imgs, proj, dv, None, state0, keep_grad=True)
+    for k in ref_a:
+        spread = float((ref_a[k] - ref_b[k]).abs().max())
+        scale = float(ref_a[k].abs().max())
+        assert float((got2[k] - 2.0 * ref_a[k]).abs().max()) <= 4.0 * spread + 4e-7 * scale, k
+    # (2) a tensor hook on conv0's weight (the LAST weight gradient forked: the one most likely to be unfinished)
+    w0 = net.cost_regularization.conv0.conv.weight
+    seen = {}
+
+    def hook(g):
+        seen["snapshot"] = g.detach().clone()        # enqueued on the stream the hook runs on, right now
+        return None
+    h = w0.register_hook(hook)
+    try:
+        got3, _ = _step(net, imgs, proj, dv, None, state0)
+    finally:
+        h.remove()
+    k0 = "cost_regularization.conv0.conv.weight"
+    spread = float((ref_a[k0] - ref_b[k0]).abs().max())
+    assert float((seen["snapshot"] - ref_a[k0]).abs().max()) <= 2.0 * spread + 1e-7 * float(ref_a[k0].abs().max())
+    _compare(ref_a, ref_b, got3, "tensor hook on conv0.weight")
+    assert not ops._BWD_OPEN
+
+
+def test_two_host_threads_two_streams_one_gpu(dev):
+    """the caller may be one Python thread per replica.  Two threads, each with its own stream, model replica and
+    sample, run forward + loss + backward through the C ABI at the same time; each must get what it gets alone.  Run in the
+    library-default mode (side-stream weight gradients joined inside the node: the per-device stream pool and the bookkeeping
+    dictionaries are shared by the threads) and in the synchronous mode."""
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
+    shapes = [(3, 128, 160, 48, 11), (3, 160, 192, 32, 12)]
+
+    def build(seed):
+        torch.manual_seed(seed)
+        net = MVSNet(refine=False)
+        with torch.no_grad():
+            net.cost_regularization.prob.weight.mul_(50.0)
+        return net.to(dev).train()
+
+    def run(idx, stream, out, rounds):
+        n, ih, iw, nd, seed = shapes[idx]
+        try:
+            with torch.cuda.stream(stream):
+                net = build(seed)
+                state0 = {k: v.clone() for k, v in net.state_dict().items()}
+                imgs, proj, dv = (t.to(dev) for t in R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=seed))
+                res = []
+                for _ in range(rounds):
+                    net.load_state_dict(state0)
+                    for p in net.parameters():
+                        p.grad = None
+                    o = net(imgs, proj, dv)
+                    gt = torch.full_like(o["depth"], 650.0)
+                    mvsnet_loss(o["depth"], gt, torch.ones_like(gt)).backward()
+                    res.append((o["depth"].detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+                stream.synchronize()
+                out[idx] = res
+        except BaseException as e:       # noqa: BLE001 -- hand the failure to the main thread
+            out[idx] = e
+
+    for async_wgrad in (True, False):
+        ops.set_async_wgrad(async_wgrad, defer_join=False)
+        alone = {}
+        for i in range(2):
+            run(i, torch.cuda.Stream(device=dev), alone, 2)
+            assert not isinstance(alone[i], BaseException), alone[i]
+        together = {}
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        threads = [threading.Thread(target=run, args=(i, streams[i], together, 4)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert not isinstance(together[i], BaseException), together[i]
+            (d_a, g_a), (d_b, g_b) = alone[i]
+            for d_t, g_t in together[i]:
+                assert float((d_t - d_a).abs().max()) <= 2 * float((d_a - d_b).abs().max()) + 1e-6 * float(d_a.abs().max())
+                for k in g_a:
+                    spread = float((g_a[k] - g_b[k]).abs().max())
+                    scale = float(g_a[k].abs().max())
+                    diff = min(float((g_t[k] - g_a[k]).abs().max()), float((g_t[k] - g_b[k]).abs().max()))
+                    assert diff <= 2.0 * spread + 1e-6 * scale, "thread %d (%s weight gradients): %s differs by %.3e (spread %.3e, scale %.3e)" % (
+                        i, "side-stream" if async_wgrad else "synchronous", k, diff, spread, scale)
+        assert not ops._BWD_OPEN
