@@ -756,8 +756,11 @@ def main():
                 for item in spec.split(","):
                     key, _, val = item.partition("=")
                     dflt = _lib.DEFAULT_TUNING.get(key)
-                    if dflt is None:
-                        raise SystemExit("bench.py --ab: give the library default of '%s' in _lib.DEFAULT_TUNING first" % key)
+                    if dflt is None:       # not in the host-side table: ask the library what it runs with
+                        import ctypes
+                        cur = ctypes.c_int(0)
+                        lib.call("mvs_get_tuning", key.encode(), ctypes.byref(cur))
+                        dflt = int(cur.value)
                     pairs.append((key, int(val), dflt))
                 def setter(on, pairs=pairs):
                     for key, val, dflt in pairs:

@@ -22,25 +22,7 @@ int g_conv_cout1_d4 = 2;
 
 extern int g_conv_split, g_conv_small, g_conv_small_wgs, g_conv_tr2pw;
 
-struct ConvArgs {
-    const float* x;         // [B,Di,Hi,Wi,Cin]
-    const float* wp;        // packed weights
-    float* y;               // [B,Do,Ho,Wo,Cout]
-    const float* scale;     // [Cout] or null
-    const float* shift;     // [Cout] or null (bias when scale == null)
-    const float* skip;      // like y, or null (added after the ReLU)
-    double* slots;          // BatchNorm statistic slots [nslots][2][Cout] (fp64 atomics, bn.hip) or null: per channel (sum y, sum y^2)
-                            // of the RAW output -- or, with bn_raw, (sum dyh, sum dyh*xhat) of the BatchNorm+ReLU block whose output
-                            // gradient this kernel writes (y = an input gradient incl. the `skip` summand)
-    int nslots;             // power of two
-    const float* bn_raw;    // like y: that block's raw (pre-BatchNorm) output, or null
-    const float* bn_stats;  // [4][Cout]: its mean, invstd, scale, shift
-    int relu;
-    int B, Di, Hi, Wi, Do, Ho, Wo, Cin, Cout;
-    int QD, QH, QW;         // coarse-grid extents
-    int ntd, nth, ntw;      // tiles per dim
-    int nb_total;           // 16-wide Cout tiles in the packed weight image; a workgroup handles NB of them from blockIdx.y*NB
-};
+#include "conv_args.h"
 
 // ------------------------------------------------------------------------------------------------
 // weight packing
@@ -132,35 +114,6 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(PackBatch pb) {
     } else {
         conv_pack_weights_item(p.w, p.wp, p.geom, p.CC, p.Cin, p.Cout, p.NB, p.layout, p.flip, idx);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
-// xcd_block() gives every XCD one contiguous range of the tile order, and brick_tile() makes that order bricks
-// of (all W tiles) x (4 H tiles) marching along D: tiles resident together on an XCD share their halos in L2.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_block(int bid, int nb) {
-    const int per = nb >> 3, rem = nb & 7, x = bid & 7, idx = bid >> 3;
-    return x * per + (x < rem ? x : rem) + idx;
-}
-__device__ __forceinline__ void brick_tile(int t, int ntw, int nth, int ntd, int& b, int& td, int& th, int& tw) {
-    const int per_b = ntw * nth * ntd;
-    b = t / per_b;
-    int r = t - b * per_b;
-    const int full = ntw * 4 * ntd;
-    int g = r / full, gh = 4;
-    if (g >= (nth >> 2)) { g = nth >> 2; gh = nth & 3; }
-    r -= g * full;
-    td = r / (ntw * gh);
-    r -= td * (ntw * gh);
-    th = g * 4 + r / ntw;
-    tw = r % ntw;
-}
-__device__ __forceinline__ void linear_tile(int t, int ntw, int nth, int ntd, int& b, int& td, int& th, int& tw) {
-    tw = t % ntw; t /= ntw;
-    th = t % nth; t /= nth;
-    td = t % ntd; t /= ntd;
-    b = t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1542,6 +1495,8 @@ int g_conv_wgrad8_groups = 192;  // tuning knob "wgrad8_groups": ... of the CG =
 int g_conv_wgrad8_nch = 2;       // tuning knob "wgrad8_nch": 2 = the CG == 8 weight gradient stages both 16-channel chunks of a 32-channel X in one workgroup.  Default since the end of round 4: at 192 workgroups the one-chunk form draws 2.31 GB from HBM per launch (0.63 GB algorithmic; 1.14 GB at 128 workgroups, 2.04 GB at 256: which halo lines neighbouring workgroups find in their XCD's L2 depends on the count), the two-chunk form 1.08 GB, at the same step time (5.313 vs 5.298 ms, profiles/r04_run31_*); alone on the GPU it is the slower kernel (0.85 vs 0.76 ms at 192 workgroups)
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
+int g_conv_direct = 3;  // tuning knob "conv_direct", bit mask: 1 = stride-2 / 8-input-channel layers run conv3d_direct.hip's LDS-free kernel
+int run_s2c8_direct(ConvArgs a, hipStream_t st);
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
 template <int GEOM, int CC>
@@ -1752,6 +1707,10 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
         MVS_REQUIRE(!(geom == GEOM_TR2 && cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
     }
     a.wp = ws;
+    // knob "conv_direct": the stride-2 layers with 8 input channels (conv1 forward, conv11's input gradient at level 0) without LDS
+    // staging -- conv3d_direct.hip
+    if ((g_conv_direct & 1) && geom == GEOM_S2 && cin == 8 && cout <= 16 && !ep.scale && !ep.shift && !ep.skip && !ep.bn_raw && !ep.relu)
+        return run_s2c8_direct(a, st);
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);

@@ -30,5 +30,36 @@ case "$what" in
     timeout 900 python bench.py --steps 20 --warmup 5 $short --ab "$2" --ab-reps ${3:-6} > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err; echo "bench exit $?"; summ gpurun_out/bench_ab.json
     MVS_ASYNC_WGRAD=0 timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/bench_k_sync.json 2> gpurun_out/bench_k_sync.err
     grep "ms/step" gpurun_out/bench_k_sync.err > gpurun_out/kernel_table_uncontended.txt; head -${4:-60} gpurun_out/kernel_table_uncontended.txt ;;
+  pmcn)   # bash tools/gpu_r5.sh pmcn "<knob settings...>": SQ / TCC counters of the narrow-layer microbenchmark (tools/bench_narrow.py), one pass per counter group
+    i=0
+    if [ "${4:-sq}" = "mem" ]; then
+      set -- "$1" "$2" "${3:-conv1 fwd}" mem "TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+    else
+      set -- "$1" "$2" "${3:-conv1 fwd}" sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+    fi
+    for grp in "${@:5}"; do
+      i=$((i+1)); rm -rf gpurun_out/pmcn_$i
+      (cd /tmp && MVS_NARROW_ONLY="${3:-conv1 fwd}" timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmcn_$i" -o pmc -- \
+          python "$OLDPWD/tools/bench_narrow.py" $2 > "$OLDPWD/gpurun_out/pmcn_$i.log" 2>&1); echo "pmc pass $i exit $?"
+    done
+    python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmcn_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not any(k in name for k in ("conv_", "bn_")):
+            continue
+        acc[name][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+for name, cs in acc.items():
+    print(name)
+    for c, v in sorted(cs.items()):
+        per = collections.defaultdict(float)
+        for d, x in v:
+            per[d] += x
+        vals = sorted(per.values())
+        print("   %-28s median %.4g  (n=%d)" % (c, vals[len(vals) // 2], len(vals)))
+PY
+    rm -rf gpurun_out/pmcn_[0-9] ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
