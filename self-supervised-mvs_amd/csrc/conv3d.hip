@@ -1495,8 +1495,10 @@ int g_conv_wgrad8_groups = 192;  // tuning knob "wgrad8_groups": ... of the CG =
 int g_conv_wgrad8_nch = 2;       // tuning knob "wgrad8_nch": 2 = the CG == 8 weight gradient stages both 16-channel chunks of a 32-channel X in one workgroup.  Default since the end of round 4: at 192 workgroups the one-chunk form draws 2.31 GB from HBM per launch (0.63 GB algorithmic; 1.14 GB at 128 workgroups, 2.04 GB at 256: which halo lines neighbouring workgroups find in their XCD's L2 depends on the count), the two-chunk form 1.08 GB, at the same step time (5.313 vs 5.298 ms, profiles/r04_run31_*); alone on the GPU it is the slower kernel (0.85 vs 0.76 ms at 192 workgroups)
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
-int g_conv_direct = 3;  // tuning knob "conv_direct", bit mask: 1 = stride-2 / 8-input-channel layers run conv3d_direct.hip's LDS-free kernel
-int run_s2c8_direct(ConvArgs a, hipStream_t st);
+int g_conv_pers = 1;    // tuning knob "conv_pers": 1 = one-chunk layers (16 -> <= 16, 8 -> 32 stride 1; 8 -> <= 16 stride 2) run conv3d_pers.hip
+int g_conv_pers_min_wgs = 1024;   // tuning knob "conv_pers_min": ... when the one-tile kernel would launch at least this many workgroups (a persistent grid needs several tiles per workgroup)
+bool conv_pers_serves(int geom, int cin, int cout);
+int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st);
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
 template <int GEOM, int CC>
@@ -1707,10 +1709,11 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
         MVS_REQUIRE(!(geom == GEOM_TR2 && cin < 16), MVS_ERR_UNSUPPORTED, "transposed stride-2 conv needs >= 16 input channels");
     }
     a.wp = ws;
-    // knob "conv_direct": the stride-2 layers with 8 input channels (conv1 forward, conv11's input gradient at level 0) without LDS
-    // staging -- conv3d_direct.hip
-    if ((g_conv_direct & 1) && geom == GEOM_S2 && cin == 8 && cout <= 16 && !ep.scale && !ep.shift && !ep.skip && !ep.bn_raw && !ep.relu)
-        return run_s2c8_direct(a, st);
+    // knob "conv_pers": single-chunk layers with a small weight image through the persistent LDS-DMA kernel (conv3d_pers.hip)
+    if (g_conv_pers && conv_pers_serves(geom, cin, cout) && (long)nblocks * (a.nb_total / NB) >= g_conv_pers_min_wgs) {
+        a.ntd = mvs_cdiv(a.QD, geom_tqd(geom)); a.nth = mvs_cdiv(a.QH, geom_tqh(geom));
+        return run_conv_pers(geom, a, st);
+    }
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);

@@ -1,0 +1,283 @@
+// Persistent implicit-GEMM convolution with double-buffered LDS-DMA staging (gfx950 global_load_lds_dwordx4).
+//
+// conv_igemm_kernel (conv3d.hip) is one tile per workgroup: load halo -> barrier -> k-loop -> store.  Its loads are in flight only
+// while the workgroup is not computing, every wave pays prologue / epilogue / tail for 100-450 MFMAs, and its weight fragments come
+// from L2 inside the k-loop.  Measured where that hurts most (profiles/r05_run5..9: the narrow level-0 layers run at 22-26 % of the
+// HBM peak AND 30 % of the MFMA rate; a direct-from-global variant removed the barrier and landed at the same time -- memory side
+// alone 72 us, MFMA side alone 55 us for 26 us of MFMA work).  This kernel is the other decomposition:
+//   * persistent workgroups (one or two per CU) walk tiles blockIdx.x, blockIdx.x + gridDim.x, ...;
+//   * the halo tile of the NEXT tile is requested by LDS-DMA (no registers, no ds_write pass) into the other half of a
+//     double buffer when the current tile's k-loop starts, and is waited for (s_waitcnt vmcnt(0), by then long landed) after it;
+//   * the layer's whole packed weight image lives in LDS for the lifetime of the workgroup -- no global load in the k-loop at all,
+//     so nothing of hipcc's own s_waitcnt bookkeeping ever sits between an LDS-DMA request and its completion;
+//   * one barrier per tile, without the release fence of __syncthreads() (the epilogue's stores stay in flight across it);
+//   * BatchNorm statistics are accumulated over all tiles of a workgroup and added to the slots once.
+// LDS layout of a halo tile: voxel-major, CC floats per voxel, NO padding (an LDS-DMA instruction writes 64 lanes x 16 bytes
+// linearly); ds_read_b128 of 16 positions at a 32- / 64-byte pitch is conflict-free / two-way (the hardware's b128 lane groups are
+// {0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md), 36 LDS cycles per wave and k-step against 512 MFMA cycles.
+// Halo voxels outside the volume are DMA'd from a zero page.  Same packed weight image, same MFMA order over k as
+// conv_igemm_kernel => bit-identical outputs (the statistics are summed in another order).
+// Serves: one channel chunk (Cin == CC in {8, 16}), stride 1 or 2, up to two 16-wide Cout tiles per workgroup.
+#include "mvs_rt.h"
+#include "conv_map.h"
+#include "conv_args.h"
+
+__device__ float g_conv_zero_page[64];
+
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// NW: waves per workgroup (4 or 8).  The LDS footprint (two halo buffers + the weight image) allows one or two workgroups per
+// CU; with four waves each that is one wave per SIMD, and a lone wave exposes every MFMA dependency and LDS latency of its own
+// instruction stream (measured: 16 -> 16 at level 1 0.094 -> 0.134 ms).  Eight waves share the SAME tile (two rows of the 4 x 4 x 16
+// block each instead of four): twice the waves per SIMD for the same LDS.
+template <int GEOM, int CC, int NB, int SIDE, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_pers_kernel(ConvArgs a) {
+    using G = ConvGeom<GEOM>;
+    constexpr int NT = NW * 64;
+    constexpr int CQ = CC / 4, MB = G::MB * 4 / NW;
+    static_assert(G::MB * 4 % NW == 0 && MB >= 1, "rows of the tile must split evenly over the waves");
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int NITEMS = NR * CQ;              // 16-byte items of a halo tile
+    constexpr int NDMA = (NITEMS + 63) / 64;     // wave-level DMA instructions per tile
+    constexpr int DPW = (NDMA + NW - 1) / NW;    // ... per wave
+    constexpr int TILEF = NDMA * 256;            // floats per buffer (whole DMA instructions)
+    constexpr int KS = (27 * CC + 15) / 16;      // ksteps_for(27, CC)
+    __shared__ __attribute__((aligned(16))) float tile[2 * TILEF];
+    __shared__ __attribute__((aligned(16))) float wl[KS * NB * 256];
+    __shared__ float red[NW * NB * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int nb0 = blockIdx.y * NB;
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+
+    // ---- the layer's weight image -> LDS (once) ----
+    for (int i = tid; i < KS * NB * 64; i += NT) {
+        const int l = i & 63, nb = (i >> 6) % NB, ks = (i >> 6) / NB;
+        *reinterpret_cast<float4*>(&wl[(size_t)i * 4]) =
+            *reinterpret_cast<const float4*>(a.wp + (((size_t)ks * a.nb_total + nb0 + nb) * 64 + l) * 4);
+    }
+
+    // ---- per-lane DMA items: tile-invariant source offsets + halo coordinates ----
+    int rel[DPW], crd[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int d = NW * j + wave;
+        const int i = 64 * d + lane;
+        const int vox = i / CQ, cq = i % CQ;
+        const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+        rel[j] = ((rd * a.Hi + rh) * a.Wi + rw) * CC + 4 * cq;
+        crd[j] = (d < NDMA && i < NITEMS) ? (rd | (rh << 8) | (rw << 16)) : -1;
+    }
+    const float* __restrict__ zero = g_conv_zero_page;
+    auto issue = [&](int t, int buf) {
+        int b, td, th, tw;
+        linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        const int id0 = td * G::TQD * G::IS - G::PAD, ih0 = th * G::TQH * G::IS - G::PAD, iw0 = tw * G::TQW * G::IS - G::PAD;
+        const long long org = ((((long long)b * a.Di + id0) * a.Hi + ih0) * a.Wi + iw0) * CC;
+        const float* __restrict__ xb = a.x + org;    // (may lie in front of the tensor for border tiles: only in-volume items use it)
+        const bool interior = id0 >= 0 && id0 + G::RD <= a.Di && ih0 >= 0 && ih0 + G::RH <= a.Hi && iw0 >= 0 && iw0 + G::RW <= a.Wi;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int d = NW * j + wave;
+            if (d >= NDMA) break;                    // wave-uniform
+            const float* src = xb + rel[j];
+            bool ok = crd[j] >= 0;
+            if (!interior) {
+                const int rd = crd[j] & 255, rh = (crd[j] >> 8) & 255, rw = (crd[j] >> 16) & 255;
+                ok = ok && id0 + rd >= 0 && id0 + rd < a.Di && ih0 + rh >= 0 && ih0 + rh < a.Hi && iw0 + rw >= 0 && iw0 + rw < a.Wi;
+            }
+            if (!ok) src = zero + 4 * (lane & 15);
+            MVS_DMA16(&tile[buf * TILEF + d * 256], src);
+        }
+    };
+
+    // ---- per-lane A offsets (floats, inside a buffer) of the lane's position in each m-block, at tap (0,0,0) ----
+    int aoff[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int f = wave * MB + mb;
+        const int qd_l = f / G::TQH, qh_l = f % G::TQH;
+        const int kq = CC == 16 ? 4 * g : 4 * (g & 1);
+        aoff[mb] = (((qd_l * G::IS) * G::RH + qh_l * G::IS) * G::RW + l15 * G::IS) * CC + kq;
+    }
+    const int tsel = CC == 8 ? (g >> 1) : 0;     // CC == 8: a k-step of 16 is two taps; lanes g = 2, 3 take the second
+
+    float st1[NB], st2[NB], bmu[NB], bis[NB], bsc[NB], bsh[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        st1[nb] = st2[nb] = 0.f;
+        bmu[nb] = bis[nb] = bsc[nb] = bsh[nb] = 0.f;
+        if (SIDE && a.bn_raw) {
+            const int co = (nb0 + nb) * 16 + l15;
+            if (co < a.Cout) { bmu[nb] = a.bn_stats[co]; bis[nb] = a.bn_stats[a.Cout + co]; bsc[nb] = a.bn_stats[2 * a.Cout + co]; bsh[nb] = a.bn_stats[3 * a.Cout + co]; }
+        }
+    }
+
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    MVS_WAIT_VMCNT(0);
+    __syncthreads();             // weights + first tile in LDS
+
+    int it = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x, buf ^ 1);     // lands under this tile's MFMAs
+        const int tb = buf * TILEF;        // (indexing the __shared__ arrays themselves keeps the accesses ds_read_b128, not flat loads)
+
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // operands of k-step ks + 1 are requested from LDS before the MFMAs of k-step ks; the MFMAs of a k-step walk the accumulators
+        // round-robin (x of every (mb, nb), then y, ...), so back-to-back MFMAs never wait for each other's result
+        auto toff_of = [&](int ks) {      // the lane's tap of k-step ks -> float offset inside the halo tile (ks: constant after unrolling)
+            if (CC == 16) return (((ks / 9) * G::RH + (ks / 3) % 3) * G::RW + ks % 3) * CC;
+            const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 26;      // (tap 27: its weights are zero; the lane re-reads tap 26)
+            const int o0 = (((t0 / 9) * G::RH + (t0 / 3) % 3) * G::RW + t0 % 3) * CC;
+            const int o1 = (((t1 / 9) * G::RH + (t1 / 3) % 3) * G::RW + t1 % 3) * CC;
+            return tsel ? o1 : o0;
+        };
+        float4 bq[2][NB], af[2][MB];
+        auto fetch = [&](int ks, float4 (&bv)[NB], float4 (&av)[MB]) {
+            const int toff = toff_of(ks);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wl[((ks * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const float4*>(&tile[tb + aoff[mb] + toff]);
+        };
+        fetch(0, bq[0], af[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) fetch(ks + 1, bq[(ks + 1) & 1], af[(ks + 1) & 1]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = MVS_MFMA_16x16x4(f4c(af[ks & 1][mb], c), f4c(bq[ks & 1][nb], c), acc[mb][nb]);
+        }
+        // the next tile's DMA (requested a whole k-loop ago) has landed; so have the previous epilogue's stores
+        MVS_WAIT_VMCNT(0);
+
+        // ---- epilogue: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
+        int b, td, th, tw;
+        linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int f = wave * MB + mb;
+            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+            const bool row_ok = qd < a.QD && qh < a.QH;
+            float sk[4][NB], rwv[4][NB];
+            if (SIDE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qw = qw0 + 4 * g + r;
+                    const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int co = (nb0 + nb) * 16 + l15;
+                        const bool ok = row_ok && qw < a.QW && co < a.Cout;
+                        sk[r][nb] = (ok && a.skip) ? a.skip[obase + co] : 0.f;
+                        rwv[r][nb] = (ok && a.bn_raw) ? a.bn_raw[obase + co] : 0.f;
+                    }
+                }
+            }
+            if (!row_ok) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qw = qw0 + 4 * g + r;
+                if (qw >= a.QW) continue;
+                const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = (nb0 + nb) * 16 + l15;
+                    if (co >= a.Cout) continue;
+                    float v = acc[mb][nb][r];
+                    float sv1 = v, sv2 = v * v;
+                    if (a.scale) v = v * a.scale[co] + a.shift[co];
+                    else if (a.shift) v = v + a.shift[co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (SIDE && a.skip) v += sk[r][nb];
+                    if (SIDE && a.bn_raw) {
+                        sv1 = (rwv[r][nb] * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
+                        sv2 = sv1 * ((rwv[r][nb] - bmu[nb]) * bis[nb]);
+                    }
+                    st1[nb] += sv1;
+                    st2[nb] += sv2;
+                    a.y[obase + co] = v;
+                }
+            }
+        }
+        // every wave has read its A fragments of `buf` (they fed MFMAs that have been issued) and has waited for its own share of the
+        // next tile's DMA: after the barrier `buf` may be overwritten and `buf ^ 1` read
+        MVS_LDS_BARRIER();
+    }
+
+    if (a.slots) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float s1 = st1[nb], s2 = st2[nb];
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
+                red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB * 16) {
+            const int stat = tid / (NB * 16), n = tid % (NB * 16);
+            if (nb0 * 16 + n < a.Cout) {
+                float s = 0.f;
+                for (int w = 0; w < NW; ++w) s += red[(w * NB * 16 + n) * 2 + stat];
+                MVS_GLOBAL_ATOMIC_ADD_F64(a.slots + ((size_t)(blockIdx.x & (a.nslots - 1)) * 2 + stat) * a.Cout + nb0 * 16 + n, (double)s);
+            }
+        }
+    }
+}
+
+int g_conv_pers_groups = 0;
+int g_conv_pers_nw = 8;
+// LDS bytes of an instantiation (host side: how many workgroups fit a CU)
+template <int GEOM, int CC, int NB>
+static int pers_lds_bytes() {
+    using G = ConvGeom<GEOM>;
+    constexpr int NDMA = (G::RD * G::RH * G::RW * (CC / 4) + 63) / 64;
+    return (2 * NDMA * 256 + ((27 * CC + 15) / 16) * NB * 256 + 4 * NB * 16 * 2) * 4;
+}
+
+template <int GEOM, int CC, int NB, int NW>
+static int launch_pers(const ConvArgs& a, hipStream_t st) {
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    const int per_cu = (160 * 1024) / pers_lds_bytes<GEOM, CC, NB>() >= 2 ? 2 : 1;
+    int groups = g_conv_pers_groups > 0 ? g_conv_pers_groups : 256 * per_cu;     // knob "conv_pers_groups" (tests: a few workgroups walk many tiles)
+    if (groups > ntiles) groups = ntiles;
+    dim3 grid(groups, a.nb_total / NB);
+    if (a.skip || a.bn_raw) MVS_LAUNCH((conv_pers_kernel<GEOM, CC, NB, 1, NW>), grid, dim3(NW * 64), 0, st, a);
+    else MVS_LAUNCH((conv_pers_kernel<GEOM, CC, NB, 0, NW>), grid, dim3(NW * 64), 0, st, a);
+    return mvs_check_launch("conv_pers");
+}
+
+// Does the persistent kernel serve this op?  (one channel chunk; a.* filled as run_igemm does for the full-size tiles of `geom`)
+bool conv_pers_serves(int geom, int cin, int cout) {
+    if (geom == GEOM_S1) return (cin == 16 && cout <= 16) || (cin == 8 && cout > 16 && cout <= 32);
+    if (geom == GEOM_S2) return cin == 8 && cout <= 16;
+    return false;
+}
+
+int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st) {
+    // knob "conv_pers_nw": waves per workgroup
+    if (g_conv_pers_nw == 8) {
+        if (geom == GEOM_S1 && a.Cin == 16) return launch_pers<GEOM_S1, 16, 1, 8>(a, st);
+        if (geom == GEOM_S1 && a.Cin == 8) return launch_pers<GEOM_S1, 8, 2, 8>(a, st);
+        if (geom == GEOM_S2 && a.Cin == 8) return launch_pers<GEOM_S2, 8, 1, 8>(a, st);
+    }
+    if (geom == GEOM_S1 && a.Cin == 16) return launch_pers<GEOM_S1, 16, 1, 4>(a, st);
+    if (geom == GEOM_S1 && a.Cin == 8) return launch_pers<GEOM_S1, 8, 2, 4>(a, st);
+    if (geom == GEOM_S2 && a.Cin == 8) return launch_pers<GEOM_S2, 8, 1, 4>(a, st);
+    mvs_set_error("conv_pers: geometry %d with %d input channels is not served", geom, a.Cin);
+    return MVS_ERR_UNSUPPORTED;
+}

@@ -77,6 +77,21 @@ static __device__ __forceinline__ void mvs_dma4(float* lds_dst, const float* gba
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(voff_bytes), "s"(gbase) : "memory", "m0");
 }
 #define MVS_DMA4(lds_dst, gbase, voff_bytes) mvs_dma4((lds_dst), (gbase), (voff_bytes))
+// 16 bytes per lane (global_load_lds_dwordx4, gfx950): lane l's 16 bytes at its own pointer gsrc land in LDS at lds_dst + 16 * l --
+// one wave instruction moves 1 KiB.  lds_dst wave-uniform (it travels in M0; M0 is saved and restored inside the statement, the
+// compiler keeps values of its own there).  Not counted by hipcc's s_waitcnt bookkeeping: the caller waits (MVS_WAIT_VMCNT).
+static __device__ __forceinline__ void mvs_dma16(float* lds_dst, const float* gsrc) {
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(mvs_lds_float*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(m0v)
+                 : "memory");
+}
+#define MVS_DMA16(lds_dst, gsrc) mvs_dma16((lds_dst), (gsrc))
+// workgroup barrier WITHOUT the release fence of __syncthreads() (which drains every outstanding global store: s_waitcnt vmcnt(0)):
+// orders LDS traffic only -- the caller has waited for its own LDS operations / LDS-DMA where that matters
+#define MVS_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // wait until at most n vector-memory operations of this wave are outstanding (n: compile-time constant <= 63)
 #define MVS_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MVS_LDS_ATOMIC_ADD(ptr, v) \

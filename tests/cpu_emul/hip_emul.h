@@ -249,6 +249,8 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 // LDS-DMA: the emulation copies synchronously (one lane = one thread), so the vmcnt waits are no-ops
 #define MVS_DMA4(lds_dst, gbase, voff_bytes) ((void)((lds_dst)[emul::lane] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gbase) + (voff_bytes))))
 #define MVS_WAIT_VMCNT(n) ((void)0)
+#define MVS_DMA16(lds_dst, gsrc) memcpy(reinterpret_cast<char*>(lds_dst) + 16 * emul::lane, (gsrc), 16)
+#define MVS_LDS_BARRIER() __syncthreads()
 #define MVS_LDS_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 #define MVS_GLOBAL_ATOMIC_ADD(ptr, v) ((void)atomicAdd((ptr), (v)))
 static inline void emul_atomic_add_f64(double* addr, double v) {

@@ -1488,3 +1488,58 @@ def test_conv_cout8_weight_gradient_two_chunks_per_workgroup(emul_lib, dims, xcd
     scale = max(1.0, float(w.grad.abs().max()))
     assert float((outs[2] - w.grad).abs().max()) < 1e-3 * scale
     assert float((outs[2] - outs[1]).abs().max()) < 2e-4 * scale
+
+
+# the persistent LDS-DMA implicit GEMM (csrc/conv3d_pers.hip): (cin, cout, stride, transposed, op, dims) -- op "fwd" / "dgrad"
+PERS_CASES = [
+    (16, 16, 1, False, "fwd", (5, 9, 37)),      # conv2: stride-1, 16-channel chunk, ragged 4 x 4 x 16 tiles in all directions
+    (16, 16, 1, False, "dgrad", (4, 6, 20)),    # its input gradient (flipped taps) with summand + BatchNorm backward statistics
+    (8, 16, 2, False, "fwd", (6, 10, 36)),      # conv1: stride 2, 8 channels (two taps per k-step)
+    (16, 8, 2, True, "dgrad", (3, 5, 18)),      # conv11's input gradient: the same geometry through mvs_convT3d_dgrad
+    (32, 8, 1, False, "dgrad", (4, 7, 19)),     # conv0's input gradient: 8 -> 32 as two Cout tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("groups", [3, 0], ids=["three_persistent_workgroups", "one_tile_per_workgroup"])
+@pytest.mark.parametrize("cin,cout,stride,transposed,op,dims", PERS_CASES)
+def test_conv3d_persistent_lds_dma_kernel_equals_one_tile_kernel(emul_lib, cin, cout, stride, transposed, op, dims, groups):
+    """conv_pers_kernel walks several tiles per workgroup through a double-buffered LDS-DMA halo with the weight image resident in
+    LDS; outputs must equal the one-tile kernel's BIT FOR BIT (same packed image, same MFMA order over k), the statistic slots to
+    rounding (another summation order), with the epilogue's summand and backward statistics, at volume borders and ragged tiles."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(cin + 5 * cout + stride)
+    b = 2
+    x = torch.randn(b, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+
+    def run():
+        if op == "fwd":
+            y, slots = ops.conv3d_forward(x, w, stride, transposed, want_stats=True)
+            return y, slots.clone()
+        yshape = (F.conv_transpose3d(x, w, stride=stride, padding=1, output_padding=stride - 1) if transposed
+                  else F.conv3d(x, w, stride=stride, padding=1)).shape
+        gy = torch.randn(yshape, generator=torch.Generator().manual_seed(7))
+        raw = torch.randn(x.shape, generator=torch.Generator().manual_seed(8))
+        add = torch.randn(x.shape, generator=torch.Generator().manual_seed(9))
+        mean, var = raw.mean(dim=(0, 2, 3, 4)), raw.var(dim=(0, 2, 3, 4), unbiased=False)
+        invstd = torch.rsqrt(var + 1e-5)
+        stats = torch.stack([mean, invstd, 0.7 * invstd, 0.1 - mean * 0.7 * invstd]).contiguous()
+        slots = torch.zeros((8, 2, cin), dtype=torch.float64)
+        gx = ops.conv3d_dgrad(gy, w, tuple(x.shape), stride, transposed, add=add, bn=(raw, stats, slots))
+        return gx, slots
+
+    emul_lib.call("mvs_set_tuning", b"conv_pers", 0)
+    try:
+        ref, ref_slots = run()
+        emul_lib.call("mvs_set_tuning", b"conv_pers", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_min", 0)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_groups", groups)
+        got, got_slots = run()
+    finally:
+        emul_lib.call("mvs_set_tuning", b"conv_pers", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_min", 1024)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_groups", 0)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    s_ref, s_got = ref_slots.sum(-3), got_slots.sum(-3)
+    assert torch.allclose(s_got, s_ref, rtol=1e-5, atol=1e-4)

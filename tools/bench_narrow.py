@@ -43,7 +43,13 @@ def main():
     w11 = (torch.randn(16, 8, 3, 3, 3, generator=g) * 0.1).to(dev)       # conv11: transposed 16 -> 8 (weight [Cin=16][Cout=8])
     wp = (torch.randn(1, 8, 3, 3, 3, generator=g) * 0.1).to(dev)
     MB = 1e6
+    x32 = torch.randn(1, 32, D, H, W, generator=g).to(dev).contiguous(memory_format=cl)
+    w0 = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.1).to(dev)        # conv0: 32 -> 8
+    w2 = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1).to(dev)       # conv2: 16 -> 16 at level 1
     cases = [
+        ("conv0 dgrad (8@L0 -> 32@L0)", lambda: ops.conv3d_dgrad(x8, w0, tuple(x32.shape), 1, False), (126 + 503) * MB),
+        ("conv2 fwd 16>16 @L1 (+stats)", lambda: ops.conv3d_forward(x16, w2, 1, False, want_stats=True), 63 * MB),
+        ("conv2 dgrad + add", lambda: ops.conv3d_dgrad(x16, w2, tuple(x16.shape), 1, False, add=x16), 94.5 * MB),
         ("conv1 fwd 8>16 s2 (+stats)", lambda: ops.conv3d_forward(x8, w1, 2, False, want_stats=True), (126 + 31.5) * MB),
         ("conv1 dgrad (16@L1 -> 8@L0)", lambda: ops.conv3d_dgrad(x16, w1, tuple(x8.shape), 2, False), (126 + 31.5) * MB),
         ("conv1 dgrad + add", lambda: ops.conv3d_dgrad(x16, w1, tuple(x8.shape), 2, False, add=x8), (252 + 31.5) * MB),
