@@ -521,14 +521,6 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
 // walk tiles, keep dW for their (ci chunk, co chunk) in MFMA accumulators, and emit one partial
 // image each; wgrad_reduce sums the partial images deterministically.
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* x;      // [B,Di,Hi,Wi,CX]
-    const float* g;      // [B,QD,QH,QW,CG]
-    float* part;         // [gridDim.x][27][CX][CG]
-    int B, Di, Hi, Wi, CX, CG;
-    int QD, QH, QW, ntd, nth, ntw;
-    int xcd;             // XCD-aware tile order (conv_c8_wgrad_kernel)
-};
 
 template <int GEOM, int CC, int NBW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -1497,6 +1489,9 @@ int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size til
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)
 int g_conv_pers = 1;    // tuning knob "conv_pers": 1 = one-chunk layers (16 -> <= 16, 8 -> 32 stride 1; 8 -> <= 16 stride 2) run conv3d_pers.hip
 int g_conv_pers_min_wgs = 1024;   // tuning knob "conv_pers_min": ... when the one-tile kernel would launch at least this many workgroups (a persistent grid needs several tiles per workgroup)
+int g_conv_wgrad_pers = 1;   // tuning knob "wgrad_pers"
+bool conv_wgrad_pers_serves(int geom, int CX, int CG);
+int run_conv_wgrad_pers(int geom, const WgradArgs& a, int max_groups, hipStream_t st);
 bool conv_pers_serves(int geom, int cin, int cout);
 int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st);
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
@@ -1808,6 +1803,13 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
         int rc1 = mvs_check_launch("conv_wgrad_cg1");
         if (rc1) return rc1;
         return wgrad_finish(ws, groups, CX, CG, gw, st);
+    }
+    // knob "wgrad_pers": one-chunk layers with <= 16 gradient channels and many tiles through the persistent LDS-DMA kernel
+    // (conv3d_pers.hip): the level-0 / level-1 layers conv1, conv11 (stride 2, 8 X channels) and conv2 (stride 1, 16)
+    if (g_conv_wgrad_pers && conv_wgrad_pers_serves(geom, CX, CG) && ntiles >= g_conv_pers_min_wgs) {
+        const int np = run_conv_wgrad_pers(geom, a, WGRAD_MAX_GROUPS, st);
+        if (np < 0) return np;
+        return wgrad_finish(ws, np, CX, CG, gw, st);
     }
     // knob "wgrad_small": quarter-size tiles (the *_SMALL geometries) for the generic kernel when the launch has many tiles anyway:
     // a stride-2 layer with 8 X channels (the L0 layers) holds a 5x9x33-voxel halo + the G tile = 87 KB of LDS per workgroup, ONE

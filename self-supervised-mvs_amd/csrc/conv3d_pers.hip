@@ -281,3 +281,177 @@ int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st) {
     mvs_set_error("conv_pers: geometry %d with %d input channels is not served", geom, a.Cin);
     return MVS_ERR_UNSUPPORTED;
 }
+
+// ================================================================================================
+// Weight gradient, same staging:  dW[tap][ci][co] = sum_{b,o} X[b, o*S + tap - 1][ci] * G[b,o][co]
+// GEMM view as in conv_wgrad_kernel (conv3d.hip): M = ci (CC = 16) or (tap pair, ci) (CC = 8), N = co (<= 16), K = positions.
+// conv_wgrad_kernel already walks tiles with persistent workgroups, but stages through registers (24-44 of them held across the
+// MFMA loop) into PADDED LDS tiles of 71-87 KB: ONE workgroup of four waves per CU, one wave per SIMD, nothing to cover its
+// ds_write pass and two barriers per tile (the level-0 layers: 0.108 ms for 22 us of MFMA work and 20 us of HBM time).  Here:
+//   * the X halo AND the G tile of the next tile arrive by LDS-DMA into the other half of a double buffer (unpadded: the A reads
+//     are ds_read_b32 of 16 consecutive floats per lane group -- a 16-float position pitch keeps the four groups of a wave on
+//     64 consecutive floats);
+//   * eight waves share a tile: waves 0-3 take the even k-steps (four positions each), waves 4-7 the odd ones, every wave
+//     with the full set of tap slots of its rank (7 or 4 MFMAs per k-step on independent accumulators); the two halves meet in LDS
+//     once, at the end of the kernel;
+//   * one fence-free barrier per tile.
+// Each workgroup writes ONE partial image; wgrad_finish (conv3d.hip) sums them in a fixed order.  The products are the same as
+// conv_wgrad_kernel's, the order of the K sum differs (another split of the positions), so results agree to fp32 rounding.
+// ================================================================================================
+template <int GEOM, int CC>
+__global__ __launch_bounds__(512) void conv_wgrad_pers_kernel(WgradArgs a) {
+    using G = ConvGeom<GEOM>;
+    constexpr int NW = 8;
+    constexpr int CQ = CC / 4;
+    constexpr int NR = G::RD * G::RH * G::RW;
+    constexpr int NPOS = G::TQD * G::TQH * G::TQW;
+    constexpr int XITEMS = NR * CQ, GITEMS = NPOS * 4;                     // 16-byte items: X halo, G tile (16 floats per position)
+    constexpr int XDMA = (XITEMS + 63) / 64, GDMA = GITEMS / 64;           // wave-level DMA instructions
+    constexpr int NDMA = XDMA + GDMA;
+    constexpr int DPW = (NDMA + NW - 1) / NW;
+    constexpr int XF = XDMA * 256, BUFF = XF + GITEMS * 4;                 // floats: X part, whole buffer
+    constexpr int NSLOT = CC == 16 ? 27 : 14;                              // CC == 8: a slot is a pair of taps (2s, 2s+1)
+    constexpr int SPW = (NSLOT + 3) / 4;                                   // slots per wave (waves w and w + 4 share a slot set)
+    constexpr int NKS = NPOS / 4;                                          // k-steps of a tile (4 positions each)
+    static_assert(G::TQW == 16 && NKS % 2 == 0, "a k-step is four consecutive positions of one row");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUFF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int w4 = wave & 3, half = wave >> 2;
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+
+    // ---- per-lane DMA items ----
+    int rel[DPW], crd[DPW];      // crd: X items (rd | rh << 8 | rw << 16), G items (pd | ph << 8 | pw << 16 | 1 << 30), -1: none
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int d = NW * j + wave;
+        rel[j] = 0; crd[j] = -1;
+        if (d < XDMA) {
+            const int i = 64 * d + lane, vox = i / CQ, cq = i % CQ;
+            const int rw = vox % G::RW, rh = (vox / G::RW) % G::RH, rd = vox / (G::RW * G::RH);
+            rel[j] = ((rd * a.Hi + rh) * a.Wi + rw) * CC + 4 * cq;
+            if (i < XITEMS) crd[j] = rd | (rh << 8) | (rw << 16);
+        } else if (d < NDMA) {
+            const int i = 64 * (d - XDMA) + lane, p = i >> 2, n4 = i & 3;
+            const int pw = p % G::TQW, ph = (p / G::TQW) % G::TQH, pd = p / (G::TQW * G::TQH);
+            rel[j] = ((pd * a.QH + ph) * a.QW + pw) * a.CG + 4 * n4;
+            if (4 * n4 < a.CG) crd[j] = pd | (ph << 8) | (pw << 16) | (1 << 30);
+        }
+    }
+    const float* __restrict__ zero = g_conv_zero_page;
+    auto issue = [&](int t, int buf) {
+        int b, td, th, tw;
+        linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+        const int id0 = qd0 * G::IS - 1, ih0 = qh0 * G::IS - 1, iw0 = qw0 * G::IS - 1;
+        const float* __restrict__ xb = a.x + ((((long long)b * a.Di + id0) * a.Hi + ih0) * a.Wi + iw0) * CC;
+        const float* __restrict__ gb = a.g + ((((long long)b * a.QD + qd0) * a.QH + qh0) * a.QW + qw0) * a.CG;
+        const bool interior = id0 >= 0 && id0 + G::RD <= a.Di && ih0 >= 0 && ih0 + G::RH <= a.Hi && iw0 >= 0 && iw0 + G::RW <= a.Wi &&
+                              qd0 + G::TQD <= a.QD && qh0 + G::TQH <= a.QH && qw0 + G::TQW <= a.QW;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int d = NW * j + wave;
+            if (d >= NDMA) break;                    // wave-uniform
+            const bool is_g = d >= XDMA;             // wave-uniform
+            const float* src = (is_g ? gb : xb) + rel[j];
+            bool ok = crd[j] >= 0;
+            if (!interior) {
+                const int c0 = crd[j] & 255, c1 = (crd[j] >> 8) & 255, c2 = (crd[j] >> 16) & 255;
+                if (is_g) ok = ok && qd0 + c0 < a.QD && qh0 + c1 < a.QH && qw0 + c2 < a.QW;
+                else ok = ok && id0 + c0 >= 0 && id0 + c0 < a.Di && ih0 + c1 >= 0 && ih0 + c1 < a.Hi && iw0 + c2 >= 0 && iw0 + c2 < a.Wi;
+            }
+            if (!ok) src = zero + 4 * (lane & 15);
+            MVS_DMA16(&lds[buf * BUFF + (is_g ? XF + (d - XDMA) * 256 : d * 256)], src);
+        }
+    };
+
+    // ---- per-lane A offsets of the wave's tap slots (floats inside the X part), incl. the lane group's position g of a k-step ----
+    int toff[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int slot = w4 + 4 * s;
+        int tap = CC == 16 ? slot : 2 * slot + (l15 >> 3);
+        if (slot >= NSLOT || tap > 26) tap = 0;      // a slot past the end computes unused values from tap 0 (no branch in the loop)
+        const int ci = CC == 16 ? l15 : (l15 & 7);
+        toff[s] = (((tap / 9) * G::RH + (tap / 3) % 3) * G::RW + tap % 3 + g * G::IS) * CC + ci;
+    }
+    f32x4 acc[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    MVS_WAIT_VMCNT(0);
+    __syncthreads();
+
+    int it = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x, buf ^ 1);
+        const int xb0 = buf * BUFF, gb0 = buf * BUFF + XF;
+#pragma unroll
+        for (int k2 = 0; k2 < NKS / 2; ++k2) {
+            // this wave's k-step: 2*k2 + half (half is wave-uniform; both candidates are constants after unrolling)
+            const int ks0 = 2 * k2, ks1 = 2 * k2 + 1;
+            auto rowoff = [](int ks) {
+                const int p = 4 * ks, pw = p % G::TQW, ph = (p / G::TQW) % G::TQH, pd = p / (G::TQW * G::TQH);
+                return (((pd * G::IS) * G::RH + ph * G::IS) * G::RW + pw * G::IS) * CC;
+            };
+            const int xo = xb0 + (half ? rowoff(ks1) : rowoff(ks0));
+            const int go = gb0 + 64 * (half ? ks1 : ks0) + lane;
+            const float bv = lds[go];
+            float av[SPW];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) av[s] = lds[xo + toff[s]];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) acc[s] = MVS_MFMA_16x16x4(av[s], bv, acc[s]);
+        }
+        MVS_WAIT_VMCNT(0);       // the next tile's DMA has landed (it was requested a whole tile of MFMAs ago)
+        MVS_LDS_BARRIER();
+    }
+
+    // ---- the two halves of the K split meet in LDS; half 0 writes the workgroup's partial image ----
+    __syncthreads();
+    if (half == 1) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[((w4 * SPW + s) * 4 + r) * 64 + lane] = acc[s][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int slot = w4 + 4 * s;
+            if (slot >= NSLOT) continue;
+            const int co = l15;
+            if (co >= a.CG) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[s][r] + lds[((w4 * SPW + s) * 4 + r) * 64 + lane];
+                const int i = 4 * g + r;            // D layout: row = 4*(lane>>4)+r -> M index, col = lane&15 -> co
+                int tap, ci;
+                if (CC == 16) { tap = slot; ci = i; }
+                else { tap = 2 * slot + (i >> 3); ci = i & 7; }
+                if (tap < 27) a.part[(((size_t)blockIdx.x * 27 + tap) * a.CX + ci) * a.CG + co] = v;
+            }
+        }
+    }
+}
+
+bool conv_wgrad_pers_serves(int geom, int CX, int CG) {
+    if (CG > 16 || CG % 4) return false;
+    return (geom == GEOM_S1 && CX == 16) || (geom == GEOM_S2 && CX == 8);
+}
+
+// a: as run_wgrad fills it for the full-size tiles of `geom`; returns the number of partial images written (one per workgroup), < 0 on error
+int run_conv_wgrad_pers(int geom, const WgradArgs& a, int max_groups, hipStream_t st) {
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    int groups = g_conv_pers_groups > 0 ? g_conv_pers_groups : 256;       // 111-115 KB of LDS: one workgroup (8 waves) per CU
+    if (groups > ntiles) groups = ntiles;
+    if (groups > max_groups) groups = max_groups;
+    if (geom == GEOM_S1) MVS_LAUNCH((conv_wgrad_pers_kernel<GEOM_S1, 16>), dim3(groups), dim3(512), 0, st, a);
+    else MVS_LAUNCH((conv_wgrad_pers_kernel<GEOM_S2, 8>), dim3(groups), dim3(512), 0, st, a);
+    const int rc = mvs_check_launch("conv_wgrad_pers");
+    return rc ? rc : groups;
+}

@@ -20,6 +20,16 @@ struct ConvArgs {
     int nb_total;           // 16-wide Cout tiles in the packed weight image; a workgroup handles NB of them from blockIdx.y*NB
 };
 
+// weight-gradient kernels (conv3d.hip, conv3d_pers.hip)
+struct WgradArgs {
+    const float* x;      // [B,Di,Hi,Wi,CX]
+    const float* g;      // [B,QD,QH,QW,CG]
+    float* part;         // [gridDim.x][27][CX][CG]
+    int B, Di, Hi, Wi, CX, CG;
+    int QD, QH, QW, ntd, nth, ntw;
+    int xcd;             // XCD-aware tile order (conv_c8_wgrad_kernel)
+};
+
 // ------------------------------------------------------------------------------------------------
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
 // xcd_block() gives every XCD one contiguous range of the tile order, and brick_tile() makes that order bricks

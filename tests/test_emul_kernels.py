@@ -1543,3 +1543,38 @@ def test_conv3d_persistent_lds_dma_kernel_equals_one_tile_kernel(emul_lib, cin, 
     assert torch.equal(got, ref), float((got - ref).abs().max())
     s_ref, s_got = ref_slots.sum(-3), got_slots.sum(-3)
     assert torch.allclose(s_got, s_ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("groups", [3, 0], ids=["three_persistent_workgroups", "one_tile_per_workgroup"])
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", [
+    (16, 16, 1, False, (5, 6, 21)),     # conv2: stride 1, 16 X channels, ragged tiles
+    (8, 16, 2, False, (6, 10, 36)),     # conv1: stride 2, 8 X channels (tap pairs), X = the layer input
+    (16, 8, 2, True, (3, 5, 18)),       # conv11 (transposed): X = the OUTPUT gradient (8 channels, fine grid), G = the input
+    (8, 8, 2, False, (4, 8, 20)),       # 8 gradient channels: half of the G tile's 16-float rows stays zero
+])
+def test_conv3d_persistent_weight_gradient(emul_lib, cin, cout, stride, transposed, dims, groups):
+    """conv_wgrad_pers_kernel (double-buffered LDS-DMA tiles, eight waves, K split over two wave groups) against autograd and
+    against the register-staged kernel it replaces for these layers."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    x = torch.randn(2, cin, *dims, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = (torch.randn(wshape, generator=g) * 0.2).requires_grad_(True)
+    y = F.conv_transpose3d(x, w, stride=stride, padding=1, output_padding=stride - 1) if transposed else F.conv3d(x, w, stride=stride, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    emul_lib.call("mvs_set_tuning", b"wgrad_pers", 0)
+    try:
+        old = ops.conv3d_wgrad(x, gy, wshape, stride, transposed)
+        emul_lib.call("mvs_set_tuning", b"wgrad_pers", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_min", 0)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_groups", groups)
+        new = ops.conv3d_wgrad(x, gy, wshape, stride, transposed)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"wgrad_pers", 1)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_min", 1024)
+        emul_lib.call("mvs_set_tuning", b"conv_pers_groups", 0)
+    scale = max(1.0, float(w.grad.abs().max()))
+    assert float((new - w.grad).abs().max()) < 1e-3 * scale
+    assert float((new - old).abs().max()) < 2e-4 * scale
+    assert not torch.equal(new, torch.zeros_like(new))
