@@ -1709,6 +1709,10 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
         a.ntd = mvs_cdiv(a.QD, geom_tqd(geom)); a.nth = mvs_cdiv(a.QH, geom_tqh(geom));
         return run_conv_pers(geom, a, st);
     }
+    // (the transposed 16 -> 8 layers: conv11 forward, conv1's input gradient -- when the W-parity-merged image was packed)
+    if ((g_conv_pers & 1) && kgeom == GEOM_TR2 && cc == 16 && cout == 8 && g_conv_tr2pw && conv_pers_serves(GEOM_TR2_PW, cin, cout) &&
+        nblocks >= g_conv_pers_min_wgs)
+        return run_conv_pers(GEOM_TR2_PW, a, st);
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);

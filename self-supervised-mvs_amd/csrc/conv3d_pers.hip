@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pers_kernel(ConvArgs a) {
     constexpr int NDMA = (NITEMS + 63) / 64;     // wave-level DMA instructions per tile
     constexpr int DPW = (NDMA + NW - 1) / NW;    // ... per wave
     constexpr int TILEF = NDMA * 256;            // floats per buffer (whole DMA instructions)
-    constexpr int KS = (27 * CC + 15) / 16;      // ksteps_for(27, CC)
+    constexpr int KS = G::PW ? 18 * CC / 16 : (27 * CC + 15) / 16;      // k-steps of the whole weight image (conv_map.h: total_ksteps)
     __shared__ __attribute__((aligned(16))) float tile[2 * TILEF];
     __shared__ __attribute__((aligned(16))) float wl[KS * NB * 256];
     __shared__ float red[NW * NB * 16 * 2];
@@ -103,16 +103,19 @@ __global__ __launch_bounds__(NW * 64) void conv_pers_kernel(ConvArgs a) {
     }
     const int tsel = CC == 8 ? (g >> 1) : 0;     // CC == 8: a k-step of 16 is two taps; lanes g = 2, 3 take the second
 
-    float st1[NB], st2[NB], bmu[NB], bis[NB], bsc[NB], bsh[NB];
+    // BatchNorm statistics (and, with bn_raw, the normalisation constants) of the lane's four channels 4g .. 4g+3 of each Cout tile
+    float st1[NB][4], st2[NB][4], bmu[NB][4], bis[NB][4], bsc[NB][4], bsh[NB][4];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        st1[nb] = st2[nb] = 0.f;
-        bmu[nb] = bis[nb] = bsc[nb] = bsh[nb] = 0.f;
-        if (SIDE && a.bn_raw) {
-            const int co = (nb0 + nb) * 16 + l15;
-            if (co < a.Cout) { bmu[nb] = a.bn_stats[co]; bis[nb] = a.bn_stats[a.Cout + co]; bsc[nb] = a.bn_stats[2 * a.Cout + co]; bsh[nb] = a.bn_stats[3 * a.Cout + co]; }
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st1[nb][r] = st2[nb][r] = 0.f;
+            bmu[nb][r] = bis[nb][r] = bsc[nb][r] = bsh[nb][r] = 0.f;
+            if (SIDE && a.bn_raw) {
+                const int co = (G::PW ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g) + r;
+                if (co < a.Cout) { bmu[nb][r] = a.bn_stats[co]; bis[nb][r] = a.bn_stats[a.Cout + co]; bsc[nb][r] = a.bn_stats[2 * a.Cout + co]; bsh[nb][r] = a.bn_stats[3 * a.Cout + co]; }
+            }
         }
-    }
 
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
     MVS_WAIT_VMCNT(0);
@@ -124,90 +127,98 @@ __global__ __launch_bounds__(NW * 64) void conv_pers_kernel(ConvArgs a) {
         if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x, buf ^ 1);     // lands under this tile's MFMAs
         const int tb = buf * TILEF;        // (indexing the __shared__ arrays themselves keeps the accesses ds_read_b128, not flat loads)
 
-        f32x4 acc[MB][NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // operands of k-step ks + 1 are requested from LDS before the MFMAs of k-step ks; the MFMAs of a k-step walk the accumulators
-        // round-robin (x of every (mb, nb), then y, ...), so back-to-back MFMAs never wait for each other's result
-        auto toff_of = [&](int ks) {      // the lane's tap of k-step ks -> float offset inside the halo tile (ks: constant after unrolling)
-            if (CC == 16) return (((ks / 9) * G::RH + (ks / 3) % 3) * G::RW + ks % 3) * CC;
-            const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 26;      // (tap 27: its weights are zero; the lane re-reads tap 26)
-            const int o0 = (((t0 / 9) * G::RH + (t0 / 3) % 3) * G::RW + t0 % 3) * CC;
-            const int o1 = (((t1 / 9) * G::RH + (t1 / 3) % 3) * G::RW + t1 % 3) * CC;
-            return tsel ? o1 : o0;
-        };
-        float4 bq[2][NB], af[2][MB];
-        auto fetch = [&](int ks, float4 (&bv)[NB], float4 (&av)[MB]) {
-            const int toff = toff_of(ks);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wl[((ks * NB + nb) * 64 + lane) * 4]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const float4*>(&tile[tb + aoff[mb] + toff]);
-        };
-        fetch(0, bq[0], af[0]);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) fetch(ks + 1, bq[(ks + 1) & 1], af[(ks + 1) & 1]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = MVS_MFMA_16x16x4(f4c(af[ks & 1][mb], c), f4c(bq[ks & 1][nb], c), acc[mb][nb]);
-        }
-        // the next tile's DMA (requested a whole k-loop ago) has landed; so have the previous epilogue's stores
-        MVS_WAIT_VMCNT(0);
-
-        // ---- epilogue: D layout col = lane&15 (co), row = 4*(lane>>4)+r (position along qw) ----
         int b, td, th, tw;
         linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
         const int qd0 = td * G::TQD, qh0 = th * G::TQH, qw0 = tw * G::TQW;
+        // GEOM_TR2_PW: four (pd, ph) parity classes, each its own k-loop (2 / 4 / 4 / 8 taps) and epilogue; the 8-tap class runs
+        // FIRST so that the next tile's DMA has landed when the first epilogue's loads queue up behind it
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int f = wave * MB + mb;
-            const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
-            const bool row_ok = qd < a.QD && qh < a.QH;
-            float sk[4][NB], rwv[4][NB];
-            if (SIDE) {
+        for (int cix = 0; cix < G::NCLS; ++cix) {
+            const int cls = G::PW ? G::NCLS - 1 - cix : 0;
+            const int KSC = G::PW ? tr2p_ntaps(cls) * CC / 16 : KS;          // k-steps of this class
+            const int kk0 = G::PW ? tr2p_tap_prefix(cls) * CC / 16 : 0;      // ... and where they start in the weight image
+            f32x4 acc[MB][NB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qw = qw0 + 4 * g + r;
-                    const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int co = (nb0 + nb) * 16 + l15;
-                        const bool ok = row_ok && qw < a.QW && co < a.Cout;
-                        sk[r][nb] = (ok && a.skip) ? a.skip[obase + co] : 0.f;
-                        rwv[r][nb] = (ok && a.bn_raw) ? a.bn_raw[obase + co] : 0.f;
-                    }
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // operands of k-step ks + 1 are requested from LDS before the MFMAs of k-step ks; the MFMAs of a k-step walk the accumulators
+            // round-robin (x of every (mb, nb), then y, ...), so back-to-back MFMAs never wait for each other's result
+            auto toff_of = [&](int ks) {      // the lane's tap of k-step ks -> float offset inside the halo tile (ks: constant after unrolling)
+                if (G::PW) {                  // CC == 16: one tap per k-step
+                    int dd, dh, dw, kd, kh;
+                    tr2p_tap(cls, ks, dd, dh, dw, kd, kh);
+                    return ((dd * G::RH + dh) * G::RW + dw) * CC;
                 }
-            }
-            if (!row_ok) continue;
+                if (CC == 16) return (((ks / 9) * G::RH + (ks / 3) % 3) * G::RW + ks % 3) * CC;
+                const int t0 = 2 * ks, t1 = 2 * ks + 1 < 27 ? 2 * ks + 1 : 26;      // (tap 27: its weights are zero; the lane re-reads tap 26)
+                const int o0 = (((t0 / 9) * G::RH + (t0 / 3) % 3) * G::RW + t0 % 3) * CC;
+                const int o1 = (((t1 / 9) * G::RH + (t1 / 3) % 3) * G::RW + t1 % 3) * CC;
+                return tsel ? o1 : o0;
+            };
+            float4 bq[2][NB], af[2][MB];
+            auto fetch = [&](int ks, float4 (&bv)[NB], float4 (&av)[MB]) {
+                const int toff = toff_of(ks);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qw = qw0 + 4 * g + r;
-                if (qw >= a.QW) continue;
-                const size_t obase = ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * a.Cout;
+                for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wl[(((kk0 + ks) * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[mb] = *reinterpret_cast<const float4*>(&tile[tb + aoff[mb] + toff]);
+            };
+            fetch(0, bq[0], af[0]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks >= KSC) break;         // (compile-time after unrolling)
+                if (ks + 1 < KSC) fetch(ks + 1, bq[(ks + 1) & 1], af[(ks + 1) & 1]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = MVS_MFMA_16x16x4(f4c(bq[ks & 1][nb], c), f4c(af[ks & 1][mb], c), acc[mb][nb]);   // D^T: rows = channels
+            }
+            // the next tile's DMA (requested a whole k-loop ago) has landed; so have the previous epilogue's stores
+            if (cix == 0) MVS_WAIT_VMCNT(0);
+
+            // ---- epilogue of the class.  The WEIGHT fragment is the MFMA's A operand (the packed image serves as either operand:
+            // lane (l15, g) holds W[k = 4g..][co = l15]), so D = (W^T X^T): row = 4*(lane>>4)+r -> output channel, col = lane&15 ->
+            // position along qw.  A lane ends with FOUR CONSECUTIVE CHANNELS of one voxel: the side inputs are read and the result is
+            // written as float4, and a wave instruction covers 16 voxels x 64 bytes = 1 KiB of contiguous memory (the one-tile kernel's
+            // D has the positions in the lane's registers: 4-byte accesses, four instructions for the same bytes).
+            // PW: row n = pw*8 + co -> lanes g = 0, 1 are the two channel quads of output voxel 2*qw, g = 2, 3 of voxel 2*qw + 1 ----
+            const int pd = G::PW ? (cls >> 1) & 1 : 0, ph = G::PW ? cls & 1 : 0, pw = G::PW ? (g >> 1) : 0;
+            const int qw = qw0 + l15;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int f = wave * MB + mb;
+                const int qd = qd0 + f / G::TQH, qh = qh0 + f % G::TQH;
+                const int od = qd * G::OS + pd, oh = qh * G::OS + ph;
+                const size_t obase = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + qw * G::OS + pw) * a.Cout;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int co = (nb0 + nb) * 16 + l15;
-                    if (co >= a.Cout) continue;
-                    float v = acc[mb][nb][r];
-                    float sv1 = v, sv2 = v * v;
-                    if (a.scale) v = v * a.scale[co] + a.shift[co];
-                    else if (a.shift) v = v + a.shift[co];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (SIDE && a.skip) v += sk[r][nb];
-                    if (SIDE && a.bn_raw) {
-                        sv1 = (rwv[r][nb] * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
-                        sv2 = sv1 * ((rwv[r][nb] - bmu[nb]) * bis[nb]);
+                    const int co0 = G::PW ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g;
+                    if (!(qd < a.QD && qh < a.QH && qw < a.QW && co0 < a.Cout)) continue;
+                    float4 sk = make_float4(0.f, 0.f, 0.f, 0.f), rw = sk;
+                    if (SIDE && a.skip) sk = *reinterpret_cast<const float4*>(a.skip + obase + co0);
+                    if (SIDE && a.bn_raw) rw = *reinterpret_cast<const float4*>(a.bn_raw + obase + co0);
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mb][nb][r];
+                        float sv1 = v, sv2 = v * v;
+                        if (a.scale) v = v * a.scale[co0 + r] + a.shift[co0 + r];
+                        else if (a.shift) v = v + a.shift[co0 + r];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (SIDE && a.skip) v += f4c(sk, r);
+                        if (SIDE && a.bn_raw) {
+                            sv1 = (f4c(rw, r) * bsc[nb][r] + bsh[nb][r] > 0.f) ? v : 0.f;
+                            sv2 = sv1 * ((f4c(rw, r) - bmu[nb][r]) * bis[nb][r]);
+                        }
+                        st1[nb][r] += sv1;
+                        st2[nb][r] += sv2;
+                        o[r] = v;
                     }
-                    st1[nb] += sv1;
-                    st2[nb] += sv2;
-                    a.y[obase + co] = v;
+                    *reinterpret_cast<float4*>(a.y + obase + co0) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
         }
@@ -217,16 +228,20 @@ __global__ __launch_bounds__(NW * 64) void conv_pers_kernel(ConvArgs a) {
     }
 
     if (a.slots) {
+        // the 16 lanes of a group hold 16 positions of the same four channels: sum over them, then over the waves
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            float s1 = st1[nb], s2 = st2[nb];
-            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            if (lane < 16) {
-                red[((wave * NB + nb) * 16 + lane) * 2 + 0] = s1;
-                red[((wave * NB + nb) * 16 + lane) * 2 + 1] = s2;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = st1[nb][r], s2 = st2[nb][r];
+                s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 8);
+                s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+                if (G::PW) { s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); }   // rows n and n ^ 8 are the same channel (pw = 0 / 1)
+                if (l15 == 0 && (!G::PW || g < 2)) {
+                    red[((wave * NB + nb) * 16 + 4 * g + r) * 2 + 0] = s1;
+                    red[((wave * NB + nb) * 16 + 4 * g + r) * 2 + 1] = s2;
+                }
             }
-        }
         __syncthreads();
         if (tid < 2 * NB * 16) {
             const int stat = tid / (NB * 16), n = tid % (NB * 16);
@@ -246,7 +261,7 @@ template <int GEOM, int CC, int NB>
 static int pers_lds_bytes() {
     using G = ConvGeom<GEOM>;
     constexpr int NDMA = (G::RD * G::RH * G::RW * (CC / 4) + 63) / 64;
-    return (2 * NDMA * 256 + ((27 * CC + 15) / 16) * NB * 256 + 4 * NB * 16 * 2) * 4;
+    return (2 * NDMA * 256 + (G::PW ? 18 * CC / 16 : (27 * CC + 15) / 16) * NB * 256 + 8 * NB * 16 * 2) * 4;
 }
 
 template <int GEOM, int CC, int NB, int NW>
@@ -263,8 +278,10 @@ static int launch_pers(const ConvArgs& a, hipStream_t st) {
 
 // Does the persistent kernel serve this op?  (one channel chunk; a.* filled as run_igemm does for the full-size tiles of `geom`)
 bool conv_pers_serves(int geom, int cin, int cout) {
+    if (cout % 4) return false;           // (a lane writes four consecutive channels)
     if (geom == GEOM_S1) return (cin == 16 && cout <= 16) || (cin == 8 && cout > 16 && cout <= 32);
     if (geom == GEOM_S2) return cin == 8 && cout <= 16;
+    if (geom == GEOM_TR2_PW) return cin == 16 && cout == 8;      // (the caller has packed the W-parity-merged image)
     return false;
 }
 
@@ -275,6 +292,7 @@ int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st) {
         if (geom == GEOM_S1 && a.Cin == 8) return launch_pers<GEOM_S1, 8, 2, 8>(a, st);
         if (geom == GEOM_S2 && a.Cin == 8) return launch_pers<GEOM_S2, 8, 1, 8>(a, st);
     }
+    if (geom == GEOM_TR2_PW && a.Cin == 16) return launch_pers<GEOM_TR2_PW, 16, 1, 8>(a, st);
     if (geom == GEOM_S1 && a.Cin == 16) return launch_pers<GEOM_S1, 16, 1, 4>(a, st);
     if (geom == GEOM_S1 && a.Cin == 8) return launch_pers<GEOM_S1, 8, 2, 4>(a, st);
     if (geom == GEOM_S2 && a.Cin == 8) return launch_pers<GEOM_S2, 8, 1, 4>(a, st);

@@ -1497,6 +1497,8 @@ PERS_CASES = [
     (8, 16, 2, False, "fwd", (6, 10, 36)),      # conv1: stride 2, 8 channels (two taps per k-step)
     (16, 8, 2, True, "dgrad", (3, 5, 18)),      # conv11's input gradient: the same geometry through mvs_convT3d_dgrad
     (32, 8, 1, False, "dgrad", (4, 7, 19)),     # conv0's input gradient: 8 -> 32 as two Cout tiles per workgroup
+    (16, 8, 2, True, "fwd", (5, 6, 19)),        # conv11: transposed stride 2, 16 -> 8 as W-parity-merged GEMMs (four classes per tile)
+    (8, 16, 2, False, "dgrad", (10, 12, 38)),   # conv1's input gradient: the same geometry with summand + backward statistics
 ]
 
 
