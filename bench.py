@@ -738,6 +738,9 @@ def main():
             elif spec == "feature_fused_apply":
                 def setter(on, base=_ops.FEATURE_FUSED_APPLY):
                     _ops.FEATURE_FUSED_APPLY = (not base) if on else base
+            elif spec == "feature_wgrad_early":
+                def setter(on, base=_ops.FEATURE_WGRAD_EARLY):
+                    _ops.FEATURE_WGRAD_EARLY = (not base) if on else base
             elif spec == "feature_wgrad_batch":
                 def setter(on, base=_ops.FEATURE_WGRAD_BATCH):
                     _ops.FEATURE_WGRAD_BATCH = (not base) if on else base

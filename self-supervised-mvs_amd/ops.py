@@ -1031,6 +1031,9 @@ FEATURE_FUSED_APPLY = os.environ.get("MVS_FEATURE_FUSED_APPLY", "1") != "0"
 FEATURE_DGRAD_BNSTATS = os.environ.get("MVS_FEATURE_DGRAD_BNSTATS", "0") == "1"
 
 
+FEATURE_WGRAD_EARLY = os.environ.get("MVS_FEATURE_WGRAD_EARLY", "1") != "0"
+
+
 class FeatureExtractorFn(torch.autograd.Function):
     """A chain of 2-D ConvBnReLU blocks closed by a plain convolution with bias -- FeatureNet (jdacs/models/mvsnet.py:17-34) -- in
     TRAINING as ONE autograd node: the same kernels in the same order as the per-block graph (conv2d.hip forward with BatchNorm's
@@ -1133,11 +1136,28 @@ class FeatureExtractorFn(torch.autograd.Function):
                               [True, bool(need[3 + 5 * n]), bool(need[3 + 5 * n + 1])])
             grads[5 * n], grads[5 * n + 1] = gfw, gfb
         have = False     # the block's backward statistics are already in its slots (the input gradient above it put them there)
+        # FEATURE_WGRAD_EARLY: the weight gradients of the LAST layers (the 32-channel ones: two of the batch kernel's three launches'
+        # worth of MFMA work) are enqueued on the side stream as soon as their output gradients exist and run next to the rest of
+        # this backward pass -- the main stream is the step's critical path (bench.py --step-events: the side stream ends 0.13 ms
+        # before it), so what leaves it shortens the step.  Joined before this node returns.
+        early_from = None
+        if batch and FEATURE_WGRAD_EARLY and _ASYNC_WGRAD_FUSED and gout.is_cuda and n >= 4:
+            early_from = next((i for i in range(n) if ws_[i].shape[0] >= 32), None)     # first block with >= 32 output channels
+            if early_from is not None and not (0 < early_from < n):
+                early_from = None
+        early_gws = None
         for i in range(n - 1, -1, -1):
             stride, padding, eps, momentum, hip_dgrad = cfg[i]
             draw, grads[5 * i + 1], grads[5 * i + 2] = bn_relu_bwd_slots(g, raws[i], statss[i], slots_b[i], have, True, groups)
             have = False
             draws[i] = draw
+            if early_from is not None and i == early_from:
+                main = torch.cuda.current_stream(gout.device)
+                side = _side_stream(gout.device)
+                side.wait_stream(main)
+                lo = early_from
+                early_gws = conv2d_wgrad_batch(list(acts[lo:]), draws[lo:] + [gout], list(ws_[lo:]) + [fw], [c[0] for c in cfg[lo:]] + [1],
+                                               None if x_stats is None else x_stats[lo:], groups, on_stream=side)
             w = ws_[i]
             want_x = i > 0 or need[0]
             if want_x and hip_dgrad:
@@ -1155,7 +1175,15 @@ class FeatureExtractorFn(torch.autograd.Function):
                 if want_x:
                     g = gx
                 grads[5 * i] = gw
-        if batch:
+        if batch and early_gws is not None:
+            lo = early_from
+            gws = conv2d_wgrad_batch(list(acts[:lo]), draws[:lo], list(ws_[:lo]), [c[0] for c in cfg[:lo]], None if x_stats is None else x_stats[:lo], groups)
+            for i in range(lo):
+                grads[5 * i] = gws[i]
+            for k, i in enumerate(range(lo, n + 1)):
+                grads[5 * i] = early_gws[k]
+            _join_side(torch.cuda.current_stream(gout.device), gout.device.index)     # complete before autograd sees them
+        elif batch:
             gws = conv2d_wgrad_batch(list(acts), draws + [gout], list(ws_) + [fw], [c[0] for c in cfg] + [1], x_stats, groups)
             for i in range(n + 1):
                 grads[5 * i] = gws[i]
@@ -1486,13 +1514,16 @@ def _wgrad_batch_plan(lib, key):
     return int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", len(key) // 8, arr)), arr
 
 
-def conv2d_wgrad_batch(xs, gys, weights, strides, x_stats=None, groups=1):
+def conv2d_wgrad_batch(xs, gys, weights, strides, x_stats=None, groups=1, on_stream=None):
     """Weight gradients of several Conv2d layers (x_i channels-last [N,Cin,H,W], gy_i channels-last [N,Cout,Ho,Wo], pad k//2) in
     ONE launch + one reduction launch; -> gradients with the shape AND memory layout of `weights` (contiguous or channels-last
     parameters alike, so autograd's AccumulateGrad takes them over without a copy).  x_stats: per layer None or the [groups,4,Cin]
-    statistics of the BatchNorm + ReLU block whose RAW output x_i is (the layer's input is normalised while it is staged)."""
+    statistics of the BatchNorm + ReLU block whose RAW output x_i is (the layer's input is normalised while it is staged).
+    on_stream: a torch stream other than the current one to enqueue the two launches on (the caller has made it wait for the
+    producers of xs / gys); outputs and workspace come from the current stream's pool and are handed over with record_stream."""
     lib = _lib_for(xs[0])
     xs, gys = [as_cl2(t) for t in xs], [as_cl2(t) for t in gys]
+    st_handle = _stream(xs[0]) if on_stream is None else on_stream.cuda_stream
     shapes = _wgrad_batch_shapes(xs, weights, strides)
     nfl, arr = _wgrad_batch_plan(lib, tuple(shapes)) if shapes is not None else (-1, None)
     if nfl < 0:
@@ -1510,9 +1541,12 @@ def conv2d_wgrad_batch(xs, gys, weights, strides, x_stats=None, groups=1):
                     raise ValueError("conv2d_wgrad_batch: x_stats[%d] %s does not match %d groups of [4,%d]" % (i, tuple(t.shape), groups, x.shape[1]))
                 st[i] = t.data_ptr()
         lib.call("mvs_conv2d_wgrad_batch_xf", len(xs), _ptr_array(xs), st, n_img // groups, _ptr_array(gys), _ptr_array(gws), _p(ws), arr,
-                 _stream(xs[0]))
-        return gws
-    lib.call("mvs_conv2d_wgrad_batch", len(xs), _ptr_array(xs), _ptr_array(gys), _ptr_array(gws), _p(ws), arr, _stream(xs[0]))
+                 st_handle, tstream=on_stream)
+    else:
+        lib.call("mvs_conv2d_wgrad_batch", len(xs), _ptr_array(xs), _ptr_array(gys), _ptr_array(gws), _p(ws), arr, st_handle, tstream=on_stream)
+    if on_stream is not None:
+        for ten in list(xs) + list(gys) + gws + [ws] + [t for t in (x_stats or ()) if t is not None]:
+            ten.record_stream(on_stream)
     return gws
 
 

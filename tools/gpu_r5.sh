@@ -61,5 +61,10 @@ for name, cs in acc.items():
         print("   %-28s median %.4g  (n=%d)" % (c, vals[len(vals) // 2], len(vals)))
 PY
     rm -rf gpurun_out/pmcn_[0-9] ;;
+  configs)  # configs 3 / 4 / 5 short lines
+    for cfg in 3 4 5; do
+      timeout 900 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 --pmc 0 > gpurun_out/bench_c$cfg.json 2> gpurun_out/bench_c$cfg.err
+      echo "config $cfg exit $?"; summ gpurun_out/bench_c$cfg.json
+    done ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
