@@ -110,9 +110,9 @@ DOMINANT = {2: "conv0_wgrad", 3: "sweep_bwd", 4: "conv_64_64", 5: "sweep_fwd_bf1
 
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
     "sweep_fwd": "plane_sweep_variance_fwd", "sweep_bwd": "plane_sweep_variance_bwd",
-    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_igemm_kernel<0, 8, 2,",
+    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_pers_kernel<0, 8, 2,",
     "sweep_fwd_bf16": "plane_sweep_variance_fwd", "conv0_fwd_bf16": "conv_bf16_kernel<",
-    "conv_64_64": "conv_igemm_kernel<0, 16, 4", "conv_16_16": "conv_igemm_kernel<0, 16, 1",
+    "conv_64_64": "conv_igemm_kernel<0, 16, 4", "conv_16_16": "conv_pers_kernel<0, 16, 1,",
 }
 # the tags tools/pmc_driver.py replays per --config (one kernel name per tag within a config: the substrings above are matched
 # against that config's driver run only)
@@ -138,9 +138,11 @@ def pmc_traffic(cfg, dtype="f32"):
     tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", MVS_PMC_CONFIG=str(cfg), MVS_PMC_DTYPE=dtype)
     dirs = []
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(tmp, counter)
-        r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+    # third pass: the SQ's instruction counters -- the plane-sweep kernels are bound by vector-ALU issue and latency, not by HBM
+    # (DESIGN.md section 4), so their line carries an ISSUE-side ceiling next to the HBM fraction
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"):
+        d = os.path.join(tmp, counter.split()[0])
+        r = subprocess.run(["rocprofv3", "--pmc"] + counter.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                             sys.executable, os.path.join(root, "tools", "pmc_driver.py")],
                            cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
@@ -160,6 +162,17 @@ def pmc_traffic(cfg, dtype="f32"):
             if sub in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 out[tag] = {"fetch_bytes": 2.0 * 1024.0 * c["FETCH_SIZE"]["mean"], "write_bytes": 1024.0 * c["WRITE_SIZE"]["mean"],
                             "hip_kernel": name}
+                if "SQ_INSTS_VALU" in c and "SQ_BUSY_CYCLES" in c:
+                    # SQ_BUSY_CYCLES is summed over the 32 shader engines; a vector-ALU wave-instruction occupies its SIMD's issue port
+                    # for 4 cycles (64 lanes on 16-lane hardware); 1024 SIMDs
+                    cyc = c["SQ_BUSY_CYCLES"]["mean"] / 32.0
+                    insts = c["SQ_INSTS_VALU"]["mean"]
+                    out[tag]["sq"] = {"valu_wave_instructions": insts, "kernel_cycles": cyc,
+                                      "valu_issue_cycles_per_simd": insts * 4.0 / 1024.0,
+                                      "valu_issue_frac": insts * 4.0 / 1024.0 / cyc if cyc else None,
+                                      "wave_cycles_quad": c.get("SQ_WAVE_CYCLES", {}).get("mean"),
+                                      "waiting_frac_of_wave_time": (c["SQ_WAIT_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"])
+                                      if c.get("SQ_WAVE_CYCLES", {}).get("mean") and "SQ_WAIT_ANY" in c else None}
     note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/pmc_driver.py at the --config %d shapes; "
             "FETCH_SIZE x2 (gfx950 counts 128-byte lines at 64 bytes)" % cfg)
     missing = [t for t in PMC_TAGS.get(cfg, ()) if t not in out and not ((dtype == "f32") == t.endswith("_bf16") and cfg == 5)]
@@ -815,6 +828,17 @@ def main():
                 kernels[k]["traffic"] = t["fetch_bytes"] + t["write_bytes"]
                 kernels[k]["traffic_fetch"], kernels[k]["traffic_write"] = t["fetch_bytes"], t["write_bytes"]
                 kernels[k]["hip_kernel"] = t.get("hip_kernel")
+                if "sq" in t:
+                    # a second bound for the kernel: the time its vector-ALU instructions need at one wave-instruction per 4 cycles
+                    # and SIMD (clock from the same counter pass); `frac_of_valu_issue_ceiling` = that time / the measured duration
+                    sq = dict(t["sq"])
+                    if sq.get("valu_issue_frac"):
+                        sq["valu_issue_floor_ms"] = kernels[k]["ms"] * sq["valu_issue_frac"]     # (the fraction is of the profiled launch)
+                    if sq.get("valu_issue_frac") and work[k][0] == "hbm":
+                        sq["bound_note"] = ("vector-ALU issue + latency bound: `frac` (of the HBM peak) is the distance to a roof this kernel "
+                                            "cannot reach; `valu_issue_frac` = share of the kernel's cycles its SIMDs' issue ports are taken by "
+                                            "vector-ALU instructions")
+                    kernels[k]["sq_counters"] = sq
                 # bytes each launch has to move at least once (conv: input volume + output volume, fp32)
                 if work[k][0] == "hbm":
                     kernels[k]["algorithmic_bytes"] = work[k][1]
@@ -839,7 +863,7 @@ def main():
                     "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                     "traffic": kernels[dom].get("traffic"), "traffic_unit": "bytes of HBM traffic per launch", "traffic_source": traffic_note,
                     "ms": kernels[dom]["ms"], "timed": kernels[dom]["timed"]}
-            for extra in ("ms_alone", "frac_alone", "alone_is"):
+            for extra in ("ms_alone", "frac_alone", "alone_is", "sq_counters"):
                 if extra in kernels[dom]:
                     roof[extra] = kernels[dom][extra]
         metric = {2: "depth-samples/sec (N=3, 640x512, D=192)", 3: "depth-samples/sec (JDACS self-supervised step, N=5, 640x512, D=192)",

@@ -50,17 +50,44 @@ __global__ __launch_bounds__(256) void softargmin_conf_fwd_kernel(SoftArgs a) {
     const float* __restrict__ dv = a.per_pixel ? a.depth + (size_t)b * a.D * a.HW + pix : a.depth + (size_t)b * a.D;
     const int dstride = a.per_pixel ? a.HW : 1;
 
-    float m = -INFINITY;
-    for (int d = slice; d < a.D; d += DS) m = fmaxf(m, lg[(size_t)d * a.HW]);
-    m = wave_slices_max<DS>(m);
-    float s = 0.f;
-    for (int d = slice; d < a.D; d += DS) s += expf(lg[(size_t)d * a.HW] - m);
-    s = wave_slices_sum<DS>(s);
-    float dep = 0.f, eidx = 0.f;
-    for (int d = slice; d < a.D; d += DS) {
-        float p = expf(lg[(size_t)d * a.HW] - m) / s;
-        dep += p * dv[(size_t)d * dstride];
-        eidx += p * (float)d;
+    float m = -INFINITY, s = 0.f, dep = 0.f, eidx = 0.f;
+    constexpr int NR = 64;       // logits a lane can hold: the three passes below then read registers instead of memory
+    if (DS > 1 && a.D <= NR * DS) {
+        // ONE pass over memory with every load of the lane in flight at once (the three dependent passes of the loop form are 3 x
+        // D/DS memory round trips of 64-byte pieces: 32 us for a 16 MB volume at BASELINE config 2); the same operations in the same
+        // order on the same values => bit-identical results
+        float v[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int d = slice + k * DS;
+            v[k] = d < a.D ? lg[(size_t)d * a.HW] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) m = fmaxf(m, v[k]);          // (fmaxf with -inf leaves m unchanged)
+        m = wave_slices_max<DS>(m);
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            if (slice + k * DS < a.D) s += expf(v[k] - m);
+        s = wave_slices_sum<DS>(s);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int d = slice + k * DS;
+            if (d < a.D) {
+                float p = expf(v[k] - m) / s;
+                dep += p * dv[(size_t)d * dstride];
+                eidx += p * (float)d;
+            }
+        }
+    } else {
+        for (int d = slice; d < a.D; d += DS) m = fmaxf(m, lg[(size_t)d * a.HW]);
+        m = wave_slices_max<DS>(m);
+        for (int d = slice; d < a.D; d += DS) s += expf(lg[(size_t)d * a.HW] - m);
+        s = wave_slices_sum<DS>(s);
+        for (int d = slice; d < a.D; d += DS) {
+            float p = expf(lg[(size_t)d * a.HW] - m) / s;
+            dep += p * dv[(size_t)d * dstride];
+            eidx += p * (float)d;
+        }
     }
     dep = wave_slices_sum<DS>(dep);
     eidx = wave_slices_sum<DS>(eidx);

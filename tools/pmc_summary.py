@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-KERNELS = ("plane_sweep", "conv_c8", "conv_igemm", "conv_wgrad", "conv_bf16", "fetch_calib")
+KERNELS = ("plane_sweep", "conv_c8", "conv_igemm", "conv_pers", "conv_wgrad", "conv_bf16", "fetch_calib")
 
 
 def summarise(dirs):
