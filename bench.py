@@ -895,6 +895,25 @@ def main():
         if ms_sustained is not None:
             res["ms_per_step_sustained"] = ms_sustained
             res["sustained_steps"] = args.sustained
+        if cfg["kind"] == "cvp_infer":
+            # the 2-D feature pyramid (jdacs-ms/models/network.py:16-41: nine 3x3 convolutions per image, at the three resolutions of
+            # this config, N images): its algorithmic FLOPs, the time of its C-ABI calls (HIP events, one more pass of the K steps)
+            # and its share of the step
+            from mvs_amd.jdacs_ms.models.network import _PYRAMID_LAYERS
+            macs_per_px = sum(9 * cin * cout for _, cin, cout in _PYRAMID_LAYERS)
+            px = sum((img_h >> lv) * (img_w >> lv) for lv in range(3)) * nviews
+            t_py = _lib.KernelTimer(None)
+            lib.profiler = t_py
+            for _ in range(args.steps):
+                eager_step()
+            torch.cuda.synchronize()
+            lib.profiler = None
+            py_ms = sum(ms * c for (n, t), (c, ms) in t_py.summary().items() if n.startswith("mvs_conv2d")) / args.steps
+            res["feature_pyramid"] = {"gflop_per_step": 2.0 * macs_per_px * px / 1e9, "ms_per_step": py_ms,
+                                      "share_of_step": py_ms / (dt / args.steps * 1e3),
+                                      "achieved_tflops": 2.0 * macs_per_px * px / (py_ms * 1e-3) / 1e12 if py_ms else None,
+                                      "frac_of_mfma_peak": 2.0 * macs_per_px * px / (py_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if py_ms else None,
+                                      "timed": "HIP events around every mvs_conv2d* call, a pass of the same K steps after the timed region"}
         if ab:
             res["ab"] = ab
         if host_trace is not None:
