@@ -133,6 +133,47 @@ int mvs_convT3d_dgrad(const float* gy, const float* w, const float* add, float* 
 int mvs_convT3d_wgrad(const float* x, const float* gy, float* gw, float* ws, int B, int D, int H, int W, int Cin,
                       int Cout, int stride, hipStream_t stream);
 
+/* ---- One call per PASS of a cost-volume regulariser ------------------------------------------------------------------
+ * Replace the whole of CostRegNet.forward (jdacs/models/mvsnet.py:66-74, jdacs-ms/models/network.py:67-74) in train mode and
+ * its autograd backward: the same kernels as the per-layer entry points above, in the same order, enqueued from C (the
+ * per-layer calls cost the launch thread ~1.7 ms per training step from Python).  Nothing is allocated: the caller supplies
+ * every tensor (channels-last-3d fp32; sizes follow from the block table).
+ * Block i: input = output of block src (-1: x), conv / transposed conv (k3 p1, bias-free; mvs_conv3d_fwd conventions, weight
+ * image packed[i] already written by mvs_conv3d_pack_weights_batch) -> BatchNorm(train, statistic slots slots[i] zeroed by the
+ * caller, running statistics updated) -> ReLU, + output of block skip (-1: none) AFTER the ReLU (mvsnet.py:70-72).
+ * (cin, cout, d, h, w): channels and the spatial dims of the block's INPUT.  The closing prob layer (mvsnet.py:63): stride-1
+ * convolution of block n-1's output with bias bprob, prob_cout output channels, workspace ws_prob (mvs_conv3d_workspace_bytes).
+ * mvs_unet_fwd outputs: raw[i] (pre-BatchNorm), y[i] (block output), stats[i] [4][cout] (mean, invstd, scale, shift), logits.
+ * mvs_unet_bwd: glogits -> gx (or NULL), gw[n+1] (weight gradients in the parameters' layouts; entry n = prob; a NULL entry
+ *   is skipped), dgamma[i], dbeta[i]; work space: gbuf[i], draw[i] (each like y[i]), wgrad_ws[n+1] (mvs_conv3d_workspace_bytes
+ *   of the WGRAD ops), slots_b[i] (zeroed backward statistic slots), packed_dgrad[n+1] (input-gradient weight images; entry i
+ *   may be NULL when block i reads x and gx is NULL).  side_stream != NULL and != main_stream: every weight gradient is
+ *   enqueued there behind a HIP event recorded on main_stream after the block's input gradient; join != 0: main_stream waits
+ *   for side_stream at the end; *side_stream_used (may be NULL) reports whether anything went to side_stream.
+ *   MVS_ERR_UNSUPPORTED for a program that needs an explicit gradient add (a block with two consumers through their INPUT, or
+ *   a skip contribution that is not the first): neither reference network is one. */
+#define MVS_UNET_MAX_BLOCKS 32
+typedef struct MvsUnetBlock {
+    int transposed, stride, src, skip;
+    float eps, momentum;
+    int cin, cout, d, h, w;
+} MvsUnetBlock;
+int mvs_unet_fwd(int n, const MvsUnetBlock* blocks, int B, const float* x, const float* const* w, const float* const* gamma,
+                 const float* const* beta, float* const* running_mean, float* const* running_var, float* const* packed,
+                 float* const* raw, float* const* y, float* const* stats, double* const* slots, const int* nslots,
+                 const float* wprob, const float* bprob, int prob_cout, float* ws_prob, float* logits, hipStream_t stream);
+int mvs_unet_bwd(int n, const MvsUnetBlock* blocks, int B, const float* x, const float* const* w, const float* wprob, int prob_cout,
+                 const float* const* y, const float* const* raw, const float* const* stats, double* const* slots_b, const int* nslots,
+                 float* const* packed_dgrad, const float* glogits, float* const* gbuf, float* const* draw, float* gx,
+                 float* const* gw, float* const* wgrad_ws, float* const* dgamma, float* const* dbeta, hipStream_t main_stream,
+                 hipStream_t side_stream, int join, int* side_stream_used);
+
+/* Measurement hook of mvs_unet_bwd (process-wide, like mvs_set_tuning): HIP events around the weight gradient of ONE block
+ * (0..n-1, n = the prob layer; < 0: off) on the stream it runs on; mvs_unet_time_read waits for them, writes the durations in
+ * ms (launch order, at most max_n) and returns how many there were. */
+int mvs_unet_time_wgrad(int block);
+int mvs_unet_time_read(float* ms, int max_n);
+
 /* ---- bf16-storage inference path of CostRegNet (BASELINE configs[4]) ------------------------------------------------
  * The same layers (jdacs/models/mvsnet.py:40-63) evaluated as in jdacs/eval.py:143 (eval mode, no_grad) with activations
  * stored in bf16 and fp32 accumulation (v_mfma_f32_16x16x32_bf16).  x, skip: bf16 [B,D,H,W,C]; w: the fp32 parameter;

@@ -16,8 +16,22 @@ _ll = C.c_longlong
 _s = C.c_void_p      # hipStream_t
 _fl = C.c_float
 
+class MvsUnetBlock(C.Structure):
+    """include/mvs_hip.h: one Conv/Deconv + BatchNorm + ReLU (+ skip) block of a regulariser program"""
+    _fields_ = [("transposed", _i), ("stride", _i), ("src", _i), ("skip", _i), ("eps", _fl), ("momentum", _fl),
+                ("cin", _i), ("cout", _i), ("d", _i), ("h", _i), ("w", _i)]
+
+
+_pp = C.POINTER(C.c_void_p)   # array of device pointers
+
 # name -> (restype, argtypes); every symbol include/mvs_hip.h declares
 SIGNATURES = {
+    "mvs_unet_time_wgrad": (_i, [_i]),
+    "mvs_unet_time_read": (_i, [C.POINTER(_fl), _i]),
+    "mvs_unet_fwd": (_i, [_i, C.POINTER(MvsUnetBlock), _i, _f, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _pp, C.POINTER(_i), _f, _f, _i,
+                          _f, _f, _s]),
+    "mvs_unet_bwd": (_i, [_i, C.POINTER(MvsUnetBlock), _i, _f, _pp, _f, _i, _pp, _pp, _pp, _pp, C.POINTER(_i), _pp, _f, _pp, _pp, _f, _pp, _pp,
+                          _pp, _pp, _s, _s, _i, C.POINTER(_i)]),
     "mvs_version": (_i, []),
     "mvs_last_error": (C.c_char_p, []),
     "mvs_is_emulation": (_i, []),
@@ -163,10 +177,73 @@ class KernelTimer:
     def add(self, name, tag, ev0, ev1):
         self.events.setdefault((name, tag), []).append((ev0, ev1))
 
+    # ---- the regulariser as ONE C call per pass (ops.C_ENTRY): no per-layer Python call to bracket.  A timer that looks at exactly one
+    # weight gradient of the regulariser (bench.py's roofline kernel) has it bracketed INSIDE mvs_unet_bwd instead (mvs_unet_time_wgrad)
+    _REG_NAMES = frozenset(("mvs_conv3d_fwd", "mvs_convT3d_fwd", "mvs_conv3d_dgrad", "mvs_convT3d_dgrad", "mvs_conv3d_wgrad", "mvs_convT3d_wgrad",
+                            "mvs_bn_relu_fwd_slots", "mvs_bn_relu_bwd_slots", "mvs_bn_bwd_reduce_slots", "mvs_conv3d_pack_weights_batch"))
+
+    def allows_c_entry(self, lib, blocks):
+        """blocks: [(transposed, cin, cout, stride, (b, d, h, w))] of the regulariser about to run (+ the prob layer last).  True: the C
+        entry may run (nothing of it is timed, or the one weight gradient this timer wants is bracketed in C)."""
+        if self.names is None:
+            return False
+        hit = self.names & self._REG_NAMES
+        if not hit:
+            return True
+        if not hit <= {"mvs_conv3d_wgrad", "mvs_convT3d_wgrad"} or self.only is None:
+            return False
+        want = [t for t in self.only if isinstance(t, str) and t.startswith("wgrad")]
+        found = []
+        for i, (transposed, cin, cout, stride, dims) in enumerate(blocks):
+            tag = "%s:%d>%d:s%d:%dx%dx%dx%d" % (("wgradT" if transposed else "wgrad", cin, cout, stride) + tuple(dims))
+            if tag in want:
+                found.append((i, "mvs_convT3d_wgrad" if transposed else "mvs_conv3d_wgrad", tag))
+        if len(found) != 1 or len(want) != 1:
+            return False
+        owner = getattr(lib, "_unet_timer", None)
+        if owner is not self:
+            if owner is not None:
+                owner._harvest()
+                owner._c = None
+            lib.raw("mvs_unet_time_read", (C.c_float * 1024)(), 1024)      # forget brackets nobody owns
+            lib.raw("mvs_unet_time_wgrad", found[0][0])
+            lib._unet_timer = self
+            self._c = (lib, found[0])
+        return True
+
+    def _harvest(self):
+        """collect the brackets mvs_unet_bwd has recorded for this timer so far"""
+        c = getattr(self, "_c", None)
+        if c is None:
+            return
+        lib, (idx, name, tag) = c
+        buf = (C.c_float * 1024)()
+        cnt = lib.raw("mvs_unet_time_read", buf, 1024)
+        if cnt > 0:
+            acc = self.__dict__.setdefault("_c_acc", {})
+            n0, s0 = acc.get((name, tag), (0, 0.0))
+            acc[(name, tag)] = (n0 + cnt, s0 + sum(buf[:cnt]))
+
+    def release_c_bracket(self, lib):
+        """the timer is no longer attached: collect what is there and switch the C-side bracket off"""
+        self._harvest()
+        self._c = None
+        lib.raw("mvs_unet_time_wgrad", -2)
+        lib._unet_timer = None
+
     def summary(self):
         """{(name, tag): (calls, mean_ms)} -- call after torch.cuda.synchronize()."""
         out = {}
         for k, evs in self.events.items():
             ms = [a.elapsed_time(b) for a, b in evs]
             out[k] = (len(ms), sum(ms) / len(ms))
+        c = getattr(self, "_c", None)
+        if c is not None:
+            self.release_c_bracket(c[0])
+        for (name, tag), (cnt, tot) in getattr(self, "_c_acc", {}).items():
+            if (name, tag) in out:
+                n0, m0 = out[(name, tag)]
+                out[(name, tag)] = (n0 + cnt, (n0 * m0 + tot) / (n0 + cnt))
+            else:
+                out[(name, tag)] = (cnt, tot / cnt)
         return out

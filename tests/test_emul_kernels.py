@@ -1580,3 +1580,85 @@ def test_conv3d_persistent_weight_gradient(emul_lib, cin, cout, stride, transpos
     assert float((new - w.grad).abs().max()) < 1e-3 * scale
     assert float((new - old).abs().max()) < 2e-4 * scale
     assert not torch.equal(new, torch.zeros_like(new))
+
+
+@pytest.mark.parametrize("which", ["small", pytest.param("mvsnet", marks=_full), pytest.param("cvp", marks=_full)])
+def test_regulariser_pass_level_c_entry_equals_per_layer_calls(emul_lib, which):
+    """mvs_unet_fwd / mvs_unet_bwd (ONE C call per pass over pointer tables into three arenas) against the same autograd node issuing
+    the per-layer C calls from Python: the same kernels in the same order => logits, BatchNorm buffers, input gradient and every
+    parameter gradient BIT-IDENTICAL; a frozen weight gets no gradient (its launch is skipped); a second backward through the same
+    graph gets fresh statistic accumulators.  "small": a three-block U-Net (stride-1, stride-2, transposed stride-2 with skip) for the
+    default suite; the two networks' regularisers take minutes of emulation (MVS_EMUL_FULL=1) and run on the GPU."""
+    from mvs_amd import nn3d, ops
+    if which == "small":
+        def build():
+            torch.manual_seed(5)
+            return torch.nn.ModuleList([nn3d.ConvBnReLU3D(8, 8, stride=1), nn3d.ConvBnReLU3D(8, 16, stride=2),
+                                        nn3d.DeconvBnReLU3D(16, 8, stride=2), nn3d.ProbConv3d(8)]).train()
+        x0 = torch.randn(1, 8, 4, 4, 16, generator=torch.Generator().manual_seed(1))
+        run = lambda m, x: ops.unet_regulariser(x, [(m[0].conv, m[0].bn, False, 1, -1, -1), (m[1].conv, m[1].bn, False, 2, 0, -1),
+                                                    (m[2][0], m[2][1], True, 2, 1, 0)], m[3])
+        frozen = "1.conv.weight"
+    else:
+        if which == "mvsnet":
+            from mvs_amd.jdacs.models.mvsnet import CostRegNet
+            x0 = torch.randn(1, 32, 8, 8, 16, generator=torch.Generator().manual_seed(1))
+        else:
+            from mvs_amd.jdacs_ms.models.network import CostRegNet
+            x0 = torch.randn(1, 16, 2, 4, 16, generator=torch.Generator().manual_seed(1))
+
+        def build():
+            torch.manual_seed(5)
+            return CostRegNet().train()
+        run = lambda m, x: m(x)
+        frozen = "conv2.conv.weight"
+    res = {}
+    for c_entry in (True, False):
+        net = build()
+        dict(net.named_parameters())[frozen].requires_grad_(False)
+        x = x0.clone().requires_grad_(True)
+        old = ops.C_ENTRY
+        ops.C_ENTRY = c_entry
+        try:
+            y = run(net, x)
+            gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+            y.backward(gout, retain_graph=c_entry)
+            g1 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            gx1 = x.grad.clone()
+            g2 = None
+            if c_entry:                                        # second backward through the same graph
+                for p in net.parameters():
+                    p.grad = None
+                y.backward(gout)
+                g2 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        finally:
+            ops.C_ENTRY = old
+        res[c_entry] = (y.detach(), gx1, g1, {k: v.clone() for k, v in net.state_dict().items()}, g2)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert set(a[2]) == set(b[2]) and frozen not in a[2] and len(a[2]) >= 8
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+        assert torch.equal(a[4][k], a[2][k]), k               # the second backward reproduces the first
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_regulariser_c_entry_rejects_bad_programs(emul_lib):
+    """C-ABI error behaviour of mvs_unet_fwd: a block that reads a later block, too many blocks, null tables."""
+    import ctypes as C
+    from mvs_amd import _lib
+    blocks = (_lib.MvsUnetBlock * 2)()
+    blocks[0].src, blocks[0].skip, blocks[0].stride = 1, -1, 1          # reads block 1: not an earlier block
+    blocks[1].src, blocks[1].skip, blocks[1].stride = 0, -1, 1
+    null = (C.c_void_p * 2)()
+    with pytest.raises(ValueError, match="earlier blocks"):
+        emul_lib.call("mvs_unet_fwd", 2, blocks, 1, None, null, null, null, null, null, null, null, null, null, null, (C.c_int * 2)(), None, None,
+                      1, None, None, None)
+    blocks[0].src = -1
+    with pytest.raises(ValueError, match="null pointer"):
+        emul_lib.call("mvs_unet_fwd", 2, blocks, 1, None, null, null, null, null, null, null, null, null, null, null, (C.c_int * 2)(), None, None,
+                      1, None, None, None)
+    with pytest.raises(ValueError, match="blocks"):
+        emul_lib.call("mvs_unet_fwd", 33, blocks, 1, None, null, null, null, null, null, null, null, null, null, null, (C.c_int * 2)(), None, None,
+                      1, None, None, None)

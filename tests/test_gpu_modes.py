@@ -231,3 +231,44 @@ def test_two_host_threads_two_streams_one_gpu(dev):
                     assert diff <= 3.0 * spread + 1e-5 * scale, "thread %d (%s weight gradients): %s differs by %.3e (spread %.3e, scale %.3e)" % (
                         i, "side-stream" if async_wgrad else "synchronous", k, diff, spread, scale)
         assert not ops._BWD_OPEN
+
+
+@pytest.mark.parametrize("which", ["mvsnet", "cvp"])
+@pytest.mark.parametrize("async_wgrad", [True, False], ids=["side_stream_weight_gradients", "synchronous"])
+def test_regulariser_one_c_call_per_pass_equals_per_layer_calls(dev, which, async_wgrad):
+    """mvs_unet_fwd / mvs_unet_bwd (the regulariser's forward / backward pass as ONE C call each, weight gradients forked to the side
+    stream behind HIP events inside the library) against the same autograd node issuing the per-layer calls from Python: the same
+    kernels in the same order on the same streams => logits, BatchNorm buffers, input gradient and every parameter gradient bit-identical.
+    Replaces the ~25 module calls of CostRegNet.forward (/root/reference/jdacs/models/mvsnet.py:66-74, jdacs-ms/models/network.py:67-74)."""
+    from mvs_amd import ops
+    if which == "mvsnet":
+        from mvs_amd.jdacs.models.mvsnet import CostRegNet
+        x0 = torch.randn(1, 32, 48, 32, 40, generator=torch.Generator().manual_seed(1))
+    else:
+        from mvs_amd.jdacs_ms.models.network import CostRegNet
+        x0 = torch.randn(1, 16, 8, 64, 80, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(5)
+    ref = CostRegNet().train()
+    ops.set_async_wgrad(async_wgrad, defer_join=False)
+    res = {}
+    for c_entry in (True, False):
+        net = CostRegNet().to(dev).train()
+        net.load_state_dict(ref.state_dict())
+        x = x0.to(dev).requires_grad_(True)
+        old = ops.C_ENTRY
+        ops.C_ENTRY = c_entry
+        try:
+            y = net(x)
+            gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            y.backward(gout)
+            torch.cuda.synchronize()
+        finally:
+            ops.C_ENTRY = old
+        res[c_entry] = (y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                        {k: v.clone() for k, v in net.state_dict().items()})
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
