@@ -221,85 +221,112 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
                     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].x, bq[u][nb].x, acc[mb][nb]);
-                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].y, bq[u][nb].y, acc[mb][nb]);
-                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].z, bq[u][nb].z, acc[mb][nb]);
-                            acc[mb][nb] = MVS_MFMA_16x16x4(af[mb].w, bq[u][nb].w, acc[mb][nb]);
+                            // (the WEIGHT fragment is the A operand -- the packed image serves as either: lane (l15, g) holds
+                            //  W[k = 4g..][column l15] -- so the result tile is transposed: see the epilogue)
+                            acc[mb][nb] = MVS_MFMA_16x16x4(bq[u][nb].x, af[mb].x, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(bq[u][nb].y, af[mb].y, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(bq[u][nb].z, af[mb].z, acc[mb][nb]);
+                            acc[mb][nb] = MVS_MFMA_16x16x4(bq[u][nb].w, af[mb].w, acc[mb][nb]);
                         }
                     load_b(ks + 2, bq[u]);
                 }
             }
         }
     }
-    // D layout: column = lane & 15 (co), row = 4 (lane >> 4) + r (position within the m-block)
-    // (PP: column = p*8 + co, row = pixel pair: pixel 2 (4 g + r) + p of the row)
-    float st1[NB], st2[NB];
+    // D layout (weights as the A operand): row = 4 (lane >> 4) + r -> output column n of the weight tile, col = lane & 15 -> position
+    // within the m-block.  A lane ends with FOUR CONSECUTIVE CHANNELS of one pixel: the raw values of the backward statistics are read
+    // and the result is written as float4 -- a wave instruction covers 16 pixels x 64 bytes (16 pixel pairs x 64 bytes with PP) of
+    // contiguous memory; with the positions in the lane's registers (rounds 1-4) the same bytes took four 4-byte instructions.
+    // (PP: column n = p*8 + co -> lanes g = 0, 1 hold the two channel quads of pixel 2 l15, lanes g = 2, 3 those of pixel 2 l15 + 1)
+    float st1[NB][4], st2[NB][4];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) st1[nb] = st2[nb] = 0.f;
-    // BST: the raw values under this lane's outputs, ALL requested before the first store (a load written after a store waits for
-    // it: the stores may alias as far as hipcc knows), and the block's per-channel statistics
-    float rawv[BST ? MBW : 1][BST ? 4 : 1][BST ? NB : 1];
-    float bmean[BST ? NB : 1], binv[BST ? NB : 1], bsc[BST ? NB : 1], bsh[BST ? NB : 1];
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[nb][r] = st2[nb][r] = 0.f;
+    float bmean[BST ? NB : 1][4], binv[BST ? NB : 1][4], bsc[BST ? NB : 1][4], bsh[BST ? NB : 1][4];
     if (BST) {
         const float* __restrict__ bs = a.bn_stats + (size_t)(n / a.imgs_per_group) * 4 * a.Cout;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15, cc = co < a.Cout ? co : 0;
-            bmean[nb] = bs[cc]; binv[nb] = bs[a.Cout + cc]; bsc[nb] = bs[2 * a.Cout + cc]; bsh[nb] = bs[3 * a.Cout + cc];
-        }
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (PP ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g) + r, cc = co < a.Cout ? co : 0;
+                bmean[nb][r] = bs[cc]; binv[nb][r] = bs[a.Cout + cc]; bsc[nb][r] = bs[2 * a.Cout + cc]; bsh[nb][r] = bs[3 * a.Cout + cc];
+            }
+    }
+    const bool vec = (a.Cout & 3) == 0;            // (a 1- or 3-channel output layer takes the scalar stores)
+    float4 rawv[BST ? MBW : 1][BST ? NB : 1];
+    if (BST) {      // ALL requested before the first store (a load written after a store waits for it: the stores may alias as far as hipcc knows)
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
-                    const int ox = (ox0 + (PP ? 2 * (4 * g + r) + (l15 >> 3) : 16 * (mb & 1) + 4 * g + r)) * a.os + a.px;
-                    const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15;
-                    float rv = 0.f;
-                    if (oy < a.YH && ox < a.YW && co < a.Cout) rv = a.bn_raw[(((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout + co];
-                    rawv[mb][r][nb] = rv;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
+                const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + a.px;
+                const int co0 = PP ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g;
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < a.YH && ox < a.YW && co0 < a.Cout) {
+                    const float* __restrict__ rp = a.bn_raw + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout + co0;
+                    if (vec) rv = *reinterpret_cast<const float4*>(rp);
+                    else { rv.x = rp[0]; if (co0 + 1 < a.Cout) rv.y = rp[1]; if (co0 + 2 < a.Cout) rv.z = rp[2]; if (co0 + 3 < a.Cout) rv.w = rp[3]; }
                 }
+                rawv[mb][nb] = rv;
+            }
     }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
-        if (oy >= a.YH) continue;
+        const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + a.px;
+        if (oy >= a.YH || ox >= a.YW) continue;
+        float* __restrict__ o = a.y + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ox = (ox0 + (PP ? 2 * (4 * g + r) + (l15 >> 3) : 16 * (mb & 1) + 4 * g + r)) * a.os + a.px;
-            if (ox >= a.YW) continue;
-            float* __restrict__ o = a.y + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co0 = PP ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g;
+            if (co0 >= a.Cout) continue;
+            float ov[4];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int co = PP ? (l15 & 7) : (nb0 + nb) * 16 + l15;
-                if (co < a.Cout) {
-                    float v = acc[mb][nb][r] + (a.bias ? a.bias[co] : 0.f);
-                    if (a.act) v = v > 0.f ? v : v * a.slope;
-                    o[co] = v;
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mb][nb][r] + ((a.bias && co0 + r < a.Cout) ? a.bias[co0 + r] : 0.f);
+                if (a.act) v = v > 0.f ? v : v * a.slope;
+                ov[r] = v;
+                if (co0 + r < a.Cout) {
                     if (BST) {
-                        const float rw = rawv[mb][r][nb];
-                        const float d1 = (rw * bsc[nb] + bsh[nb] > 0.f) ? v : 0.f;
-                        st1[nb] += d1; st2[nb] = fmaf(d1, (rw - bmean[nb]) * binv[nb], st2[nb]);
-                    } else if (STATS) { st1[nb] += v; st2[nb] = fmaf(v, v, st2[nb]); }
+                        const float rw = r == 0 ? rawv[BST ? mb : 0][BST ? nb : 0].x : (r == 1 ? rawv[BST ? mb : 0][BST ? nb : 0].y : (r == 2 ? rawv[BST ? mb : 0][BST ? nb : 0].z : rawv[BST ? mb : 0][BST ? nb : 0].w));
+                        const float d1 = (rw * bsc[BST ? nb : 0][r] + bsh[BST ? nb : 0][r] > 0.f) ? v : 0.f;
+                        st1[nb][r] += d1; st2[nb][r] = fmaf(d1, (rw - bmean[BST ? nb : 0][r]) * binv[BST ? nb : 0][r], st2[nb][r]);
+                    } else if (STATS) { st1[nb][r] += v; st2[nb][r] = fmaf(v, v, st2[nb][r]); }
                 }
+            }
+            if (vec) *reinterpret_cast<float4*>(o + co0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.Cout) o[co0 + r] = ov[r];
             }
         }
     }
     if constexpr (STATS) {
-        // 16 (wave, lane group) partial sums per column, summed in a fixed order; PP: columns c and c + 8 are the same channel
-        __shared__ float red[16 * NB * 16 * 2];
+        // the 16 lanes of a group hold 16 positions of the same four columns: butterfly over them (fixed order), one partial per
+        // (wave, column), summed over the four waves in a fixed order; PP: columns c and c + 8 are the same channel
+        __shared__ float red[4 * NB * 16 * 2];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            red[((wave * 4 + g) * NB * 16 + nb * 16 + l15) * 2] = st1[nb];
-            red[((wave * 4 + g) * NB * 16 + nb * 16 + l15) * 2 + 1] = st2[nb];
-        }
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = st1[nb][r], s2 = st2[nb][r];
+                s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 8);
+                s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+                if (l15 == 0) {
+                    red[((wave * NB + nb) * 16 + 4 * g + r) * 2] = s1;
+                    red[((wave * NB + nb) * 16 + 4 * g + r) * 2 + 1] = s2;
+                }
+            }
         __syncthreads();
         const int ncol = PP ? 8 : NB * 16;
         if (tid < 2 * ncol) {
             const int stat = tid / ncol, col = tid % ncol;
             float t = 0.f;
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 t += red[(k * NB * 16 + col) * 2 + stat];
                 if (PP) t += red[(k * NB * 16 + col + 8) * 2 + stat];
             }

@@ -22,7 +22,7 @@
 #include "conv_map.h"
 #include "conv_args.h"
 
-__device__ float g_conv_zero_page[64];
+__device__ __attribute__((aligned(16))) float g_conv_zero_page[64];
 
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
