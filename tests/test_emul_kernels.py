@@ -10,7 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_as_accurate_as_fp32_reference, load_golden, rel_l1, state_dict_from
+from conftest import (assert_as_accurate_as_fp32_reference, assert_grads_as_accurate_as_fp32_reference, load_golden, rel_l1,
+                      state_dict_from)
 from emul_util import emul_lib  # noqa: F401
 from oracle import ref_torch as R
 
@@ -54,14 +55,17 @@ def test_plane_sweep_variance(emul_lib, c, ns, per_pixel, alias, ac):
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth,
                                  ms_alias=alias, align_corners=ac)
     exp.backward(gup)
-    with torch.no_grad():
-        t64 = R.plane_sweep_variance(ref.double(), [s.double() for s in srcs], [rot[:, i].double() for i in range(ns)],
-                                     [trans[:, i].double() for i in range(ns)], depth.double(), ms_alias=alias,
-                                     align_corners=ac)
-    assert_as_accurate_as_fp32_reference(var.detach(), exp.detach(), t64, what="variance volume")
-    assert float((var - exp).abs().max()) < 2e-4
-    for a, t in zip(got, [ref] + srcs):
-        assert float((a - t.grad).abs().max()) < 1e-3 * max(1.0, float(t.grad.abs().max()))
+    ref64 = ref.detach().double().requires_grad_(True)
+    src64 = [s.detach().double().requires_grad_(True) for s in srcs]
+    t64 = R.plane_sweep_variance(ref64, src64, [rot[:, i].double() for i in range(ns)],
+                                 [trans[:, i].double() for i in range(ns)], depth.double(), ms_alias=alias, align_corners=ac)
+    t64.backward(gup.double())
+    assert_as_accurate_as_fp32_reference(var.detach(), exp.detach(), t64.detach(), what="variance volume")
+    names = ["ref"] + ["src%d" % i for i in range(ns)]
+    assert_grads_as_accurate_as_fp32_reference(
+        dict(zip(names, got)), {n: t.grad for n, t in zip(names, [ref] + srcs)},
+        {n: t.grad for n, t in zip(names, [ref64] + src64)}, what="plane-sweep feature gradients N=%d" % (ns + 1))
+
 
 @pytest.mark.parametrize("c,ns,d,gd", [(8, 2, 67, 2), (16, 1, 66, 2), (8, 2, 65, 0), (8, 2, 66, -1)])
 def test_plane_sweep_backward_long_segment(emul_lib, c, ns, d, gd):
