@@ -110,7 +110,7 @@ DOMINANT = {2: "conv0_wgrad", 3: "sweep_bwd", 4: "conv_64_64", 5: "sweep_fwd_bf1
 
 HIP_KERNEL_OF = {   # bench tag -> substring of the HIP kernel's name in the rocprofv3 output
     "sweep_fwd": "plane_sweep_variance_fwd", "sweep_bwd": "plane_sweep_variance_bwd",
-    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_kernel", "conv0_dgrad": "conv_pers_kernel<0, 8, 2,",
+    "conv0_fwd": "conv_c8_fwd_bc_kernel", "conv0_wgrad": "conv_c8_wgrad_gs_kernel", "conv0_dgrad": "conv_pers_kernel<0, 8, 2,",
     "sweep_fwd_bf16": "plane_sweep_variance_fwd", "conv0_fwd_bf16": "conv_bf16_kernel<",
     "conv_64_64": "conv_igemm_kernel<0, 16, 4", "conv_16_16": "conv_pers_kernel<0, 16, 1,",
 }

@@ -1492,6 +1492,9 @@ int g_conv_pers_min_wgs = 1024;   // tuning knob "conv_pers_min": ... when the o
 int g_conv_wgrad_pers = 1;   // tuning knob "wgrad_pers"
 bool conv_wgrad_pers_serves(int geom, int CX, int CG);
 int run_conv_wgrad_pers(int geom, const WgradArgs& a, int max_groups, hipStream_t st);
+bool conv_c8_wgrad_gs_serves(int geom, int CX, int CG);
+int run_conv_c8_wgrad_gs(const WgradArgs& a, int max_groups, int waves, hipStream_t st);
+int g_conv_wgrad8_gs = 2;   // tuning knob "wgrad8_gs": conv0's weight gradient in the output-gradient-shifted form on the 16x16x4 MFMA (conv3d_pers.hip: conv_c8_wgrad_gs_kernel); 1: eight waves per workgroup, 2: sixteen (0.463 / 0.447 ms alone); 0: conv_c8_wgrad_kernel (4x4x1 MFMA, X shifted)
 bool conv_pers_serves(int geom, int cin, int cout);
 int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st);
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
@@ -1786,6 +1789,11 @@ static int run_wgrad(int geom, const float* X, const float* Gt, float* gw, float
     if (g_conv_c8 && geom == GEOM_S1 && CG == 8 && CX % 16 == 0) {
         const int max8 = g_conv_wgrad8_groups < 1 ? 1 : (g_conv_wgrad8_groups > 512 ? 512 : g_conv_wgrad8_groups);
         const int g8 = ntiles < max8 ? ntiles : max8;   // 60 KB LDS -> 2 resident workgroups per CU
+        if (g_conv_wgrad8_gs && conv_c8_wgrad_gs_serves(geom, CX, CG)) {
+            const int np = run_conv_c8_wgrad_gs(a, g8, g_conv_wgrad8_gs == 1 ? 8 : 16, st);
+            if (np < 0) return np;
+            return wgrad_finish(ws, np, CX, CG, gw, st);
+        }
         if (CX % 32 == 0 && g_conv_wgrad8_nch == 2) {     // both 16-channel chunks of a 32-channel line in one workgroup (knob "wgrad8_nch")
             const int g2 = g8 > 256 ? 256 : g8;              // 110 KB of LDS: one workgroup per CU
             if (g_conv_c8 & 4) MVS_LAUNCH((conv_c8_wgrad_kernel<true, 2>), dim3(g2, CX / 32), dim3(256), 0, st, a);

@@ -473,3 +473,206 @@ int run_conv_wgrad_pers(int geom, const WgradArgs& a, int max_groups, hipStream_
     const int rc = mvs_check_launch("conv_wgrad_pers");
     return rc ? rc : groups;
 }
+
+// ================================================================================================
+// conv0's weight gradient (mvsnet.py:40: 32 -> 8, stride 1), output-gradient-shifted form.
+//   dW[t][ci][co] = sum_p X[p + t - 1][ci] * G[p][co] = sum_q X[q][ci] * G[q + 1 - t][co]        (q = p + t - 1)
+// conv_c8_wgrad_kernel (conv3d.hip) walks p, shifts X and runs on the 16-block 4x4x1 MFMA (Cout = 8 half-fills a 16-wide N tile);
+// that instruction issues every 11 cycles instead of its nominal 8 (profiles/r01_mfma_rate.log), and the kernel sits at 85 % of
+// THAT ceiling = 53 % of the fp32 MFMA peak with one wave per SIMD (110 KB of LDS: a 6 x 6 x 18 halo of 32-channel voxels).
+// Walking q instead makes the SHIFTED operand the narrow one:
+//   * GEMM view: M = ci (two 16-row tiles), K = 4 consecutive W positions q, N = 16 = (a PAIR of taps, co): A = X[q][ci] is read
+//     unshifted, B = G[q + 1 - t][co] for the two taps of the pair -- the full-rate v_mfma_f32_16x16x4_f32 with every N column
+//     useful (14 pairs for 27 taps: 96 %), 28 MFMAs of 32 cycles per four positions instead of 112 of 11;
+//   * X needs NO halo (each voxel is read from HBM exactly once: 503 MB), the 8-channel G takes the 6 x 6 x 18 halo instead
+//     (20 KB per tile, out of L2 for the most part);
+//   * X tile + G halo = 53 KB -> double-buffered LDS-DMA staging, eight waves on one tile (two per SIMD): wave rank
+//     (wave & 3) = (M tile, parity of the tap pair) owns seven accumulator tiles, waves w and w + 4 split the k-steps of a tile
+//     and meet in LDS once at the end of the kernel;
+//   * tap pairs are chosen so that the two halves of a B read sit on different banks: (wt = 0, wt = 2) of a (dt, ht) are 16 floats
+//     apart, (ht, ht + 1) at wt = 1 are 18 voxels = 16 floats (mod 32) apart.
+// Same products as conv_c8_wgrad_kernel, another order of the K sum: results agree to fp32 rounding.  One partial image per
+// workgroup, summed by wgrad_finish (conv3d.hip).
+// ================================================================================================
+__device__ __forceinline__ int gs_pair_tap(int nt, int t2) {      // tap (dt*9 + ht*3 + wt) of column half t2 of pair nt; 27: none
+    if (nt < 9) return 3 * nt + 2 * t2;                            // (dt, ht) = nt: wt = 0 / 2
+    if (nt < 12) return 9 * (nt - 9) + 1 + 3 * t2;                 // dt = nt - 9: (ht = 0, wt = 1) / (ht = 1, wt = 1)
+    if (nt == 12) return t2 ? 16 : 7;                              // (0, 2, 1) / (1, 2, 1)
+    return t2 ? 27 : 25;                                           // (2, 2, 1) / none
+}
+
+// NW: waves per workgroup, 8 or 16 (two or four per SIMD: ~100 registers per wave leave room for either); NW / 4 wave groups split a
+// tile's k-steps.  Measured alone at config 2 (profiles/r05_run28..31; conv_c8_wgrad_kernel: 0.650 ms): first form (hipcc's own
+// schedule, DMA requests in front of the tile's first MFMA) 0.553, software pipeline 0.463, 16 waves + requests under the MFMAs
+// 0.447 ms = 121 TFLOP/s = 77 % of the fp32 MFMA peak.  Diagnostic builds: without any DMA after the first tile 0.403 (the MFMA loop
+// itself: 27.5 M MFMAs x 32 cycles / 1024 SIMDs at 2.2-2.3 GHz = 0.38-0.39), X requests only 0.449, G requests only 0.445 -- the
+// staging traffic, not the schedule, is what is left.  The loop is written as an explicit software pipeline (operands of k-step j + 1 requested before the MFMAs of
+// k-step j, scheduling fences around the MFMA block): left to itself hipcc issues the eight reads of a k-step, waits, issues its
+// seven MFMAs and only then the next reads.  All k-step-dependent parts of the LDS addresses are instruction immediates.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_c8_wgrad_gs_kernel(WgradArgs a) {
+    constexpr int CX = 32, CG = 8, KSPLIT = NW / 4;
+    constexpr int TD = 4, TH = 4, TW = 16, NPOS = TD * TH * TW;           // X tile (no halo)
+    constexpr int GD = TD + 2, GH = TH + 2, GW = TW + 2, NGV = GD * GH * GW;   // G halo tile
+    constexpr int XITEMS = NPOS * (CX / 4), GITEMS = NGV * (CG / 4);      // 16-byte items
+    constexpr int XDMA = XITEMS / 64, GDMA = (GITEMS + 63) / 64;          // wave-level DMA instructions
+    constexpr int NDMA = XDMA + GDMA, DPW = (NDMA + NW - 1) / NW;
+    constexpr int XF = XDMA * 256, BUFF = XF + GDMA * 256;                // floats
+    constexpr int NS = 7;                                                 // tap pairs (accumulator tiles) per wave
+    constexpr int NJ = NPOS / 4 / KSPLIT;                                 // k-steps of a tile per wave
+    static_assert(NW == 8 || NW == 16, "the k-steps of one row (four) go to one or two wave groups each");
+    static_assert((KSPLIT - 1) * 4 * NS * 256 <= 2 * BUFF, "the K split's exchange fits the staging buffers");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUFF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int w4 = wave & 3, kq = wave >> 2;
+    const int mt = w4 >> 1, par = w4 & 1;
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+
+    // ---- per-lane DMA items ----
+    int rel[DPW], crd[DPW];      // crd: X items (pd | ph << 8 | pw << 16), G items (rd | rh << 8 | rw << 16), -1: none
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int d = NW * j + wave;
+        rel[j] = 0; crd[j] = -1;
+        if (d < XDMA) {
+            const int i = 64 * d + lane, vox = i >> 3, cq = i & 7;
+            const int pw = vox % TW, ph = (vox / TW) % TH, pd = vox / (TW * TH);
+            rel[j] = ((pd * a.Hi + ph) * a.Wi + pw) * CX + 4 * cq;
+            crd[j] = pd | (ph << 8) | (pw << 16);
+        } else if (d < NDMA) {
+            const int i = 64 * (d - XDMA) + lane, gv = i >> 1, hq = i & 1;
+            const int rw = gv % GW, rh = (gv / GW) % GH, rd = gv / (GW * GH);
+            rel[j] = ((rd * a.QH + rh) * a.QW + rw) * CG + 4 * hq;
+            if (i < GITEMS) crd[j] = rd | (rh << 8) | (rw << 16);
+        }
+    }
+    const float* __restrict__ zero = g_conv_zero_page;
+    // tile order: linear, workgroup i takes tiles i, i + gridDim.x, ... (X has no halo to share; the brick order of conv_c8_wgrad_kernel
+    // measured 1-2 % slower here: profiles/r05_run29..31)
+    const int vb = blockIdx.x;
+    auto issue = [&](int t, int buf) {
+        int b, td, th, tw;
+        linear_tile(t, a.ntw, a.nth, a.ntd, b, td, th, tw);
+        const int qd0 = td * TD, qh0 = th * TH, qw0 = tw * TW;
+        const float* __restrict__ xb = a.x + ((((long long)b * a.Di + qd0) * a.Hi + qh0) * a.Wi + qw0) * CX;
+        const float* __restrict__ gb = a.g + ((((long long)b * a.QD + (qd0 - 1)) * a.QH + (qh0 - 1)) * a.QW + (qw0 - 1)) * CG;
+        const bool interior = qd0 >= 1 && qd0 + TD + 1 <= a.Di && qh0 >= 1 && qh0 + TH + 1 <= a.Hi && qw0 >= 1 && qw0 + TW + 1 <= a.Wi;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int d = NW * j + wave;
+            if (d >= NDMA) break;                    // wave-uniform
+            const bool is_g = d >= XDMA;             // wave-uniform
+            const float* src = (is_g ? gb : xb) + rel[j];
+            bool ok = crd[j] >= 0;
+            if (!interior) {
+                const int c0 = crd[j] & 255, c1 = (crd[j] >> 8) & 255, c2 = (crd[j] >> 16) & 255;
+                if (is_g) ok = ok && qd0 - 1 + c0 >= 0 && qd0 - 1 + c0 < a.QD && qh0 - 1 + c1 >= 0 && qh0 - 1 + c1 < a.QH &&
+                               qw0 - 1 + c2 >= 0 && qw0 - 1 + c2 < a.QW;
+                else ok = ok && qd0 + c0 < a.Di && qh0 + c1 < a.Hi && qw0 + c2 < a.Wi;
+            }
+            if (!ok) src = zero + 4 * (lane & 15);
+            MVS_DMA16(&lds[buf * BUFF + d * 256], src);      // X instructions fill [0, XF), G instructions follow
+        }
+    };
+
+    // ---- per-lane operand offsets (floats): A inside the X part, B inside the G part, both incl. the lane group's position g and
+    //      the wave group's k-step inside a row (k-step ks = KSPLIT * j + kq starts at position 4 * ks: row j / (4 / KSPLIT), pw = ...) ----
+    const int aoff = (g + 4 * kq) * CX + 16 * mt + l15;
+    int goff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        int tap = gs_pair_tap(2 * s + par, l15 >> 3);
+        if (tap > 26) tap = 13;                      // the column half without a tap computes unused values (no branch in the loop)
+        const int dt = tap / 9, ht = (tap / 3) % 3, wt = tap % 3;
+        goff[s] = XF + ((((2 - dt) * GH + (2 - ht)) * GW + (2 - wt) + g + 4 * kq) * CG) + (l15 & 7);
+    }
+    f32x4 acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (vb < ntiles) issue(vb, 0);
+    MVS_WAIT_VMCNT(0);
+    __syncthreads();
+
+    int it = 0;
+    for (int t = vb; t < ntiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const float* __restrict__ xs = lds + buf * BUFF + aoff;
+        const float* __restrict__ gs[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) gs[s] = lds + buf * BUFF + goff[s];
+        // wave-independent (compile-time) part of k-step j's offsets: positions 4 * KSPLIT * j ...
+        auto xrow = [](int j) { return 4 * KSPLIT * j * CX; };
+        auto grow = [](int j) {
+            const int p = 4 * KSPLIT * j, pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+            return ((pd * GH + ph) * GW + pw) * CG;
+        };
+        float av = xs[xrow(0)], bv[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bv[s] = gs[s][grow(0)];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float an = 0.f, bn[NS];
+            if (j + 1 < NJ) {
+                an = xs[xrow(j + 1)];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) bn[s] = gs[s][grow(j + 1)];
+            }
+            MVS_SCHED_FENCE();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = MVS_MFMA_16x16x4(av, bv[s], acc[s]);
+            MVS_SCHED_FENCE();
+            // the next tile's requests (tile coordinates, addresses, bounds, NDMA / NW instructions) go out under the execution of
+            // the MFMAs just issued instead of in front of the tile's first one
+            if (j == 1 && t + (int)gridDim.x < ntiles) issue(t + gridDim.x, buf ^ 1);
+            if (j + 1 < NJ) {
+                av = an;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) bv[s] = bn[s];
+            }
+        }
+        MVS_WAIT_VMCNT(0);       // the next tile's DMA has landed (it was requested a whole tile of MFMAs ago)
+        MVS_LDS_BARRIER();
+    }
+
+    // ---- the wave groups of the K split meet in LDS; group 0 writes the workgroup's partial image ----
+    __syncthreads();
+    if (kq > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[((((kq - 1) * 4 + w4) * NS + s) * 4 + r) * 64 + lane] = acc[s][r];
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = gs_pair_tap(2 * s + par, l15 >> 3);
+            if (tap > 26) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[s][r];
+#pragma unroll
+                for (int q = 1; q < KSPLIT; ++q) v += lds[((((q - 1) * 4 + w4) * NS + s) * 4 + r) * 64 + lane];
+                const int ci = 16 * mt + 4 * g + r;          // D layout: row = 4*(lane>>4)+r -> M index, col = lane&15 -> (tap of the pair, co)
+                a.part[(((size_t)blockIdx.x * 27 + tap) * CX + ci) * CG + (l15 & 7)] = v;
+            }
+        }
+    }
+}
+
+bool conv_c8_wgrad_gs_serves(int geom, int CX, int CG) { return geom == GEOM_S1 && CX == 32 && CG == 8; }
+
+// a: as run_wgrad fills it (4 x 4 x 16 tiles over the volume); waves: 8 or 16 per workgroup; returns the number of partial images written, < 0 on error
+int run_conv_c8_wgrad_gs(const WgradArgs& a, int max_groups, int waves, hipStream_t st) {
+    const int ntiles = a.B * a.ntd * a.nth * a.ntw;
+    int groups = max_groups < 256 ? max_groups : 256;                     // 106 KB of LDS: one workgroup (8 waves) per CU
+    if (groups > ntiles) groups = ntiles;
+    if (groups < 1) groups = 1;
+    if (waves == 16) MVS_LAUNCH((conv_c8_wgrad_gs_kernel<16>), dim3(groups), dim3(1024), 0, st, a);
+    else MVS_LAUNCH((conv_c8_wgrad_gs_kernel<8>), dim3(groups), dim3(512), 0, st, a);
+    const int rc = mvs_check_launch("conv_c8_wgrad_gs");
+    return rc ? rc : groups;
+}

@@ -1586,6 +1586,37 @@ def test_conv3d_persistent_weight_gradient(emul_lib, cin, cout, stride, transpos
     assert not torch.equal(new, torch.zeros_like(new))
 
 
+@pytest.mark.parametrize("groups", [3, 256], ids=["three_persistent_workgroups", "one_tile_per_workgroup"])
+@pytest.mark.parametrize("b,dims", [(2, (5, 6, 21)), (1, (8, 8, 32)), (1, (1, 1, 1)), (1, (3, 9, 17))],
+                         ids=["ragged_tiles_batch_2", "whole_tiles_with_interior", "one_voxel", "one_past_a_tile"])
+@pytest.mark.parametrize("waves", [1, 2], ids=["eight_waves", "sixteen_waves"])
+def test_conv0_weight_gradient_output_gradient_shifted_form(emul_lib, b, dims, groups, waves):
+    """conv_c8_wgrad_gs_kernel (conv0, 32 -> 8: X read unshifted without a halo, G with the halo as the shifted operand, 16x16x4 MFMA with
+    N = (tap pair, co), double-buffered LDS-DMA tiles, eight or sixteen waves) against autograd and the 4x4x1-MFMA kernel it replaces."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, 32, *dims, generator=g)
+    w = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    y = F.conv3d(x, w, stride=1, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    emul_lib.call("mvs_set_tuning", b"wgrad8_gs", 0)
+    try:
+        old = ops.conv3d_wgrad(x, gy, (8, 32, 3, 3, 3), 1, False)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_gs", waves)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_groups", groups)
+        new = ops.conv3d_wgrad(x, gy, (8, 32, 3, 3, 3), 1, False)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"wgrad8_gs", 1)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_groups", 256)
+    scale = max(1.0, float(w.grad.abs().max()))
+    assert float((new - w.grad).abs().max()) < 1e-3 * scale
+    assert float((new - old).abs().max()) < 2e-4 * scale
+    assert not torch.equal(new, torch.zeros_like(new))
+    # every tap of every (ci, co) is a different sum: a wrong tap pairing or operand shift cannot hide behind the tolerance
+    assert float((new - w.grad).abs().max()) < 0.05 * float(w.grad.abs().mean())
+
+
 @pytest.mark.parametrize("which", ["small", pytest.param("mvsnet", marks=_full), pytest.param("cvp", marks=_full)])
 def test_regulariser_pass_level_c_entry_equals_per_layer_calls(emul_lib, which):
     """mvs_unet_fwd / mvs_unet_bwd (ONE C call per pass over pointer tables into three arenas) against the same autograd node issuing

@@ -48,6 +48,7 @@ def main():
     w2 = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1).to(dev)       # conv2: 16 -> 16 at level 1
     cases = [
         ("conv0 dgrad (8@L0 -> 32@L0)", lambda: ops.conv3d_dgrad(x8, w0, tuple(x32.shape), 1, False), (126 + 503) * MB),
+        ("conv0 wgrad (32@L0 x 8@L0)", lambda: ops.conv3d_wgrad(x32, x8, tuple(w0.shape), 1, False), (126 + 503) * MB),
         ("conv2 fwd 16>16 @L1 (+stats)", lambda: ops.conv3d_forward(x16, w2, 1, False, want_stats=True), 63 * MB),
         ("conv2 dgrad + add", lambda: ops.conv3d_dgrad(x16, w2, tuple(x16.shape), 1, False, add=x16), 94.5 * MB),
         ("conv1 fwd 8>16 s2 (+stats)", lambda: ops.conv3d_forward(x8, w1, 2, False, want_stats=True), (126 + 31.5) * MB),
