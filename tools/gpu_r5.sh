@@ -71,6 +71,7 @@ PY
     timeout 900 python bench.py $short --force-collective --sustained 200 > gpurun_out/final_bench_collective_sustained.json 2> gpurun_out/final_bench_cs.err; echo "collective+sustained exit $?"; summ gpurun_out/final_bench_collective_sustained.json
     MVS_ASYNC_WGRAD=0 timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/final_bench_k_sync.json 2> gpurun_out/final_bench_k_sync.err
     grep "ms/step" gpurun_out/final_bench_k_sync.err > gpurun_out/final_kernel_table_sync_mode.txt; head -8 gpurun_out/final_kernel_table_sync_mode.txt
-    timeout 600 python tools/bench_narrow.py "" > gpurun_out/final_narrow_layers.log 2>&1; grep -v amdgpu gpurun_out/final_narrow_layers.log | tail -14 ;;
+    timeout 600 python tools/bench_narrow.py "" > gpurun_out/final_narrow_layers.log 2>&1; grep -v amdgpu gpurun_out/final_narrow_layers.log | tail -15
+    timeout 900 python bench.py --steps 20 --warmup 5 $short --ab "wgrad8_gs=0;wgrad8_gs=1;wgrad8_groups=192;wgrad8_groups=224;c_entry" --ab-reps 6 > gpurun_out/final_bench_ab.json 2> gpurun_out/final_bench_ab.err; echo "ab exit $?"; summ gpurun_out/final_bench_ab.json ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
