@@ -181,6 +181,45 @@ def pmc_traffic(cfg, dtype="f32"):
     return out, note
 
 
+def wgrad_all_cus(lib, dev, dims, flops, groups_all=256, reps=12):
+    """conv0's weight gradient with every CU (knob wgrad8_groups = 256), alone on the GPU, at the config's shape: the kernel's own
+    quality next to the numbers of the launch the step uses (which is given FEWER workgroups on purpose: it runs on the side stream
+    and the step is fastest when it leaves part of the chip to the main stream -- the A/B pairs are under profiles/)."""
+    import ctypes
+    from mvs_amd import ops as _o
+    d, h, w = dims
+    g = torch.Generator().manual_seed(7)
+    cl = torch.channels_last_3d
+    x = torch.randn(1, FEAT_C, d, h, w, generator=g).to(dev).contiguous(memory_format=cl)
+    gy = torch.randn(1, 8, d, h, w, generator=g).to(dev).contiguous(memory_format=cl)
+    cur = ctypes.c_int(0)
+    lib.call("mvs_get_tuning", b"wgrad8_groups", ctypes.byref(cur))
+    lib.call("mvs_set_tuning", b"wgrad8_groups", groups_all)
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                _o.conv3d_wgrad(x, gy, (8, FEAT_C, 3, 3, 3), 1, False)
+            torch.cuda.synchronize()
+            timer = _lib.KernelTimer(only={"mvs_conv3d_wgrad"}, names={"mvs_conv3d_wgrad"})
+            prev, lib.profiler = lib.profiler, timer
+            try:
+                for _ in range(reps):
+                    _o.conv3d_wgrad(x, gy, (8, FEAT_C, 3, 3, 3), 1, False)
+                torch.cuda.synchronize()
+            finally:
+                lib.profiler = prev
+    finally:
+        lib.call("mvs_set_tuning", b"wgrad8_groups", int(cur.value))
+    ms = [v[1] for v in timer.summary().values()]
+    if not ms:
+        return {}
+    ms = ms[0]      # mean over `reps` launches
+    return {"ms_all_cus": ms, "frac_all_cus": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "groups_in_step": int(cur.value),
+            "all_cus_is": "the same kernel on the same shape with %d workgroups (one per CU) and nothing beside it, convolution + the "
+                          "reduction of its partial images (the C-ABI call); in the step it is launched with `groups_in_step` "
+                          "workgroups on the side stream" % groups_all}
+
+
 def host_cpu():
     """(model name, physical cores, logical CPUs) of this box from lscpu / os."""
     import subprocess
@@ -859,6 +898,11 @@ def main():
                 k3["frac_alone"] = work[dom_key][1] / (s3[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
                 k3["alone_is"] = ("the same launch in the synchronous-weight-gradient pass after the timed region (main stream, nothing "
                                   "beside it); `ms` / `frac` are its duration on the side stream, under the main stream's kernels")
+        if dom_key == "conv0_wgrad" and dom_key in kernels and train and world == 1:
+            try:
+                kernels[dom_key].update(wgrad_all_cus(lib, dev, (ndepth, img_h // 4, img_w // 4), work[dom_key][1]))
+            except Exception as e:  # the bench line must still come out
+                kernels[dom_key]["all_cus_is"] = "not measured: %r" % (e,)
         dom = max(kernels, key=lambda k: kernels[k]["ms"], default=None)
         roof = None
         if dom is not None:
@@ -866,7 +910,7 @@ def main():
                     "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                     "traffic": kernels[dom].get("traffic"), "traffic_unit": "bytes of HBM traffic per launch", "traffic_source": traffic_note,
                     "ms": kernels[dom]["ms"], "timed": kernels[dom]["timed"]}
-            for extra in ("ms_alone", "frac_alone", "alone_is", "sq_counters"):
+            for extra in ("ms_alone", "frac_alone", "alone_is", "ms_all_cus", "frac_all_cus", "groups_in_step", "all_cus_is", "sq_counters"):
                 if extra in kernels[dom]:
                     roof[extra] = kernels[dom][extra]
         metric = {2: "depth-samples/sec (N=3, 640x512, D=192)", 3: "depth-samples/sec (JDACS self-supervised step, N=5, 640x512, D=192)",

@@ -148,7 +148,7 @@ _INSTANCE = None
 
 # library defaults of the measurement knobs (csrc: g_conv_c8, g_conv_xcd); MVS_TUNING="k8=2,xcd=0" overrides them
 # for A/B runs of bench.py / tools without touching code
-DEFAULT_TUNING = {"k8": 7, "xcd": 1, "side_pre": 1, "conv_pers": 1, "conv_pers_min": 1024, "conv_pers_nw": 8, "wgrad_pers": 1, "conv_small": 1, "tr2pw": 1, "sweep_bwd": 0, "wgrad_small": 0, "wgrad_groups": 768, "wgrad8_groups": 256, "wgrad8_gs": 2, "wgrad8_nch": 2, "cout1_h4": 1, "wgrad2d_batch": 2048}
+DEFAULT_TUNING = {"k8": 7, "xcd": 1, "side_pre": 1, "conv_pers": 1, "conv_pers_min": 1024, "conv_pers_nw": 8, "wgrad_pers": 1, "conv_small": 1, "tr2pw": 1, "sweep_bwd": 0, "wgrad_small": 0, "wgrad_groups": 768, "wgrad8_groups": 192, "wgrad8_gs": 2, "wgrad8_nch": 2, "cout1_h4": 1, "wgrad2d_batch": 2048}
 
 
 def get() -> MvsLib:

@@ -1483,7 +1483,7 @@ int g_conv_small = 1;   // tuning knob "conv_small": quarter-size workgroup tile
 int g_conv_c8 = 7;      // tuning knob "k8", bit mask: 1|2 = Cout==8 stride-1 layers run the 4x4x1 MFMA forward with the weights as the broadcast operand (0: generic kernel), +4 = weight gradient with g as the broadcast operand
 int g_conv_wgrad_groups = 768;   // tuning knob "wgrad_groups": persistent workgroups of the generic weight-gradient kernels (<= 768)
 int g_conv_cout1_h4 = 1;         // tuning knob "cout1_h4": the 8 -> 1 layer with four outputs per thread (conv_cout1_h4_kernel); 0: one output per thread
-int g_conv_wgrad8_groups = 256;  // tuning knob "wgrad8_groups": ... of the CG == 8 kernel (conv0; <= 512).  On the side stream it runs under the plane-sweep backward and the 2-D extractor's backward.  While the main stream was the longer one the step was faster the less this kernel took from it (5.440 ms at 512, 5.416 at 384, 5.413 at 256, 5.400 at 128: profiles/r04_run9_*); since the extractor's weight gradients became one launch the side stream ends last (+0.05 ms at the join) and 192 is the best of 128 / 192 / 256 / 384 / 512 (5.28 / 5.23 / 5.25 / 5.24 / 5.28: profiles/r04_run25_*)
+int g_conv_wgrad8_groups = 192;  // tuning knob "wgrad8_groups": ... of the CG == 8 kernel (conv0; <= 512).  On the side stream it runs under the plane-sweep backward and the 2-D extractor's backward.  While the main stream was the longer one the step was faster the less this kernel took from it (5.440 ms at 512, 5.416 at 384, 5.413 at 256, 5.400 at 128: profiles/r04_run9_*); since the extractor's weight gradients became one launch the side stream ends last (+0.05 ms at the join) and 192 is the best of 128 / 192 / 256 / 384 / 512 (5.28 / 5.23 / 5.25 / 5.24 / 5.28: profiles/r04_run25_*); round 5, conv_c8_wgrad_gs_kernel (sixteen waves, 106 KB of LDS per workgroup): 4.77 ms/step at 192, 4.78 at 176 / 160, 4.79 at 224, 4.83 at 256, 4.85 at 128 (profiles/r05_final_session.log, r05_run33_*)
 int g_conv_wgrad8_nch = 2;       // tuning knob "wgrad8_nch": 2 = the CG == 8 weight gradient stages both 16-channel chunks of a 32-channel X in one workgroup.  Default since the end of round 4: at 192 workgroups the one-chunk form draws 2.31 GB from HBM per launch (0.63 GB algorithmic; 1.14 GB at 128 workgroups, 2.04 GB at 256: which halo lines neighbouring workgroups find in their XCD's L2 depends on the count), the two-chunk form 1.08 GB, at the same step time (5.313 vs 5.298 ms, profiles/r04_run31_*); alone on the GPU it is the slower kernel (0.85 vs 0.76 ms at 192 workgroups)
 int g_conv_wgrad_small = 0;   // tuning knob "wgrad_small": 1 = quarter-size tiles in the generic weight-gradient kernel for 8-channel / stride-2 layers with many tiles, 2 = for every layer with many tiles, 3 = always (tests)
 int g_conv_side_pre = 1;   // tuning knob "side_pre": one-Cout-tile kernels with epilogue side inputs (skip / bn_raw) request them before the k-loop (1) or at the top of the epilogue (0)

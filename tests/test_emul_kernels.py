@@ -1607,8 +1607,8 @@ def test_conv0_weight_gradient_output_gradient_shifted_form(emul_lib, b, dims, g
         emul_lib.call("mvs_set_tuning", b"wgrad8_groups", groups)
         new = ops.conv3d_wgrad(x, gy, (8, 32, 3, 3, 3), 1, False)
     finally:
-        emul_lib.call("mvs_set_tuning", b"wgrad8_gs", 1)
-        emul_lib.call("mvs_set_tuning", b"wgrad8_groups", 256)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_gs", 2)
+        emul_lib.call("mvs_set_tuning", b"wgrad8_groups", 192)
     scale = max(1.0, float(w.grad.abs().max()))
     assert float((new - w.grad).abs().max()) < 1e-3 * scale
     assert float((new - old).abs().max()) < 2e-4 * scale
