@@ -186,7 +186,7 @@ def wgrad_all_cus(lib, dev, dims, flops, groups_all=256, reps=12):
     quality next to the numbers of the launch the step uses (which is given FEWER workgroups on purpose: it runs on the side stream
     and the step is fastest when it leaves part of the chip to the main stream -- the A/B pairs are under profiles/)."""
     import ctypes
-    from mvs_amd import ops as _o
+    from mvs_amd import _lib, ops as _o
     d, h, w = dims
     g = torch.Generator().manual_seed(7)
     cl = torch.channels_last_3d
@@ -210,10 +210,11 @@ def wgrad_all_cus(lib, dev, dims, flops, groups_all=256, reps=12):
                 lib.profiler = prev
     finally:
         lib.call("mvs_set_tuning", b"wgrad8_groups", int(cur.value))
-    ms = [v[1] for v in timer.summary().values()]
+    ms = sorted(a.elapsed_time(b) for evs in timer.events.values() for a, b in evs)
     if not ms:
         return {}
-    ms = ms[0]      # mean over `reps` launches
+    print("[bench] conv0 weight gradient alone with %d workgroups, ms per call: %s" % (groups_all, " ".join("%.3f" % m for m in ms)), file=sys.stderr)
+    ms = ms[len(ms) // 2]      # median of `reps` calls
     return {"ms_all_cus": ms, "frac_all_cus": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "groups_in_step": int(cur.value),
             "all_cus_is": "the same kernel on the same shape with %d workgroups (one per CU) and nothing beside it, convolution + the "
                           "reduction of its partial images (the C-ABI call); in the step it is launched with `groups_in_step` "

@@ -66,12 +66,12 @@ PY
       timeout 900 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --gpu-reference 0 --pmc 0 > gpurun_out/bench_c$cfg.json 2> gpurun_out/bench_c$cfg.err
       echo "config $cfg exit $?"; summ gpurun_out/bench_c$cfg.json
     done ;;
-  final)  # the closing sequence of the round: tools/gpu_round.sh final + what round 5 added
-    bash tools/gpu_round.sh final
+  final|final2)  # the closing sequence of the round: tools/gpu_round.sh final (final2: without configs 4 / 5) + what round 5 added
+    bash tools/gpu_round.sh $what
     timeout 900 python bench.py $short --force-collective --sustained 200 > gpurun_out/final_bench_collective_sustained.json 2> gpurun_out/final_bench_cs.err; echo "collective+sustained exit $?"; summ gpurun_out/final_bench_collective_sustained.json
     MVS_ASYNC_WGRAD=0 timeout 600 python bench.py --steps 10 --warmup 3 --time-all-kernels $short > gpurun_out/final_bench_k_sync.json 2> gpurun_out/final_bench_k_sync.err
     grep "ms/step" gpurun_out/final_bench_k_sync.err > gpurun_out/final_kernel_table_sync_mode.txt; head -8 gpurun_out/final_kernel_table_sync_mode.txt
     timeout 600 python tools/bench_narrow.py "" > gpurun_out/final_narrow_layers.log 2>&1; grep -v amdgpu gpurun_out/final_narrow_layers.log | tail -15
-    timeout 900 python bench.py --steps 20 --warmup 5 $short --ab "wgrad8_gs=0;wgrad8_gs=1;wgrad8_groups=192;wgrad8_groups=224;c_entry" --ab-reps 6 > gpurun_out/final_bench_ab.json 2> gpurun_out/final_bench_ab.err; echo "ab exit $?"; summ gpurun_out/final_bench_ab.json ;;
+    timeout 900 python bench.py --steps 20 --warmup 5 $short --ab "wgrad8_gs=0;wgrad8_gs=1;wgrad8_groups=160;wgrad8_groups=256;c_entry" --ab-reps 6 > gpurun_out/final_bench_ab.json 2> gpurun_out/final_bench_ab.err; echo "ab exit $?"; summ gpurun_out/final_bench_ab.json ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
