@@ -217,8 +217,10 @@ def wgrad_all_cus(lib, dev, dims, flops, groups_all=256, reps=12):
     ms = ms[len(ms) // 2]      # median of `reps` calls
     return {"ms_all_cus": ms, "frac_all_cus": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "groups_in_step": int(cur.value),
             "all_cus_is": "the same kernel on the same shape with %d workgroups (one per CU) and nothing beside it, convolution + the "
-                          "reduction of its partial images (the C-ABI call); in the step it is launched with `groups_in_step` "
-                          "workgroups on the side stream" % groups_all}
+                          "reduction of its partial images (the C-ABI call), on RANDOM operands right after the timed passes (median of "
+                          "%d calls); in the step it is launched with `groups_in_step` workgroups on the side stream.  Random fp32 "
+                          "operands on a warm chip are the slowest case of this MFMA-bound kernel: the step's own tensors at %d "
+                          "workgroups take 0.46 ms, a fresh process on random tensors 0.45 (profiles/README.md)" % (groups_all, reps, groups_all)}
 
 
 def host_cpu():
