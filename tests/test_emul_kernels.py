@@ -1586,11 +1586,15 @@ def test_conv3d_persistent_weight_gradient(emul_lib, cin, cout, stride, transpos
     assert not torch.equal(new, torch.zeros_like(new))
 
 
-@pytest.mark.parametrize("groups", [3, 256], ids=["three_persistent_workgroups", "one_tile_per_workgroup"])
-@pytest.mark.parametrize("b,dims", [(2, (5, 6, 21)), (1, (8, 8, 32)), (1, (1, 1, 1)), (1, (3, 9, 17))],
-                         ids=["ragged_tiles_batch_2", "whole_tiles_with_interior", "one_voxel", "one_past_a_tile"])
-@pytest.mark.parametrize("waves", [1, 2], ids=["eight_waves", "sixteen_waves"])
-def test_conv0_weight_gradient_output_gradient_shifted_form(emul_lib, b, dims, groups, waves):
+@pytest.mark.parametrize("waves,b,dims,groups", [
+    (2, 2, (3, 5, 17), 3),         # sixteen waves; ragged tiles, batch 2, three persistent workgroups walk eight tiles
+    (1, 2, (3, 5, 17), 192),       # eight waves; one tile per workgroup
+    (2, 1, (8, 8, 32), 3),         # whole tiles
+    (2, 1, (1, 1, 1), 192),        # one voxel: 26 of 27 taps see only the zero page
+    (1, 1, (3, 9, 17), 3),         # one voxel past a tile in H and W
+    pytest.param(2, 1, (12, 12, 48), 5, marks=_full),   # 27 tiles, the middle one takes the interior path (no bounds checks); the GPU suite runs it at config 2's size
+], ids=["sixteen_waves_ragged_batch_2", "eight_waves_one_tile_per_workgroup", "whole_tiles", "one_voxel", "one_past_a_tile", "interior_tile"])
+def test_conv0_weight_gradient_output_gradient_shifted_form(emul_lib, waves, b, dims, groups):
     """conv_c8_wgrad_gs_kernel (conv0, 32 -> 8: X read unshifted without a halo, G with the halo as the shifted operand, 16x16x4 MFMA with
     N = (tap pair, co), double-buffered LDS-DMA tiles, eight or sixteen waves) against autograd and the 4x4x1-MFMA kernel it replaces."""
     from mvs_amd import ops
