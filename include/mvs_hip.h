@@ -40,8 +40,12 @@ int mvs_is_emulation(void);         /* 0 in the product library */
  * 1 view pairs + LDS atomics; "fwd_dl" 0 | 1 per-plane depths staged in LDS (default) | 2 + in-block gather waits;
  * "bwd_gd" 2 (default: 2-plane gradient groups, 2 waves/SIMD) | 0 (1-plane groups, 3 waves/SIMD), "bwd_pf" 0 | 1 block
  * lookahead (1-2 views) | 2 one wave/SIMD (3-4 views), "bwd_dslab", "bwd_nowin", "bwd_cpt" (ignored); "nt", "tile_w", "dslab";
- * "conv_split", "conv_small", "conv_small_wgs", "tr2pw", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups".
- * Process-wide, not part of the data path's contract. */
+ * "conv_split", "conv_small", "conv_small_wgs", "tr2pw", "k8", "fs", "xcd"; "conv2d_s2_mfma", "wgrad2d_groups";
+ * round 5: "conv_pers" / "conv_pers_min" / "conv_pers_groups" / "conv_pers_nw" (persistent LDS-DMA convolutions), "wgrad_pers",
+ * "wgrad8_gs" 0 | 1 | 2 (conv0's weight gradient: 4x4x1-MFMA kernel | output-gradient-shifted form with eight | sixteen waves),
+ * "wgrad8_groups" (its workgroups: 192 of 256 CUs on the side stream), "wgrad_groups".  The full table with ranges is in
+ * csrc/plane_sweep.hip (mvs_set_tuning); the defaults are mirrored in _lib.DEFAULT_TUNING and checked by
+ * tests/test_capi_symbols.py.  Process-wide, not part of the data path's contract. */
 int mvs_set_tuning(const char* key, int value);
 int mvs_get_tuning(const char* key, int* value);   /* the knob's current value (a freshly loaded library: its default) */
 
