@@ -435,6 +435,63 @@ def test_conv3d_family_vs_torch(dev, conv_tiles, cin, cout, stride, transposed, 
     assert float((gw.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("b,dims,groups", [(2, (13, 21, 53), 192), (1, (12, 12, 48), 7), (1, (1, 1, 1), 192)],
+                         ids=["ragged_batch_2_with_interior_tiles", "seven_persistent_workgroups", "one_voxel"])
+def test_conv0_weight_gradient_forms_vs_fp64_autograd(dev, b, dims, groups):
+    """conv0's weight gradient (32 -> 8): the output-gradient-shifted kernel with sixteen and eight waves (knob wgrad8_gs = 2 / 1) and the
+    4x4x1-MFMA kernel it replaced (0), each against autograd in fp64 under the conftest criterion (the fp32 yardstick is ATen's own
+    fp32 weight gradient), and against each other."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(b, 32, *dims, generator=g)
+    gy = torch.randn(b, 8, *dims, generator=g)
+    w64 = torch.zeros(8, 32, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w64, padding=1).backward(gy.double())
+    w32 = torch.zeros(8, 32, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, w32, padding=1).backward(gy)
+    got = {}
+    try:
+        for form in (2, 1, 0):
+            lib.call("mvs_set_tuning", b"wgrad8_gs", form)
+            lib.call("mvs_set_tuning", b"wgrad8_groups", groups)
+            got[form] = ops.conv3d_wgrad(x.to(dev), gy.to(dev), (8, 32, 3, 3, 3), 1, False).cpu()
+    finally:
+        lib.call("mvs_set_tuning", b"wgrad8_gs", _lib.DEFAULT_TUNING["wgrad8_gs"])
+        lib.call("mvs_set_tuning", b"wgrad8_groups", _lib.DEFAULT_TUNING["wgrad8_groups"])
+    for form, gw in got.items():
+        assert_grads_as_accurate_as_fp32_reference({"w": gw}, {"w": w32.grad}, {"w": w64.grad}, what="conv0 weight gradient, wgrad8_gs=%d" % form)
+    scale = max(1.0, float(w64.grad.abs().max()))
+    assert float((got[2] - got[0]).abs().max()) < 2e-4 * scale and float((got[1] - got[0]).abs().max()) < 2e-4 * scale
+
+
+def test_conv0_weight_gradient_forms_agree_at_config2_size(dev):
+    """The same three kernels on BASELINE config 2's cost volume (1 x 32 x 192 x 128 x 160: 15360 tiles, 60-80 per persistent workgroup)
+    with a smooth non-negative X like the variance volume: the forms differ only in the order of a 3.9 M-term sum per element."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = (torch.randn(1, 32, 192, 128, 160, generator=g, device=dev) ** 2 * 0.3).contiguous(memory_format=torch.channels_last_3d)
+    gy = (torch.randn(1, 8, 192, 128, 160, generator=g, device=dev) * 1e-3).contiguous(memory_format=torch.channels_last_3d)
+    got = {}
+    try:
+        for form in (2, 1, 0):
+            lib.call("mvs_set_tuning", b"wgrad8_gs", form)
+            got[form] = ops.conv3d_wgrad(x, gy, (8, 32, 3, 3, 3), 1, False).double().cpu()
+    finally:
+        lib.call("mvs_set_tuning", b"wgrad8_gs", _lib.DEFAULT_TUNING["wgrad8_gs"])
+    # truth of one (ci, co) plane of taps from an fp64 reduction on the GPU: dW[t][ci][co] = sum_p X[p + t - 1][ci] G[p][co]
+    xs, gs = x[0, 5].double(), gy[0, 3].double()
+    xp = F.pad(xs, (1, 1, 1, 1, 1, 1))
+    truth = torch.stack([(xp[kd:kd + 192, kh:kh + 128, kw:kw + 160] * gs).sum() for kd in range(3) for kh in range(3) for kw in range(3)]).cpu()
+    ref_err = float((got[0][3, 5].reshape(-1) - truth).abs().sum() / truth.abs().sum())
+    for form in (2, 1):
+        err = float((got[form][3, 5].reshape(-1) - truth).abs().sum() / truth.abs().sum())
+        assert err <= 4.0 * ref_err + 2e-5, (form, err, ref_err)
+        rel = float((got[form] - got[0]).abs().sum() / got[0].abs().sum())
+        assert rel < 2e-5, (form, rel)
+
+
 @pytest.mark.parametrize("cin,dims", [(32, (9, 18, 40)), (16, (8, 22, 16)), (8, (5, 4, 33))])
 @pytest.mark.parametrize("k8,xcd", [(7, 1), (7, 0), (1, 1), (1, 0)])
 def test_conv_cout8_forms_and_tile_orders(dev, cin, dims, k8, xcd):
