@@ -796,6 +796,9 @@ def main():
             elif spec == "c_entry":
                 def setter(on, base=_ops.C_ENTRY):
                     _ops.C_ENTRY = (not base) if on else base
+            elif spec == "feature_bias_side":
+                def setter(on, base=_ops.FEATURE_BIAS_SIDE):
+                    _ops.FEATURE_BIAS_SIDE = (not base) if on else base
             elif spec == "feature_wgrad_early":
                 def setter(on, base=_ops.FEATURE_WGRAD_EARLY):
                     _ops.FEATURE_WGRAD_EARLY = (not base) if on else base

@@ -1232,6 +1232,7 @@ FEATURE_DGRAD_BNSTATS = os.environ.get("MVS_FEATURE_DGRAD_BNSTATS", "0") == "1"
 
 
 FEATURE_WGRAD_EARLY = os.environ.get("MVS_FEATURE_WGRAD_EARLY", "1") != "0"
+FEATURE_BIAS_SIDE = os.environ.get("MVS_FEATURE_BIAS_SIDE", "1") != "0"   # with FEATURE_WGRAD_EARLY: the closing convolution's bias gradient on the side stream
 
 
 class FeatureExtractorFn(torch.autograd.Function):
@@ -1327,24 +1328,35 @@ class FeatureExtractorFn(torch.autograd.Function):
             raise RuntimeError("mvs_amd: FEATURE_FUSED_APPLY needs every convolution weight to require a gradient and a one-launch "
                                "weight-gradient instantiation for every layer (the normalised activations were not kept)")
         draws = [None] * n
-        if batch:
-            g = bwd(gout, acts[n], fw, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
-            if need[3 + 5 * n + 1]:
-                grads[5 * n + 1] = gout.sum((0, 2, 3))
-        else:
-            g, gfw, gfb = bwd(gout, acts[n], fw, [fw.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                              [True, bool(need[3 + 5 * n]), bool(need[3 + 5 * n + 1])])
-            grads[5 * n], grads[5 * n + 1] = gfw, gfb
-        have = False     # the block's backward statistics are already in its slots (the input gradient above it put them there)
         # FEATURE_WGRAD_EARLY: the weight gradients of the LAST layers (the 32-channel ones: two of the batch kernel's three launches'
         # worth of MFMA work) are enqueued on the side stream as soon as their output gradients exist and run next to the rest of
-        # this backward pass -- the main stream is the step's critical path (bench.py --step-events: the side stream ends 0.13 ms
+        # this backward pass -- the main stream is the step's critical path (bench.py --step-events: the side stream ends 0.1 ms
         # before it), so what leaves it shortens the step.  Joined before this node returns.
         early_from = None
         if batch and FEATURE_WGRAD_EARLY and _ASYNC_WGRAD_FUSED and gout.is_cuda and n >= 4:
             early_from = next((i for i in range(n) if ws_[i].shape[0] >= 32), None)     # first block with >= 32 output channels
             if early_from is not None and not (0 < early_from < n):
                 early_from = None
+        if batch:
+            if need[3 + 5 * n + 1]:
+                if early_from is not None and FEATURE_BIAS_SIDE:
+                    # the closing convolution's bias gradient (two reduction launches over the output gradient) is nobody's input
+                    # before the optimiser: on the side stream too, into a buffer of the main stream's allocator pool
+                    main = torch.cuda.current_stream(gout.device)
+                    side = _side_stream(gout.device)
+                    gb = torch.empty(gout.shape[1], dtype=gout.dtype, device=gout.device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        torch.sum(gout, (0, 2, 3), out=gb)
+                    grads[5 * n + 1] = gb
+                else:
+                    grads[5 * n + 1] = gout.sum((0, 2, 3))
+            g = bwd(gout, acts[n], fw, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        else:
+            g, gfw, gfb = bwd(gout, acts[n], fw, [fw.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                              [True, bool(need[3 + 5 * n]), bool(need[3 + 5 * n + 1])])
+            grads[5 * n], grads[5 * n + 1] = gfw, gfb
+        have = False     # the block's backward statistics are already in its slots (the input gradient above it put them there)
         early_gws = None
         for i in range(n - 1, -1, -1):
             stride, padding, eps, momentum, hip_dgrad = cfg[i]
