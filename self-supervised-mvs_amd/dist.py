@@ -137,19 +137,43 @@ class FlatGradBucket:
         views of the bucket would instead cost one accumulate-add launch per parameter and step: autograd adds into an
         existing .grad, it only hands over ownership when .grad is None.)  With flatten_params the gradient of a
         parameter is laid out like the parameter (same strides), so bucket[i] is the gradient of flat_param[i]."""
-        self.check_aliasing()
-        grads = []
-        for p in self.params:
-            g = p.grad
-            if g is None:
-                g = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
-            elif self.flat_param is not None and g.stride() != p.stride():
-                # autograd handed over a gradient in another layout than the parameter's: re-lay it out (one small copy)
-                g = self._storage_order(torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device).copy_(g))
-            else:
-                g = self._storage_order(g) if self.flat_param is not None else g.reshape(-1)
-            grads.append(g)
-        torch.cat(grads, out=self.flat)
+        # (the aliasing walk is 55 data_ptr() calls: on the first steps and then every 32nd -- the launch thread's time per step is
+        # within 20-40 % of the GPU's: profiles/README.md, host enqueue)
+        self._gathers = getattr(self, "_gathers", 0) + 1
+        if self._gathers <= 2 or self._gathers % 32 == 0:
+            self.check_aliasing()
+        fast = self.flat_param is not None and hasattr(torch, "_foreach_copy_")
+        if fast:
+            # the common step: every parameter has a gradient in the parameter's own layout -> one multi-tensor copy into cached
+            # views of the bucket that carry those strides (no per-tensor view construction on the launch thread)
+            views = getattr(self, "_grad_views", None)
+            if views is None:
+                views, off = [], 0
+                for p in self.params:
+                    n = p.numel()
+                    views.append(self.flat[off:off + n].as_strided(p.shape, p.stride()))
+                    off += n
+                self._grad_views = views
+            grads = [p.grad for p in self.params]
+            for g, v in zip(grads, views):
+                if g is None or g.dtype != v.dtype or g.stride() != v.stride():
+                    fast = False
+                    break
+            if fast:
+                torch._foreach_copy_(views, grads)
+        if not fast:
+            grads = []
+            for p in self.params:
+                g = p.grad
+                if g is None:
+                    g = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device)
+                elif self.flat_param is not None and g.stride() != p.stride():
+                    # autograd handed over a gradient in another layout than the parameter's: re-lay it out (one small copy)
+                    g = self._storage_order(torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device).copy_(g))
+                else:
+                    g = self._storage_order(g) if self.flat_param is not None else g.reshape(-1)
+                grads.append(g)
+            torch.cat(grads, out=self.flat)
         # an optimizer.zero_grad() (set_to_none=True is torch's default) drops the slices' .grad views of the bucket and the
         # next opt.step() would then skip every slice without an error: re-attach them (no launch, views only)
         for p, lo, hi in getattr(self, "_opt_slices", ()):
