@@ -155,6 +155,52 @@ def test_flat_bucket_keeps_channels_last_params_trainable():
     with pytest.raises(RuntimeError, match="no longer aliases"):
         bucket.gather()
 
+def test_flat_bucket_gather_fast_path_equals_the_concatenation():
+    """FlatGradBucket.gather(): the one-launch copy into cached strided views of the bucket (every gradient present, in its parameter's
+    layout) writes exactly what the concatenation of the gradients in storage order writes; a missing gradient, a gradient in another
+    layout or another dtype take the general path and give the same bucket as before the fast path existed."""
+    import mvs_amd  # noqa: F401
+    from mvs_amd import dist as mdist
+    torch.manual_seed(1)
+    model = torch.nn.Sequential(torch.nn.Conv3d(4, 8, 3, padding=1), torch.nn.BatchNorm3d(8), torch.nn.Conv2d(8, 4, 5, stride=2, padding=2),
+                                torch.nn.Conv3d(8, 1, 3, padding=1))
+    model[0].weight.data = model[0].weight.data.contiguous(memory_format=torch.channels_last_3d)
+    model[2].weight.data = model[2].weight.data.contiguous(memory_format=torch.channels_last)
+    bucket = mdist.FlatGradBucket(model.parameters(), flatten_params=True)
+    params = list(model.parameters())
+
+    def expected():
+        parts = []
+        for p in params:
+            if p.grad is None:
+                parts.append(torch.zeros(p.numel()))
+            else:
+                parts.append(torch.empty_strided(p.shape, p.stride()).copy_(p.grad).as_strided((p.numel(),), (1,)))
+        return torch.cat(parts)
+
+    for step in range(3):                                   # the cached views are reused from the second step on
+        for p in params:
+            p.grad = torch.empty_strided(p.shape, p.stride()).normal_()
+        want = expected()
+        bucket.gather()
+        assert torch.equal(bucket.flat, want)
+    assert len(bucket._grad_views) == len(params)
+    params[0].grad = torch.randn(params[0].shape)           # a contiguous gradient for a channels-last parameter: general path
+    assert params[0].grad.stride() != params[0].stride()
+    want = expected()
+    bucket.gather()
+    assert torch.equal(bucket.flat, want)
+    params[3].grad = None                                   # a parameter without a gradient: zeros in its slice
+    want = expected()
+    bucket.gather()
+    assert torch.equal(bucket.flat, want)
+    for p in params:                                        # and back on the fast path
+        p.grad = torch.empty_strided(p.shape, p.stride()).normal_()
+    want = expected()
+    bucket.gather()
+    assert torch.equal(bucket.flat, want)
+
+
 def test_sliced_optimizer_params_equal_the_single_flat_tensor():
     """FlatGradBucket.optimizer_params(): Adam over the flat store as N slices gives bit-identical parameters to Adam over the one
     flat tensor (element-wise update), for several steps, and the slices alias the store / the bucket."""
