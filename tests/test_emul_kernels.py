@@ -1352,7 +1352,7 @@ def _stock_extractor(net, x, groups):
 
 # (the one-launch weight gradients without the consumer-side BatchNorm -- MVS_FEATURE_FUSED_APPLY=0 -- are covered kernel by kernel in
 #  test_conv2d_weight_gradients_of_all_layers_in_one_launch and end to end on the GPU)
-@pytest.mark.parametrize("wgrad_batch,fused,dgrad_bn", [(False, False, False), (True, True, False), (True, True, True)],
+@pytest.mark.parametrize("wgrad_batch,fused,dgrad_bn", [(False, False, False), (True, True, False), pytest.param(True, True, True, marks=_full)],
                          ids=["library_wgrad", "consumer_side_batchnorm", "consumer_side_batchnorm+dgrad_statistics"])
 def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused, dgrad_bn):
     """ops.FeatureExtractorFn (FeatureNet in training as ONE autograd node: mvsnet.py:17-34 + module.py:15-22 for every block) on the
@@ -1496,7 +1496,7 @@ def test_conv_cout8_weight_gradient_two_chunks_per_workgroup(emul_lib, dims, xcd
 
 # the persistent LDS-DMA implicit GEMM (csrc/conv3d_pers.hip): (cin, cout, stride, transposed, op, dims) -- op "fwd" / "dgrad"
 PERS_CASES = [
-    (16, 16, 1, False, "fwd", (5, 9, 37)),      # conv2: stride-1, 16-channel chunk, ragged 4 x 4 x 16 tiles in all directions
+    (16, 16, 1, False, "fwd", (5, 6, 21)),      # conv2: stride-1, 16-channel chunk, ragged 4 x 4 x 16 tiles in all directions
     (16, 16, 1, False, "dgrad", (4, 6, 20)),    # its input gradient (flipped taps) with summand + BatchNorm backward statistics
     (8, 16, 2, False, "fwd", (6, 10, 36)),      # conv1: stride 2, 8 channels (two taps per k-step)
     (16, 8, 2, True, "dgrad", (3, 5, 18)),      # conv11's input gradient: the same geometry through mvs_convT3d_dgrad
@@ -1588,10 +1588,10 @@ def test_conv3d_persistent_weight_gradient(emul_lib, cin, cout, stride, transpos
 
 @pytest.mark.parametrize("waves,b,dims,groups", [
     (2, 2, (3, 5, 17), 3),         # sixteen waves; ragged tiles, batch 2, three persistent workgroups walk eight tiles
-    (1, 2, (3, 5, 17), 192),       # eight waves; one tile per workgroup
-    (2, 1, (8, 8, 32), 3),         # whole tiles
+    pytest.param(1, 2, (3, 5, 17), 192, marks=_full),   # eight waves (knob wgrad8_gs = 1; on the GPU: test_conv0_weight_gradient_forms_vs_fp64_autograd); one tile per workgroup
+    pytest.param(2, 1, (8, 8, 32), 3, marks=_full),     # whole tiles
     (2, 1, (1, 1, 1), 192),        # one voxel: 26 of 27 taps see only the zero page
-    (1, 1, (3, 9, 17), 3),         # one voxel past a tile in H and W
+    (1, 1, (3, 9, 17), 3),         # eight waves; one voxel past a tile in H and W
     pytest.param(2, 1, (12, 12, 48), 5, marks=_full),   # 27 tiles, the middle one takes the interior path (no bounds checks); the GPU suite runs it at config 2's size
 ], ids=["sixteen_waves_ragged_batch_2", "eight_waves_one_tile_per_workgroup", "whole_tiles", "one_voxel", "one_past_a_tile", "interior_tile"])
 def test_conv0_weight_gradient_output_gradient_shifted_form(emul_lib, waves, b, dims, groups):
