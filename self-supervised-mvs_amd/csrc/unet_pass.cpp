@@ -210,6 +210,12 @@ extern "C" int mvs_unet_bwd(int n, const MvsUnetBlock* blk, int B, const float* 
     const float* gp[MVS_UNET_MAX_BLOCKS];               // current gradient w.r.t. each block's output (null: none yet)
     bool have[MVS_UNET_MAX_BLOCKS];                     // its backward statistics are already in slots_b[j]
     for (int j = 0; j < n; ++j) { gp[j] = nullptr; have[j] = false; }
+    bool gx_written = false;                            // a second reader of the volume x ADDS to gx (the last write used to win)
+    // a failure after the first fork must not leave work on the side stream unjoined (and must tell the caller the stream was used)
+    struct Closer {
+        MvsForkJoin& fj; bool& used; hipStream_t side, main; int* out; bool done = false;
+        ~Closer() { if (!done) { if (used) fj.join(side, main); if (out) *out = used ? 1 : 0; } }
+    } closer{fj, side_used, side_stream, main_stream, side_stream_used};
 
     // ---- prob layer ----
     int od, oh, ow;
@@ -255,16 +261,19 @@ extern "C" int mvs_unet_bwd(int n, const MvsUnetBlock* blk, int B, const float* 
             have[b.src] = bn;
         } else if (gx) {
             MVS_REQUIRE(packed_dgrad[i], MVS_ERR_NULL, "mvs_unet_bwd: gx wanted but block %d has no input-gradient weight image", i);
+            const float* add = gx_written ? gx : nullptr;
             if (b.transposed)
-                MVS_TRY(mvs_convT3d_dgrad(draw[i], w[i], nullptr, gx, packed_dgrad[i], B, b.d, b.h, b.w, b.cin, b.cout, b.stride, nullptr,
+                MVS_TRY(mvs_convT3d_dgrad(draw[i], w[i], add, gx, packed_dgrad[i], B, b.d, b.h, b.w, b.cin, b.cout, b.stride, nullptr,
                                           nullptr, nullptr, 0, 1, main_stream));
             else
-                MVS_TRY(mvs_conv3d_dgrad(draw[i], w[i], nullptr, gx, packed_dgrad[i], B, b.d, b.h, b.w, b.cin, b.cout, b.stride, nullptr,
+                MVS_TRY(mvs_conv3d_dgrad(draw[i], w[i], add, gx, packed_dgrad[i], B, b.d, b.h, b.w, b.cin, b.cout, b.stride, nullptr,
                                          nullptr, nullptr, 0, 1, main_stream));
+            gx_written = true;
         }
         // the side stream forks where the weight gradient is enqueued: after the block's input gradient
         MVS_TRY(wgrad(i, xin, draw[i], &b, b.d, b.h, b.w, b.cin, b.cout, b.stride, b.transposed));
     }
+    closer.done = true;
     if (side_used && join) fj.join(side_stream, main_stream);
     if (side_stream_used) *side_stream_used = side_used ? 1 : 0;     // 1 and no join: weight gradients are still running on the side stream
     return MVS_OK;

@@ -137,11 +137,14 @@ class FlatGradBucket:
         views of the bucket would instead cost one accumulate-add launch per parameter and step: autograd adds into an
         existing .grad, it only hands over ownership when .grad is None.)  With flatten_params the gradient of a
         parameter is laid out like the parameter (same strides), so bucket[i] is the gradient of flat_param[i]."""
-        # (the aliasing walk is 55 data_ptr() calls: on the first steps and then every 32nd -- the launch thread's time per step is
-        # within 20-40 % of the GPU's: profiles/README.md, host enqueue)
-        self._gathers = getattr(self, "_gathers", 0) + 1
-        if self._gathers <= 2 or self._gathers % 32 == 0:
+        # every step: one tuple of the parameters' storage addresses against the one seen last (55 data_ptr() calls ~ 15 us of launch-thread
+        # time; round 5 walked only every 32nd step and could skip a re-allocated parameter for 31 optimiser steps -- ADVICE r5).  On a
+        # change: the aliasing check (raises if a parameter left the flat store) and fresh gradient views (strides may have changed).
+        ptrs = tuple(p.data_ptr() for p in self.params)
+        if ptrs != getattr(self, "_param_ptrs", None):
             self.check_aliasing()
+            self._param_ptrs = ptrs
+            self._grad_views = None
         fast = self.flat_param is not None and hasattr(torch, "_foreach_copy_")
         if fast:
             # the common step: every parameter has a gradient in the parameter's own layout -> one multi-tensor copy into cached

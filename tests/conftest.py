@@ -20,6 +20,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The oracle / golden PARITY tests are collected first, the execution-mode self-comparisons (tests/test_gpu_z_modes.py) last:
+    with `-x`, a mode test may never stand in front of the parity record again (GPUTEST_r05).  Stable within each group."""
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name == "test_gpu_parity.py":
+            return 0
+        if name == "test_gpu_z_modes.py":
+            return 2
+        return 1
+    items.sort(key=rank)
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     out = {}

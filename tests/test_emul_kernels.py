@@ -1683,6 +1683,63 @@ def test_regulariser_pass_level_c_entry_equals_per_layer_calls(emul_lib, which):
         assert torch.equal(a[3][k], b[3][k]), k
 
 
+def _run_program(emul_lib, c_entry, layers_of, x0):
+    from mvs_amd import ops
+    net = layers_of()
+    x = x0.clone().requires_grad_(True)
+    old = ops.C_ENTRY
+    ops.C_ENTRY = c_entry
+    try:
+        y = net.run(x)
+        y.backward(torch.randn(y.shape, generator=torch.Generator().manual_seed(2)))
+    finally:
+        ops.C_ENTRY = old
+    return y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+
+def test_regulariser_c_entry_two_readers_of_the_volume_and_unsupported_programs(emul_lib):
+    """ADVICE r5.  (1) a program in which TWO blocks read the volume x: mvs_unet_bwd used to write gx twice with add = null (the last
+    write won, silently); it now accumulates, and the C entry equals the per-layer path.  (2) a block that is the skip operand of two
+    later blocks (needs an explicit gradient add, which mvs_unet_bwd refuses): `_UnetPlan.ok` must send it down the per-layer path at
+    FORWARD time -- the result then equals C_ENTRY = False trivially, and no MVS_ERR_UNSUPPORTED surfaces in backward()."""
+    from mvs_amd import nn3d, ops
+    x0 = torch.randn(1, 8, 4, 4, 16, generator=torch.Generator().manual_seed(1))
+
+    class TwoReaders(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(7)
+            self.a, self.b, self.c = nn3d.ConvBnReLU3D(8, 8), nn3d.ConvBnReLU3D(8, 8), nn3d.ConvBnReLU3D(8, 8)
+            self.prob = nn3d.ProbConv3d(8)
+            self.train()
+
+        def run(self, x):     # a = f(x); b = g(x) + a; c = h(b)
+            return ops.unet_regulariser(x, [(self.a.conv, self.a.bn, False, 1, -1, -1), (self.b.conv, self.b.bn, False, 1, -1, 0),
+                                            (self.c.conv, self.c.bn, False, 1, 1, -1)], self.prob)
+
+    prog = ((False, 1, -1, -1, 1e-5, 0.1), (False, 1, -1, 0, 1e-5, 0.1), (False, 1, 1, -1, 1e-5, 0.1))
+    plan = ops._UnetPlan(emul_lib, prog, (1, 8, 4, 4, 16), [(8, 8, 3, 3, 3)] * 3, 1)
+    assert plan.ok
+    a, b = _run_program(emul_lib, True, TwoReaders, x0), _run_program(emul_lib, False, TwoReaders, x0)
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[1], b[1]), "x.grad: two readers of the volume"
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+
+    class TwoSkips(TwoReaders):
+        def run(self, x):     # a = f(x); b = g(a) + a; c = h(b) + a: block 0 is the skip operand of blocks 1 and 2
+            return ops.unet_regulariser(x, [(self.a.conv, self.a.bn, False, 1, -1, -1), (self.b.conv, self.b.bn, False, 1, 0, 0),
+                                            (self.c.conv, self.c.bn, False, 1, 1, 0)], self.prob)
+
+    prog2 = ((False, 1, -1, -1, 1e-5, 0.1), (False, 1, 0, 0, 1e-5, 0.1), (False, 1, 1, 0, 1e-5, 0.1))
+    assert not ops._UnetPlan(emul_lib, prog2, (1, 8, 4, 4, 16), [(8, 8, 3, 3, 3)] * 3, 1).ok
+    a, b = _run_program(emul_lib, True, TwoSkips, x0), _run_program(emul_lib, False, TwoSkips, x0)
+    assert torch.equal(a[1], b[1])
+    # the skip consumer BEFORE the input consumer in the backward order is the supported direction; the other one is refused too
+    prog3 = ((False, 1, -1, -1, 1e-5, 0.1), (False, 1, -1, 0, 1e-5, 0.1), (False, 1, 0, 1, 1e-5, 0.1))   # block 0: skip of 1, input of 2
+    assert not ops._UnetPlan(emul_lib, prog3, (1, 8, 4, 4, 16), [(8, 8, 3, 3, 3)] * 3, 1).ok
+
+
 def test_regulariser_c_entry_rejects_bad_programs(emul_lib):
     """C-ABI error behaviour of mvs_unet_fwd: a block that reads a later block, too many blocks, null tables."""
     import ctypes as C
