@@ -86,6 +86,33 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restric
     if (idx >= total) return;
     conv2d_pack_item(w, wp, NT, CC, Cin, Cout, NB, transposed, cls, pp, 0, idx);
 }
+// Round 6: the four parity-class images of a 5x5 stride-2 layer's input gradient in ONE launch (blockIdx.y = class), taps COMPACTED:
+// class (py, px) only has (3 - py) x (3 - px) non-empty taps of the 3x3 coarse-grid kernel (c2_s2_tap: offset -1 of an odd parity has
+// no original tap), so its K dimension walks 9 / 6 / 6 / 4 taps instead of 9 each (25 instead of 36 tap-slices of MFMA work).
+// Image of class c at wp + c2_s2d_prefix(c): [chunk][ksteps_c][NB][64][4]; flattened k = 16 ks + 4 (l>>4) + j -> (compact tap i = k / CC,
+// ci = chunk*CC + k % CC), compact tap i -> coarse offsets (ty', tx') = (py + i / ntx, px + i % ntx).
+MVS_HD inline int c2_s2d_ntaps(int cls) { return (3 - (cls >> 1)) * (3 - (cls & 1)); }
+MVS_HD inline int c2_s2d_floats(int cls, int CC, int nch, int NB) { return nch * c2_ksteps(c2_s2d_ntaps(cls), CC) * NB * 256; }
+MVS_HD inline int c2_s2d_prefix(int cls, int CC, int nch, int NB) {
+    int s = 0;
+    for (int c = 0; c < cls; ++c) s += c2_s2d_floats(c, CC, nch, NB);
+    return s;
+}
+__global__ __launch_bounds__(256) void conv2d_pack_s2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int CC, int Cin, int Cout,
+                                                              int NB, int nch) {
+    const int cls = blockIdx.y, py = cls >> 1, px = cls & 1, ntx = 3 - px, ntk = c2_s2d_ntaps(cls);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= c2_s2d_floats(cls, CC, nch, NB)) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
+    const int KS = c2_ksteps(ntk, CC), chunk = kk / KS, ks = kk % KS;
+    const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = nb * 16 + (lane & 15);
+    float v = 0.f;
+    if (tap < ntk && ci < Cin && co < Cout) {
+        const int ty = c2_s2_tap(py + tap / ntx, py), tx = c2_s2_tap(px + tap % ntx, px);
+        v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
+    }
+    wp[c2_s2d_prefix(cls, CC, nch, NB) + idx] = v;
+}
 // the forward images of a list of layers in one launch (blockIdx.y = list entry): the 2-D extractor packs its layers once per
 // step (round 3: one pack launch, plus one layout copy of a channels-last weight, in front of every convolution)
 struct Pack2dItem {
@@ -111,10 +138,14 @@ __global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(Pack2dBatch pb) 
 // padding stays zero: only elements inside the image are transformed.
 // BST (with STATS): the output is the complete gradient w.r.t. relu(bn(raw)) of the block in front; what goes to the slots is that
 // block's backward statistics, like the 3-D input-gradient epilogues (conv3d.hip) -- its reduce pass (mvs_bn_bwd_reduce_slots) goes.
-template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false, bool XF = false, bool BST = false>
+// S2D (round 6): the input gradient of a 5x5 stride-2 layer, all four output-parity classes in ONE launch (class = blockIdx.z): a 3x3
+// stride-1 pass over gy on the coarse grid per class with the class's COMPACTED tap list (conv2d_pack_s2d_kernel); a.py / a.px / a.wp are
+// replaced by the class's.  Rounds 2-5 issued four pack launches + four passes of nine taps each.
+template <int KS, int S, int CC, int NB, bool PP = false, bool STATS = false, bool XF = false, bool BST = false, bool S2D = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     using G = Geo2<KS, S>;
     static_assert(!PP || (KS == 3 && S == 1 && NB == 1), "pixel pairs: 3x3 stride 1, one column tile");
+    static_assert(!S2D || (KS == 3 && S == 1 && !PP && !STATS && !XF && !BST), "S2D: the plain 3x3 stride-1 pass");
     constexpr int NTK = PP ? 12 : G::NT;                 // taps the K dimension walks
     constexpr int MBW = PP ? 2 : 4;                      // m-blocks per wave: a block is 16 pixel PAIRS of a row with PP
     constexpr int CCP = CC + 4, CQ = CC / 4, NR = G::RH * G::RW, KSTEPS = (NTK * CC + 15) / 16;
@@ -127,6 +158,18 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     const int n = t;
     const int oy0 = th * G::TH, ox0 = tw * G::TW;
     const int nb0 = blockIdx.y * NB;
+    int ksteps = KSTEPS, py = a.py, px = a.px;
+    const float* __restrict__ wp = a.wp;
+    if constexpr (S2D) {
+        const int cls = blockIdx.z, nch = (a.Cin + CC - 1) / CC;
+        py = cls >> 1; px = cls & 1;
+        if (oy0 * 2 + py >= a.YH || ox0 * 2 + px >= a.YW) return;           // the odd classes have one grid row / column fewer
+        const int ntx = 3 - px, ntk = c2_s2d_ntaps(cls);
+        ksteps = c2_ksteps(ntk, CC);
+        wp += c2_s2d_prefix(cls, CC, nch, a.nb_total);
+        for (int i = tid; i < (int)(sizeof(tapoff) / sizeof(int)); i += 256)
+            tapoff[i] = i < ntk ? ((py + i / ntx) * G::RW + px + i % ntx) * CCP : 0;
+    } else
     for (int i = tid; i < (int)(sizeof(tapoff) / sizeof(int)); i += 256)   // padded k-steps read a valid location (zero weights)
         tapoff[i] = i < NTK ? (PP ? ((i / 4) * G::RW + i % 4) * CCP : ((i / KS) * G::RW + i % KS) * CCP) : 0;
     // wave -> output rows 2w, 2w+1; m-block mb: row 2w + (mb >> 1), columns 16 (mb & 1) + l15
@@ -200,18 +243,18 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
         // weight fragments (global / L2) run two k-steps ahead of the MFMAs that consume them
         float4 bq[2][NB];
         auto load_b = [&](int ks, float4 (&dst)[NB]) {
-            const int kc = ks < KSTEPS ? ks : KSTEPS - 1;
+            const int kc = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                dst[nb] = *reinterpret_cast<const float4*>(a.wp + (((size_t)(chunk * KSTEPS + kc) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
+                dst[nb] = *reinterpret_cast<const float4*>(wp + (((size_t)(chunk * ksteps + kc) * a.nb_total + nb0 + nb) * 64 + lane) * 4);
         };
         load_b(0, bq[0]);
         load_b(1, bq[1]);
-        for (int ks0 = 0; ks0 < KSTEPS; ks0 += 2) {
+        for (int ks0 = 0; ks0 < ksteps; ks0 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ks = ks0 + u;
-                if (ks < KSTEPS) {
+                if (ks < ksteps) {
                     const int kflat = 16 * ks + 4 * g;
                     const int aoff = tapoff[kflat / CC] + kflat % CC;
                     float4 af[MBW];
@@ -261,8 +304,8 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
         for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
-                const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + a.px;
+                const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + py;
+                const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + px;
                 const int co0 = PP ? 4 * (g & 1) : (nb0 + nb) * 16 + 4 * g;
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (oy < a.YH && ox < a.YW && co0 < a.Cout) {
@@ -275,8 +318,8 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(Conv2dArgs a) {
     }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
-        const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + a.py;
-        const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + a.px;
+        const int oy = (oy0 + 2 * wave + (PP ? mb : (mb >> 1))) * a.os + py;
+        const int ox = (ox0 + (PP ? 2 * l15 + (g >> 1) : 16 * (mb & 1) + l15)) * a.os + px;
         if (oy >= a.YH || ox >= a.YW) continue;
         float* __restrict__ o = a.y + (((size_t)n * a.YH + oy) * a.YW + ox) * a.Cout;
 #pragma unroll
@@ -843,7 +886,7 @@ static const int C2_WGRAD_GROUPS = 1024;  // partial images the workspace holds
 int g_conv2d_wgrad_groups = 256;          // tuning knob "wgrad2d_groups" (<= 1024): persistent workgroups of the weight gradient (256 = one per CU;
                                           // more let a CU overlap one workgroup's tile staging with another's MFMA loop -- not yet measured)
 int g_conv2d_pp = 1;        // tuning knob "conv2d_pp": 3x3 stride-1 layers with <= 8 output channels as pixel-pair GEMMs (conv2d_igemm_kernel<.., PP>)
-int g_conv2d_s2_mfma = 1;   // tuning knob "conv2d_s2_mfma": stride-2 input gradient as four parity-class MFMA passes (0: direct VALU form)
+int g_conv2d_s2_mfma = 2;   // tuning knob "conv2d_s2_mfma": stride-2 input gradient as ONE four-class MFMA pass with compacted taps (2, round 6), four parity-class passes (1), direct VALU form (0)
 
 static bool c2_shape_ok(int ks, int stride) { return (ks == 3 && stride == 1) || (ks == 5 && stride == 2); }
 static int c2_cc(int ks, int cin) { return ks == 5 ? 8 : (cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32))); }
@@ -1055,6 +1098,26 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
     if (rc) return rc;
     MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv2d_dgrad: null pointer argument");
     if (stride == 1) return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream);
+    if (g_conv2d_s2_mfma == 2) {
+        // round 6: the four parity classes in ONE pass (class = blockIdx.z) behind ONE pack launch, compacted taps (25 tap slices, not 36)
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        const int cc = c2_cc(3, Cout), nch = mvs_cdiv(Cout, cc), nbt = mvs_cdiv(Cin, 16);
+        MVS_REQUIRE(nbt <= 2, MVS_ERR_UNSUPPORTED, "conv2d_dgrad: the 5x5 stride-2 layers have <= 32 input channels");
+        Conv2dArgs a = {};
+        a.x = gy; a.bias = nullptr; a.y = gx; a.N = N; a.Hi = Ho; a.Wi = Wo; a.Cin = Cout; a.Cout = Cin;
+        a.os = 2; a.py = 0; a.px = 0; a.YH = H; a.YW = W;
+        a.Ho = mvs_cdiv(H, 2); a.Wo = mvs_cdiv(W, 2);                               // grid points of the even class (the largest)
+        a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32); a.nb_total = nbt;
+        a.wp = ws;
+        MVS_LAUNCH(conv2d_pack_s2d_kernel, dim3(mvs_cdiv(c2_s2d_floats(0, cc, nch, nbt), 256), 4), dim3(256), 0, stream, w, ws, cc, Cout, Cin, nbt, nch);
+        dim3 grid(N * a.nth * a.ntw, 1, 4);
+#define MVS_S2D_CASE(CCV)                                                                                                           \
+    if (nbt == 1) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, CCV, 1, false, false, false, false, true>), grid, dim3(256), 0, stream, a);  \
+    else MVS_LAUNCH((conv2d_igemm_kernel<3, 1, CCV, 2, false, false, false, false, true>), grid, dim3(256), 0, stream, a);
+        if (cc == 8) { MVS_S2D_CASE(8) } else if (cc == 16) { MVS_S2D_CASE(16) } else if (cc == 32) { MVS_S2D_CASE(32) } else { MVS_S2D_CASE(4) }
+#undef MVS_S2D_CASE
+        return mvs_check_launch("conv2d_dgrad_s2_one_pass");
+    }
     if (g_conv2d_s2_mfma) {
         // four parity classes, each a 3x3 stride-1 pass over gy on the coarse grid with its own (partly empty) weight image
         const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;

@@ -798,13 +798,14 @@ def test_conv2d_family(emul_lib, cin, cout, ks, stride, hw):
             emul_lib.call("mvs_set_tuning", b"conv2d_pp", 1)
         assert float((y0 - yr).abs().max()) < 2e-4 and float((gx0 - xr.grad).abs().max()) < 3e-4
         assert float((y0 - y.detach()).abs().max()) < 2e-5      # same products, another summation order
-    if stride == 2:   # the direct form of the stride-2 input gradient (tuning knob "2" = 0) agrees with the parity-class MFMA passes
-        emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 0)
-        try:
-            gx = ops.conv2d_dgrad(gy, w, tuple(x.shape), 2)
-        finally:
-            emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 1)
-        assert float((gx - xr.grad).abs().max()) < 3e-4
+    if stride == 2:   # the other forms of the stride-2 input gradient: direct VALU (0), four parity-class passes (1); default: ONE pass, compacted taps (2)
+        for form in (0, 1):
+            emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", form)
+            try:
+                gx = ops.conv2d_dgrad(gy, w, tuple(x.shape), 2)
+            finally:
+                emul_lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 2)
+            assert float((gx - xr.grad).abs().max()) < 3e-4, form
 
 
 @pytest.mark.skipif(os.environ.get("MVS_EMUL_FULL") != "1", reason="45 s of emulation; set MVS_EMUL_FULL=1 (the GPU version is test_gpu_parity.py::test_featurenet_hip_convs_vs_stock; test_conv2d_family runs by default)")

@@ -1068,6 +1068,18 @@ def test_conv2d_family_vs_torch(dev, cin, cout, ks, stride, hw):
     assert float((xa.grad.cpu() - xr.grad).abs().max()) < 5e-4
     assert float((wa.grad.cpu() - wr.grad).abs().max()) < 1e-3 * max(1.0, float(wr.grad.abs().max()))
     assert float((ba.grad.cpu() - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
+    if stride == 2:
+        # the input gradient above ran as ONE four-class pass with compacted taps (knob conv2d_s2_mfma = 2, round 6); the four
+        # separate parity-class passes (1) and the direct VALU form (0) compute the same sums in other orders
+        from mvs_amd import _lib
+        lib = _lib.get()
+        for form in (1, 0):
+            lib.call("mvs_set_tuning", b"conv2d_s2_mfma", form)
+            try:
+                gx = ops.conv2d_dgrad(gy.to(dev), w.to(dev), tuple(x.shape), 2)
+            finally:
+                lib.call("mvs_set_tuning", b"conv2d_s2_mfma", 2)
+            assert float((gx.cpu() - xr.grad).abs().max()) < 5e-4, form
 
 
 def test_featurenet_hip_convs_vs_stock(dev):
