@@ -43,6 +43,13 @@ static __device__ __forceinline__ int mvs_quad_bcast_i(int v, int s) {
 #define MVS_FFSLL(m) __ffsll((unsigned long long)(m))
 #define MVS_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define MVS_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)   // a value known to be the same in every lane -> SGPR
+// element i of a wave-uniform read-only float table through the SCALAR cache (s_load_dword into an SGPR, lgkmcnt): a load through a plain
+// pointer is a VECTOR load in every kernel that also stores (nothing is provably read-only for hipcc) and sits in the in-order vmcnt queue
+typedef const __attribute__((address_space(4))) float mvs_const_float;
+#define MVS_SCALAR_LD(ptr, i) (((mvs_const_float*)(ptr))[(i)])
+// "this value is produced HERE": stops loop-invariant code motion from hoisting what is computed from it (a 64-bit address needed on
+// a rare path would otherwise be formed once in front of the loop and live -- or be spilled -- across it)
+#define MVS_OPAQUE_U(x) asm volatile("" : "+v"(x))
 #define MVS_MFMA_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 // cbsz = 4: the A operand of block `abid` (lanes 4*abid .. 4*abid+3) is broadcast to all 16 blocks
 #define MVS_MFMA_4x4x1_BC(a, b, c, abid) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (abid), 0)

@@ -572,13 +572,15 @@ template <int V> struct PwBlock {
 };
 
 // The pixel groups (LPP consecutive lanes) whose `want` is set add their accumulators to the wave's window, one group
-// per iteration of a wave-uniform loop.  win / gp already include the lane's channel offset.  Within an iteration all
+// per iteration of a wave-uniform loop.  win already includes the lane's channel offset (gbase / foff: see below).  Within an iteration all
 // LDS reads of the block (4 taps x V float4) are issued before the first add: ONE LDS round trip per flush (taps handled
 // one after the other cost eight dependent round trips, ~1000 cycles).  A tap outside the window (or all of them when
 // the window is unusable) goes to global memory with atomics; a tap outside the image is dropped (zero padding).
 template <int C, int V, int CK, int LPP>
 __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlock<V>& blk, int H, int W,
-                                                float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gp) {
+                                                float* __restrict__ win, const Win& w, bool use_win, float* __restrict__ gbase, unsigned foff) {
+    // (gbase: the view's gradient map, wave-uniform; foff: the lane's batch + channel offset.  The per-lane 64-bit pointer gbase + foff
+    //  is only formed on the rare global-atomic path: as an argument it lived in two VGPRs per view across the whole plane loop)
     unsigned long long m = MVS_BALLOT(want);
     while (m) {
         const int grp = (MVS_FFSLL(m) - 1) / LPP;
@@ -642,7 +644,9 @@ __device__ __forceinline__ void pw_flush_groups(bool want, int lane, const PwBlo
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (img[t] && !inw[t]) {
-                        float* p = gp + ((size_t)(cy + (t >> 1)) * W + cx + (t & 1)) * C;
+                        unsigned fo = foff;
+                        MVS_OPAQUE_U(fo);
+                        float* p = gbase + (size_t)fo + ((size_t)(cy + (t >> 1)) * W + cx + (t & 1)) * C;
 #pragma unroll
                         for (int k = 0; k < V; ++k) {
                             MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 0, gsrc4[t][k].x); MVS_GLOBAL_ATOMIC_ADD(p + CK * k + 1, gsrc4[t][k].y);
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     const float xf = (float)x, yf = (float)y;
     const int cq = 4 * q;
     const size_t fbase = (size_t)b * HW * C + cq;
+    const unsigned fb32 = (unsigned)fbase;           // the host checks B * H * W * C < 2^31 for this kernel
     float4 r[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) r[k] = ld4(a.ref + fbase + (size_t)pix * C + CK * k);
@@ -698,13 +703,21 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     const float two_n = live ? 2.0f * inv_n : 0.0f;  // dead lanes contribute exact zeros
     const float* __restrict__ rotb = a.rot + (size_t)b * NS_T * 9;
     const float* __restrict__ trb = a.trans + (size_t)b * NS_T * 3;
-    float rx[NS_T], ry[NS_T], rz[NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
+    // REMAT (3-4 source views at 2 waves per SIMD, round 6): the per-lane ray coefficients rx / ry / rz (12 VGPRs at 4 views) are NOT kept
+    // across the plane loop but recomputed per plane from the view's rotation, read through the scalar cache -- the same two fused
+    // multiply-adds, bit for bit.  Kept in VGPRs they were spilled, and the reload of every view's pair sat behind an `s_waitcnt
+    // vmcnt(0)` at the top of its `locate`: four scratch round trips per plane, each also draining the upstream-gradient prefetch
+    // (N = 5: 62 % of wave time parked, 1.09 ms; profiles/r06_run3_bench_c3.json).
+    constexpr bool REMAT = NS_T >= 3 && WPS >= 2;
+    float rx[REMAT ? 1 : NS_T], ry[REMAT ? 1 : NS_T], rz[REMAT ? 1 : NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
         const float* R = rotb + s * 9;
-        rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
-        ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
-        rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
+        if constexpr (!REMAT) {
+            rx[s] = fmaf(R[0], xf, fmaf(R[1], yf, R[2]));
+            ry[s] = fmaf(R[3], xf, fmaf(R[4], yf, R[5]));
+            rz[s] = fmaf(R[6], xf, fmaf(R[7], yf, R[8]));
+        }
         tx[s] = trb[s * 3]; ty[s] = trb[s * 3 + 1]; tz[s] = trb[s * 3 + 2];
     }
     float4 gr[V];
@@ -785,26 +798,39 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
             }
             // where view s samples at depth `dep`: base texel + fractions (the forward kernel's arithmetic)
             auto locate = [&](int s, float dep, int& x0, int& y0, float& wx, float& wy) {
-                const float zz = fmaf(rz[s], dep, tz[s]);
+                float rxs, rys, rzs;
+                if constexpr (REMAT) {
+                    const float* R = rotb + s * 9;
+                    rxs = fmaf(MVS_SCALAR_LD(R, 0), xf, fmaf(MVS_SCALAR_LD(R, 1), yf, MVS_SCALAR_LD(R, 2)));
+                    rys = fmaf(MVS_SCALAR_LD(R, 3), xf, fmaf(MVS_SCALAR_LD(R, 4), yf, MVS_SCALAR_LD(R, 5)));
+                    rzs = fmaf(MVS_SCALAR_LD(R, 6), xf, fmaf(MVS_SCALAR_LD(R, 7), yf, MVS_SCALAR_LD(R, 8)));
+                } else {
+                    rxs = rx[s]; rys = ry[s]; rzs = rz[s];
+                }
+                const float zz = fmaf(rzs, dep, tz[s]);
                 float iz = MVS_RCP(zz);
                 iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
-                const float ix = fmaf(fmaf(rx[s], dep, tx[s]) * iz, a.sx, a.ox);
-                const float iy = fmaf(fmaf(ry[s], dep, ty[s]) * iz, a.sy, a.oy);
+                const float ix = fmaf(fmaf(rxs, dep, tx[s]) * iz, a.sx, a.ox);
+                const float iy = fmaf(fmaf(rys, dep, ty[s]) * iz, a.sy, a.oy);
                 const float fx = floorf(ix), fy = floorf(iy);
                 wx = ix - fx; wy = iy - fy;
                 x0 = MVS_F2I(fx); y0 = MVS_F2I(fy);
             };
             // the 2x2 block with base texel (x0, y0) of view s: zero where a tap is outside the image
             auto gather = [&](int s, int x0, int y0, float4 (&o00)[V], float4 (&o01)[V], float4 (&o10)[V], float4 (&o11)[V]) {
-                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                // (wave-uniform base + a 32-bit lane offset: the loads take the SGPR-base addressing form and no 64-bit per-lane pointer
+                //  per view stays alive across the plane loop -- at 4 views those were spilled and reloaded in front of every gather)
+                const float* __restrict__ sb = a.src[s];
+                const int o = (int)fb32 + (y0 * a.W + x0) * C;
                 if (x0 >= 0 && x0 + 1 < a.W && y0 >= 0 && y0 + 1 < a.H) {   // common case: all four taps inside the image
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
-                        o00[k] = ld4(f + CK * k); o01[k] = ld4(f + C + CK * k);
-                        o10[k] = ld4(f + a.W * C + CK * k); o11[k] = ld4(f + a.W * C + C + CK * k);
+                        o00[k] = ld4(sb + (unsigned)(o + CK * k)); o01[k] = ld4(sb + (unsigned)(o + C + CK * k));
+                        o10[k] = ld4(sb + (unsigned)(o + a.W * C + CK * k)); o11[k] = ld4(sb + (unsigned)(o + a.W * C + C + CK * k));
                     }
                     return;
                 }
+                const float* __restrict__ f = sb + (long)o;
                 const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
                 const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
 #pragma unroll
@@ -832,6 +858,9 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
             // own LDS row and read back one plane ahead: a global load here (hipcc emits a VECTOR load, the kernel also stores) sits
             // in the same in-order queue as the upstream-gradient requests, and waiting for it drains them.  Per-pixel hypotheses:
             // a vector load per plane.
+            // (the wave index as a SCALAR: with the row address derived from threadIdx the compiler kept it in a vector register, spilled
+            //  it at 4 views and reloaded it from scratch in front of every plane's read -- behind an s_waitcnt vmcnt(0))
+            const int wvu = MVS_UNIFORM_I(wv);
             auto depth_of = [&](int d) __attribute__((always_inline)) -> float {
                 if constexpr (!PPD) {
                     if (a.per_pixel) return a.depth[((size_t)b * a.D + d) * HW + pix];
@@ -839,10 +868,10 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 const int i = d - ds;
                 if ((i & 63) == 0) {                 // wave-uniform; a wave's DS operations execute in order
                     MVS_WAVE_SYNC();
-                    if (d + lane < de) s_dep[wv][lane] = a.depth[b * a.D + d + lane];
+                    if (d + lane < de) s_dep[wvu][lane] = a.depth[b * a.D + d + lane];
                     MVS_WAVE_SYNC();
                 }
-                return s_dep[wv][i & 63];
+                return s_dep[wvu][i & 63];
             };
             float dep_next = depth_of(ds);
             // PFL: sample position of the plane about to be processed + the staged block of the lanes that enter a new one there
@@ -875,7 +904,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                         for (int s = 0; s < NS_T; ++s)
                             if (MVS_ANY(chg[s]))
                                 pw_flush_groups<C, V, CK, LPP>(chg[s] && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s], fb32);
 #pragma unroll
                         for (int s = 0; s < NS_T; ++s) {
 #pragma unroll
@@ -925,7 +954,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                             for (int s = 0; s < NS_T; ++s)
                                 if (MVS_ANY(chg[s]))
                                     pw_flush_groups<C, V, CK, LPP>(chg[s] && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                                   wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                                                                   wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s], fb32);
 #pragma unroll
                             for (int s = 0; s < NS_T; ++s) {
                                 if (chg[s]) {
@@ -950,7 +979,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                                 // the tap values): the L2 round trip of the gather overlaps the LDS round trips of the flush
                                 if (chg) gather(s, x0, y0, blk[s].t00, blk[s].t01, blk[s].t10, blk[s].t11);
                                 pw_flush_groups<C, V, CK, LPP>(chg && live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W,
-                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s] + fbase);
+                                                               wwin + s * VIEW_FLOATS + cq, w[s], use[s], a.gsrc[s], fb32);
                                 if (chg) {
                                     blk[s].cx = x0; blk[s].cy = y0;
 #pragma unroll
@@ -1044,7 +1073,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
 #pragma unroll
             for (int s = 0; s < NS_T; ++s)
                 pw_flush_groups<C, V, CK, LPP>(live && blk[s].cx != -0x40000000, lane, blk[s], a.H, a.W, wwin + s * VIEW_FLOATS + cq,
-                                               w[s], use[s], a.gsrc[s] + fbase);
+                                               w[s], use[s], a.gsrc[s], fb32);
         }
         // ---- write the segment out: the four waves' windows summed on the fly, coalesced global atomics ----
         __syncthreads();
@@ -1274,10 +1303,12 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     using Cfg = PwCfg<C, CPT>;
     a.tiles_x = mvs_cdiv(a.W, 2 * Cfg::BW);
     a.tiles_y = mvs_cdiv(a.H, 2 * Cfg::BH);
-    // depth slabs: >= ~2048 workgroups (2 resident per CU, several rounds), each >= 16 planes: every extra slab
+    // depth slabs: >= ~1280 workgroups (2 resident per CU, 2.5 rounds), each >= 16 planes: every extra slab
     // re-gathers the blocks, writes its windows out once more and adds one grad_ref atomic per pixel and channel
+    // (round 6, config 2 / 3 = 640 tiles: 2 slabs of 96 planes instead of 4 of 48 -- step 4.782 -> 4.761 ms, 6.32 -> 6.27 ms; ONE slab of 192
+    //  planes is slower again: 4.777 -> 4.789, 6.20 -> 6.32: profiles/r06_run3_bench_ab.json)
     const int tiles = a.tiles_x * a.tiles_y * a.B;
-    int nslab = mvs_cdiv(2048, tiles);
+    int nslab = mvs_cdiv(1280, tiles);
     if (nslab > a.D / 16) nslab = a.D / 16;
     if (nslab < 1) nslab = 1;
     a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
@@ -1294,7 +1325,7 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
 
 template <int C>
 static int launch_bwd(SweepArgs& a, hipStream_t st) {
-    if (g_sweep_bwd_variant != 1 && a.NS <= 4) {
+    if (g_sweep_bwd_variant != 1 && a.NS <= 4 && (long long)a.B * a.H * a.W * C < (1LL << 31)) {   // (32-bit feature-map offsets in the per-wave-window kernel)
         // 1-2 views: 2 waves per SIMD with the upstream gradient requested two planes ahead (knob "bwd_gd" = 0: 3 waves per SIMD, one
         // rotating register set); 3-4 views: 2 waves per SIMD (knob "bwd_pf" = 2: ONE wave per SIMD, 512 registers, nothing spills)
         const bool gd2 = g_sweep_bwd_gd == 2;

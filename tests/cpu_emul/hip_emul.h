@@ -180,6 +180,8 @@ static inline void emul_wave_sync() {
 #define MVS_FFSLL(m) __builtin_ffsll((long long)(m))
 #define MVS_WAVE_SYNC() emul_wave_sync()
 #define MVS_UNIFORM_I(x) (x)
+#define MVS_SCALAR_LD(ptr, i) ((ptr)[(i)])
+#define MVS_OPAQUE_U(x) ((void)0)
 #define MVS_QUAD_BCAST_I(v, s) __shfl((int)(v), (emul::lane & ~3) | (s))
 #define MVS_QUAD_BCAST_F(v, s) __shfl((float)(v), (emul::lane & ~3) | (s))
 #define MVS_SCHED_FENCE() ((void)0)
