@@ -21,6 +21,7 @@
 #include <string.h>
 #include "mvs_rt.h"
 
+#include <type_traits>
 #include "plane_sweep_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -557,6 +558,10 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_bwd_kernel(SweepArgs
 //    atomics (64 consecutive floats per wave instruction: 330 G/s against 79 G/s for the 4-float pattern of a
 //    per-thread flush), grad_ref likewise goes through LDS so that a wave instruction covers whole 128-byte texels.
 // ------------------------------------------------------------------------------------------------
+// component c (a constant after unrolling) of a float4 held in registers
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float& f4r(float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
 template <int C, int CPT> struct PwCfg {
     static constexpr int LPP = C / CPT;             // lanes per pixel
     static constexpr int PPW = 64 / LPP;            // pixels per wave, as a BW x BH block
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
     // multiply-adds, bit for bit.  Kept in VGPRs they were spilled, and the reload of every view's pair sat behind an `s_waitcnt
     // vmcnt(0)` at the top of its `locate`: four scratch round trips per plane, each also draining the upstream-gradient prefetch
     // (N = 5: 62 % of wave time parked, 1.09 ms; profiles/r06_run3_bench_c3.json).
-    constexpr bool REMAT = NS_T >= 3 && WPS >= 2;
+    constexpr bool REMAT = NS_T >= 4 && WPS >= 2 && GD == 2;
     float rx[REMAT ? 1 : NS_T], ry[REMAT ? 1 : NS_T], rz[REMAT ? 1 : NS_T], tx[NS_T], ty[NS_T], tz[NS_T];
 #pragma unroll
     for (int s = 0; s < NS_T; ++s) {
@@ -801,9 +806,11 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 float rxs, rys, rzs;
                 if constexpr (REMAT) {
                     const float* R = rotb + s * 9;
-                    rxs = fmaf(MVS_SCALAR_LD(R, 0), xf, fmaf(MVS_SCALAR_LD(R, 1), yf, MVS_SCALAR_LD(R, 2)));
-                    rys = fmaf(MVS_SCALAR_LD(R, 3), xf, fmaf(MVS_SCALAR_LD(R, 4), yf, MVS_SCALAR_LD(R, 5)));
-                    rzs = fmaf(MVS_SCALAR_LD(R, 6), xf, fmaf(MVS_SCALAR_LD(R, 7), yf, MVS_SCALAR_LD(R, 8)));
+                    float xo = xf, yo = yf;          // "produced here": without this the six multiply-adds are hoisted back out of the loop
+                    MVS_OPAQUE_U(xo); MVS_OPAQUE_U(yo);
+                    rxs = fmaf(MVS_SCALAR_LD(R, 0), xo, fmaf(MVS_SCALAR_LD(R, 1), yo, MVS_SCALAR_LD(R, 2)));
+                    rys = fmaf(MVS_SCALAR_LD(R, 3), xo, fmaf(MVS_SCALAR_LD(R, 4), yo, MVS_SCALAR_LD(R, 5)));
+                    rzs = fmaf(MVS_SCALAR_LD(R, 6), xo, fmaf(MVS_SCALAR_LD(R, 7), yo, MVS_SCALAR_LD(R, 8)));
                 } else {
                     rxs = rx[s]; rys = ry[s]; rzs = rz[s];
                 }
@@ -887,7 +894,21 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 if (ds + 1 < de) dep_next = depth_of(ds + 1);
             }
             // one plane: gu = the plane's upstream gradient
-            auto plane = [&](const int d, const float4 (&gu)[V]) __attribute__((always_inline)) {
+            // the upstream gradient of the NEXT group of planes.  Where it is requested matters more than how far ahead: vector loads return
+            // IN ORDER, so the wait for a re-gathered block (most planes have one) also waits for every request in front of it.  Requested
+            // at the top of the group (knob "bwd_gpf" = 0, the default) the prefetch sits in front of this plane's gathers; requested AFTER
+            // the gathers have been waited for (1, round 6) it has the arithmetic half of the plane as cover before the next plane's gathers
+            // queue up behind it.  Measured (profiles/r06_run6_*): the late form is SLOWER -- config-2 step 4.811 -> 4.843 ms, config 3
+            // 5.928 -> 5.988 -- so the exposed round trip is not the prefetch's.  Kept as a knob.
+            auto request_next_group = [&](const int d) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const float* __restrict__ gnx = gptr + (size_t)(min(d + G + j, de - 1) - ds) * gstep;   // clamped: always a valid plane
+#pragma unroll
+                    for (int k = 0; k < V; ++k) gn[j][k] = ld4(gnx + CK * k);
+                }
+            };
+            auto plane = [&](const int d, const float4 (&gu)[V], auto first) __attribute__((always_inline)) {
                 float fwx[NS_T], fwy[NS_T];
                 if constexpr (PFL) {
                     // (a) lanes whose sample point left their block: flush the accumulators, take over the staged block (requested
@@ -996,6 +1017,12 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                     }
                 }
                 MVS_SCHED_FENCE();
+                if constexpr (decltype(first)::value) {
+                    if (a.gpf_late) {
+                        request_next_group(d);
+                        MVS_SCHED_FENCE();
+                    }
+                }
                 // phase 2, one float4 of channels at a time (keeps the live temporaries to one chunk): bilinear samples of all
                 // views, their mean, then the gradients of the samples into the register accumulators.  The upstream gradient of
                 // the NEXT plane is requested as soon as this plane's chunk has been consumed (no second buffer).
@@ -1006,6 +1033,57 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                     const float ex = 1.0f - wx, ey = 1.0f - wy;
                     wt[s][0] = ey * ex; wt[s][1] = ey * wx; wt[s][2] = wy * ex; wt[s][3] = wy * wx;
                 }
+                if constexpr (NS_T >= 3) {
+                    static_assert(NS_T < 3 || !WARP_ONLY, "plain homo_warping has one source view");
+                    // 3-4 views: the same arithmetic TWO channels at a time (round 6) -- per component nothing changes (same operations in the
+                    // same order: bit-identical), but only 2 x NS_T sample values are alive between the sampling and the gradient half
+                    // instead of 4 x NS_T: the 8 registers that decide whether the plane loop of the 4-view kernel spills
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+#pragma unroll
+                        for (int h0 = 0; h0 < 4; h0 += 2) {
+                            float S[2], v[NS_T][2], gsv[2], Smv[2];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float rc = f4c(r[k], h0 + j);
+                                S[j] = MS_ALIAS ? rc * rc : rc;
+                            }
+#pragma unroll
+                            for (int s = 0; s < NS_T; ++s) {
+                                const PwBlock<V>& B = blk[s];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int c = h0 + j;
+                                    v[s][j] = fmaf(f4c(B.t11[k], c), wt[s][3], fmaf(f4c(B.t10[k], c), wt[s][2], fmaf(f4c(B.t01[k], c), wt[s][1], f4c(B.t00[k], c) * wt[s][0])));
+                                    S[j] += v[s][j];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int c = h0 + j;
+                                const float rc = f4c(r[k], c);
+                                gsv[j] = f4c(gu[k], c) * two_n;          // g * 2/N (0 on dead lanes)
+                                Smv[j] = S[j] * inv_n;
+                                if (MS_ALIAS) f4r(gr[k], c) += gsv[j] * rc * (1.0f - 2.0f * Smv[j]);
+                                else f4r(gr[k], c) += gsv[j] * (rc - Smv[j]);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NS_T; ++s) {
+                                PwBlock<V>& B = blk[s];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int c = h0 + j;
+                                    const float gv = gsv[j] * (v[s][j] - Smv[j]);
+                                    f4r(B.g00[k], c) = fmaf(gv, wt[s][0], f4c(B.g00[k], c));
+                                    f4r(B.g01[k], c) = fmaf(gv, wt[s][1], f4c(B.g01[k], c));
+                                    f4r(B.g10[k], c) = fmaf(gv, wt[s][2], f4c(B.g10[k], c));
+                                    f4r(B.g11[k], c) = fmaf(gv, wt[s][3], f4c(B.g11[k], c));
+                                }
+                            }
+                            MVS_SCHED_FENCE();
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     float4 S = WARP_ONLY ? z4 : (MS_ALIAS ? make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w) : r[k]);
@@ -1050,19 +1128,15 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                     }
                     MVS_SCHED_FENCE();
                 }
+                }
             };
 #pragma clang loop unroll(disable)
             for (int d = ds; d < de; d += G) {
-#pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const float* __restrict__ gnx = gptr + (size_t)(min(d + G + j, de - 1) - ds) * gstep;   // clamped: always a valid plane
-#pragma unroll
-                    for (int k = 0; k < V; ++k) gn[j][k] = ld4(gnx + CK * k);
-                }
+                if (!a.gpf_late) request_next_group(d);
                 MVS_SCHED_FENCE();
-                plane(d, gc[0]);
+                plane(d, gc[0], std::true_type());
                 if constexpr (G == 2) {
-                    if (d + 1 < de) plane(d + 1, gc[1]);
+                    if (d + 1 < de) plane(d + 1, gc[1], std::false_type());
                 }
 #pragma unroll
                 for (int j = 0; j < G; ++j)
@@ -1168,6 +1242,8 @@ static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 
 static int g_sweep_xcd = 0;           // knob "sweep_xcd": XCD-compact workgroup order of the cached forward and the per-wave-window backward
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
+static int g_sweep_bwd_gd34 = 0;      // knob "bwd_gd34": 3-4 source views with the upstream gradient requested two planes ahead (as 1-2 views run), 2 waves/SIMD
+static int g_sweep_bwd_gpf = 0;       // knob "bwd_gpf": where the per-wave-window backward requests the next planes' upstream gradient: 0 top of the group, 1 after the plane's gathers
 int g_sweep_bwd_nowin = 0;            // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
 int g_sweep_bwd_dslab = 0;            // knob "bwd_dslab": planes per workgroup of the per-wave-window backward, 0 = auto
 // Measurement knobs (A/B runs of tools/bench_kernels.py and the tests).  Full-string keys: an unknown or misspelt key
@@ -1179,7 +1255,7 @@ static const MvsKnob* mvs_find_knob(const char* key) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"k8", &g_conv_c8, 0, 15},             {"cout1_d4", &g_conv_cout1_d4, 0, 3}, {"bf16_dp", &g_conv_bf16_dp, 0, 1}, {"conv2d_pp", &g_conv2d_pp, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20}, {"wgrad2d_batch", &g_conv2d_wgrad_batch_groups, 1, 4096},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 2},
         {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1}, {"conv_pers", &g_conv_pers, 0, 1}, {"conv_pers_min", &g_conv_pers_min_wgs, 0, 1 << 30}, {"conv_pers_groups", &g_conv_pers_groups, 0, 4096}, {"conv_pers_nw", &g_conv_pers_nw, 4, 8}, {"wgrad_pers", &g_conv_wgrad_pers, 0, 1}, {"wgrad_small", &g_conv_wgrad_small, 0, 3}, {"wgrad_groups", &g_conv_wgrad_groups, 1, 768}, {"wgrad8_groups", &g_conv_wgrad8_groups, 1, 512}, {"wgrad8_gs", &g_conv_wgrad8_gs, 0, 2}, {"wgrad8_nch", &g_conv_wgrad8_nch, 1, 2}, {"cout1_h4", &g_conv_cout1_h4, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"bwd_gd34", &g_sweep_bwd_gd34, 0, 1}, {"bwd_gpf", &g_sweep_bwd_gpf, 0, 1}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
     };
     for (const MvsKnob& k : knobs)
         if (strcmp(key, k.name) == 0) return &k;
@@ -1313,6 +1389,7 @@ static int launch_bwd_pw(SweepArgs& a, hipStream_t st) {
     if (nslab < 1) nslab = 1;
     a.dslab = g_sweep_bwd_dslab > 0 ? g_sweep_bwd_dslab : mvs_cdiv(a.D, nslab);
     a.no_window = g_sweep_bwd_nowin;
+    a.gpf_late = g_sweep_bwd_gpf;
     a.xcd = g_sweep_xcd;
     dim3 grid(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B), block(256);
     if (a.warp_only) {
@@ -1335,8 +1412,8 @@ static int launch_bwd(SweepArgs& a, hipStream_t st) {
         }
         if (a.NS == 1) return gd2 ? launch_bwd_pw<C, 1, 2, 2>(a, st) : launch_bwd_pw<C, 1, 0, 3>(a, st);
         if (a.NS == 2) return gd2 ? launch_bwd_pw<C, 2, 2, 2>(a, st) : launch_bwd_pw<C, 2, 0, 3>(a, st);
-        if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 2, 1>(a, st) : launch_bwd_pw<C, 3, 0, 2>(a, st);
-        return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 4, 2, 1>(a, st) : launch_bwd_pw<C, 4, 0, 2>(a, st);
+        if (a.NS == 3) return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 3, 2, 1>(a, st) : (g_sweep_bwd_gd34 ? launch_bwd_pw<C, 3, 2, 2>(a, st) : launch_bwd_pw<C, 3, 0, 2>(a, st));
+        return g_sweep_bwd_pf == 2 ? launch_bwd_pw<C, 4, 2, 1>(a, st) : (g_sweep_bwd_gd34 ? launch_bwd_pw<C, 4, 2, 2>(a, st) : launch_bwd_pw<C, 4, 0, 2>(a, st));
     }
     // more than four source views (or knob "sweep_bwd" = 1): view pairs per workgroup, LDS-atomic windows
     a.tiles_x = mvs_cdiv(a.W, Tile<C>::TW);

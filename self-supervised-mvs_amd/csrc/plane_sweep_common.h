@@ -21,6 +21,7 @@ struct SweepArgs {
     int tiles_x, tiles_y;
     int tile_w;      // cached forward kernel: pixels per tile row (tile = tile_w x PPB/tile_w)
     int no_window;   // test knob "bwd_nowin": per-wave-window backward sends every flush down its global-atomic path
+    int gpf_late;    // knob "bwd_gpf": the per-wave-window backward requests the next planes' upstream gradient after the plane's gathers
     int bf16_out;    // forward: the volume is stored in bf16 (inference path)
     int nt_store;    // stream the volume with non-temporal stores (written once, read by the next kernel from HBM anyway)
     int xcd;         // knob "sweep_xcd": XCD-compact workgroup order (sweep_wg below)
