@@ -764,8 +764,10 @@ __global__ __launch_bounds__(256) MVS_WAVES_PER_SIMD(WPS) void plane_sweep_varia
                 corner_bounds(a, rotb + s * 9, trb + s * 3, cxa, cxb, cya, cyb, da, db, lox, hix, loy, hiy);
                 w[s] = make_window(a, lox, hix, loy, hiy);
                 // wave-uniform, but computed on the vector ALU: move to scalar registers (they live through the plane loop)
-                w[s].x0 = MVS_UNIFORM_I(w[s].x0); w[s].y0 = MVS_UNIFORM_I(w[s].y0);
-                w[s].w = MVS_UNIFORM_I(w[s].w); w[s].h = MVS_UNIFORM_I(w[s].h);
+                if constexpr (NS_T >= 3 || WPS >= 3) {   // (1-2 views at 2 waves/SIMD have vector registers to spare and no scalar ones: there the geometry stays where it was computed)
+                    w[s].x0 = MVS_UNIFORM_I(w[s].x0); w[s].y0 = MVS_UNIFORM_I(w[s].y0);
+                    w[s].w = MVS_UNIFORM_I(w[s].w); w[s].h = MVS_UNIFORM_I(w[s].h);
+                }
                 use[s] = (long)w[s].w * w[s].h <= WCAP;
                 fits = fits && use[s];
                 use[s] = use[s] && !a.no_window;

@@ -31,5 +31,19 @@ case "$what" in
     grep "ms/step" $out/bench_k_sync.err > $out/kernel_table_sync_mode.txt; head -${4:-70} $out/kernel_table_sync_mode.txt ;;
   line)   # short bench line of a config
     timeout 900 python bench.py --config ${3:-2} --steps 20 --warmup 5 $short > $out/bench_c${3:-2}.json 2> $out/bench_c${3:-2}.err; echo "exit $?"; summ $out/bench_c${3:-2}.json ;;
+  libab)  # bash tools/gpu_r6.sh libab <dir> [config] [reps]: two BUILDS of the library (tools/ab/lib_old.so, lib_new.so), alternating short bench lines
+    lib=self-supervised-mvs_amd/libmvs_hip.so; cp $lib /tmp/lib_keep.so
+    for i in $(seq 1 ${4:-3}); do
+      for v in old new; do
+        cp tools/ab/lib_$v.so $lib
+        timeout 600 python bench.py --config ${3:-2} --steps 20 --warmup 5 $short > $out/bench_${v}_$i.json 2> $out/bench_${v}_$i.err
+        python - $out/bench_${v}_$i.json $v <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[2], round(d["ms_per_step"], 4), {k: round(v["ms"], 4) for k, v in d.get("kernels", {}).items()})
+PY
+      done
+    done
+    cp /tmp/lib_keep.so $lib ;;
   *) echo "unknown section $what"; exit 2 ;;
 esac
