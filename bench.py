@@ -835,6 +835,9 @@ def main():
             elif spec == "feature_fused_apply":
                 def setter(on, base=_ops.FEATURE_FUSED_APPLY):
                     _ops.FEATURE_FUSED_APPLY = (not base) if on else base
+            elif spec == "feature_c_entry":
+                def setter(on, base=_ops.FEATURE_C_ENTRY):
+                    _ops.FEATURE_C_ENTRY = (not base) if on else base
             elif spec == "feature_all_own":
                 def setter(on, base=_ops.FEATURE_ALL_OWN):
                     _ops.FEATURE_ALL_OWN = (not base) if on else base

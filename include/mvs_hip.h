@@ -291,6 +291,12 @@ int mvs_conv2d_lrelu_fwd(const float* x, const float* w, const float* bias, floa
                          int Cout, int ks, int stride, float negative_slope, hipStream_t stream);
 int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
                      int stride, hipStream_t stream);
+/* mvs_conv2d_fwd with the parameter tensor channels-last in memory ([Cout][ks][ks][Cin]) when w_channels_last: read in place. */
+int mvs_conv2d_fwd_wl(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                      int ks, int stride, int w_channels_last, hipStream_t stream);
+/* mvs_conv2d_dgrad with the parameter tensor channels-last in memory ([Cout][ks][ks][Cin]) when w_channels_last: read in place. */
+int mvs_conv2d_dgrad_wl(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                        int stride, int w_channels_last, hipStream_t stream);
 int mvs_conv2d_wgrad(const float* x, const float* gy, float* gw, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
                      int stride, hipStream_t stream);
 /* Weight gradients of up to 8 layers in ONE launch + one reduction launch (the training extractor's backward pass: replaces the
@@ -322,6 +328,39 @@ int mvs_conv2d_wgrad_batch_xf(int n, const float* const* x, const float* const* 
                               float* const* gw, float* ws, const int* shapes, hipStream_t stream);
 int mvs_conv2d_wgrad_batch(int n, const float* const* x, const float* const* gy, float* const* gw, float* ws, const int* shapes,
                            hipStream_t stream);
+
+/* ---- One C call per pass of the TRAINING feature extractor (round 6; csrc/feature_pass.cpp) ------------------------------------
+ * FeatureNet (jdacs/models/mvsnet.py:17-34): n ConvBnReLU blocks (module.py:15-22; 3x3 stride 1 or 5x5 stride 2, bias-free) closed by a
+ * 3x3 stride-1 convolution with bias (mvsnet.py:32), on N channels-last images that are G statistics groups of N/G consecutive images
+ * (the views of a sample: mvsnet.py:115 calls the extractor once per view).  Replaces the 15 module calls of FeatureNet.forward and
+ * the ~30 autograd nodes of its backward pass by two calls that enqueue the same kernels in the same order:
+ * mvs_feature_fwd: one pack launch for all forward weight images (packed[i]: mvs_conv2d_workspace_floats(0, ...) floats each), then per
+ *   block mvs_conv2d_fwd_stats(_xf) -> raw[i] [N,Ho,Wo,cout] + slots[i] (zeroed by the caller, [G][nslots[i]][2][cout] fp64), and
+ *   mvs_bn_finalize_slots -> stats[i] [G][4][cout] (block i's BatchNorm + ReLU is applied by block i+1 while it stages its input);
+ *   the LAST block gets mvs_bn_relu_fwd_slots -> y_last; then the closing convolution -> out [N,Ho,Wo,close_cout] (ws_close:
+ *   mvs_conv2d_workspace_floats(0, ...)).  Running statistics are updated in place, group after group.
+ * mvs_feature_bwd: gout -> gx (or NULL), gw[n+1] (every layer's weight gradient, in the parameter's own memory layout; entry n = the
+ *   closing convolution), dgamma[i], dbeta[i].  Work space: gbuf[i] (gradient w.r.t. block i's output, like raw[i]), draw[i] (like
+ *   raw[i]), slots_b[i] (zeroed), dgrad_ws (the largest mvs_conv2d_workspace_floats(1, ...) of the chain), wgrad_ws_main / _side
+ *   (mvs_conv2d_wgrad_batch_workspace_floats of layers [0, early_from) / [early_from, n]).  0 < early_from < n and side_stream !=
+ *   main_stream: the weight gradients of layers early_from .. n are enqueued on side_stream as soon as block early_from's raw-output
+ *   gradient exists; main_stream waits for side_stream before the call returns (also on an error); *side_stream_used reports it. */
+#define MVS_FEAT_MAX_BLOCKS 7
+typedef struct MvsFeatBlock {
+    int cin, cout, ks, stride;
+    float eps, momentum;
+    int w_channels_last;
+    int h, w;                         /* spatial dims of the block's INPUT */
+} MvsFeatBlock;
+int mvs_feature_fwd(int n, const MvsFeatBlock* blocks, int N, int G, const float* x, const float* const* w, const float* const* gamma,
+                    const float* const* beta, float* const* running_mean, float* const* running_var, float* const* packed,
+                    float* const* raw, float* y_last, float* const* stats, double* const* slots, const int* nslots, const float* wclose,
+                    const float* bclose, int close_cout, int close_w_channels_last, float* ws_close, float* out, hipStream_t stream);
+int mvs_feature_bwd(int n, const MvsFeatBlock* blocks, int N, int G, const float* x, const float* const* w, const float* wclose,
+                    int close_cout, int close_w_channels_last, const float* const* raw, const float* y_last, const float* const* stats,
+                    double* const* slots_b, const int* nslots, const float* gout, float* const* gbuf, float* const* draw, float* gx,
+                    float* dgrad_ws, float* const* gw, float* wgrad_ws_main, float* wgrad_ws_side, float* const* dgamma,
+                    float* const* dbeta, int early_from, hipStream_t main_stream, hipStream_t side_stream, int* side_stream_used);
 
 /* ---- geometric-consistency filter on the path's depth maps ---------------------------------------------
  * Replaces reproject_with_depth + check_geometric_consistency (jdacs/eval.py:169-224) for ALL source views of one

@@ -22,6 +22,12 @@ class MvsUnetBlock(C.Structure):
                 ("cin", _i), ("cout", _i), ("d", _i), ("h", _i), ("w", _i)]
 
 
+class MvsFeatBlock(C.Structure):
+    """include/mvs_hip.h: one ConvBnReLU block of the training 2-D extractor (mvs_feature_fwd / mvs_feature_bwd)"""
+    _fields_ = [("cin", _i), ("cout", _i), ("ks", _i), ("stride", _i), ("eps", _fl), ("momentum", _fl), ("w_channels_last", _i),
+                ("h", _i), ("w", _i)]
+
+
 _pp = C.POINTER(C.c_void_p)   # array of device pointers
 
 # name -> (restype, argtypes); every symbol include/mvs_hip.h declares
@@ -32,6 +38,12 @@ SIGNATURES = {
                           _f, _f, _s]),
     "mvs_unet_bwd": (_i, [_i, C.POINTER(MvsUnetBlock), _i, _f, _pp, _f, _i, _pp, _pp, _pp, _pp, C.POINTER(_i), _pp, _f, _pp, _pp, _f, _pp, _pp,
                           _pp, _pp, _s, _s, _i, C.POINTER(_i)]),
+    "mvs_feature_fwd": (_i, [_i, C.POINTER(MvsFeatBlock), _i, _i, _f, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _f, _pp, _pp, C.POINTER(_i), _f, _f, _i,
+                             _i, _f, _f, _s]),
+    "mvs_feature_bwd": (_i, [_i, C.POINTER(MvsFeatBlock), _i, _i, _f, _pp, _f, _i, _i, _pp, _f, _pp, _pp, C.POINTER(_i), _f, _pp, _pp, _f, _f,
+                             _pp, _f, _f, _pp, _pp, _i, _s, _s, C.POINTER(_i)]),
+    "mvs_conv2d_dgrad_wl": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    "mvs_conv2d_fwd_wl": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     "mvs_version": (_i, []),
     "mvs_last_error": (C.c_char_p, []),
     "mvs_is_emulation": (_i, []),

@@ -56,35 +56,40 @@ MVS_HD inline int c2_s2_tap(int tp, int par) {   // tp in 0..2 = offset -1, 0, +
 // 12 taps per pixel PAIR instead of 9 per pixel, and the 16 lanes of a row store 64 consecutive bytes.
 // wcl (forward images only): the parameter tensor is channels-last in memory ([Cout][ky][kx][Cin], what
 // module.to(memory_format=torch.channels_last) makes of a Conv2d weight) instead of [Cout][Cin][ky][kx].
+// parameter element [o][i][tap] of a layer with I input channels and T taps: [O][I][T] contiguous, or [O][T][I] when the tensor is channels-last in memory
+__device__ __forceinline__ float c2_wt(const float* __restrict__ w, int o, int i, int I, int T, int tap, int wcl) {
+    return wcl ? w[((size_t)o * T + tap) * I + i] : w[((size_t)o * I + i) * T + tap];
+}
 __device__ __forceinline__ void conv2d_pack_item(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC, int Cin, int Cout,
                                                  int NB, int transposed, int cls, int pp, int wcl, int idx) {
     const int j = idx & 3, lane = (idx >> 2) & 63, nb = (idx >> 8) % NB, kk = (idx >> 8) / NB;
     const int KS = c2_ksteps(pp ? 12 : NT, CC), chunk = kk / KS, ks = kk % KS;
     const int k = 16 * ks + 4 * (lane >> 4) + j, tap = k / CC, ci = chunk * CC + k % CC, co = pp ? (lane & 7) : nb * 16 + (lane & 15);
     float v = 0.f;
+    // (input-gradient images read the parameter transposed: element [co_layer = ci][ci_layer = co][tap'] -- c2_wt below -- in either memory layout)
     if (pp) {
         const int p = (lane & 15) >> 3, ty = tap / 4, tx = tap % 4 - p;
         if (tap < 12 && tx >= 0 && tx <= 2 && ci < Cin && co < Cout) {
             const int t9 = ty * 3 + tx;
-            v = transposed ? w[((size_t)ci * Cout + co) * 9 + (8 - t9)]
+            v = transposed ? c2_wt(w, ci, co, Cout, 9, 8 - t9, wcl)
                            : (wcl ? w[((size_t)co * 9 + t9) * Cin + ci] : w[((size_t)co * Cin + ci) * 9 + t9]);
         }
     } else if (tap < NT && ci < Cin && co < Cout) {
         if (cls >= 0) {
             const int ty = c2_s2_tap(tap / 3, cls >> 1), tx = c2_s2_tap(tap % 3, cls & 1);
-            if (ty >= 0 && tx >= 0) v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
+            if (ty >= 0 && tx >= 0) v = c2_wt(w, ci, co, Cout, 25, ty * 5 + tx, wcl);
         } else {
-            v = transposed ? w[((size_t)ci * Cout + co) * NT + (NT - 1 - tap)]
+            v = transposed ? c2_wt(w, ci, co, Cout, NT, NT - 1 - tap, wcl)
                            : (wcl ? w[((size_t)co * NT + tap) * Cin + ci] : w[((size_t)co * Cin + ci) * NT + tap]);
         }
     }
     wp[idx] = v;
 }
 __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int NT, int CC,
-                                                          int Cin, int Cout, int NB, int transposed, int total, int cls, int pp) {
+                                                          int Cin, int Cout, int NB, int transposed, int total, int cls, int pp, int wcl) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    conv2d_pack_item(w, wp, NT, CC, Cin, Cout, NB, transposed, cls, pp, 0, idx);
+    conv2d_pack_item(w, wp, NT, CC, Cin, Cout, NB, transposed, cls, pp, wcl, idx);
 }
 // Round 6: the four parity-class images of a 5x5 stride-2 layer's input gradient in ONE launch (blockIdx.y = class), taps COMPACTED:
 // class (py, px) only has (3 - py) x (3 - px) non-empty taps of the 3x3 coarse-grid kernel (c2_s2_tap: offset -1 of an odd parity has
@@ -99,7 +104,7 @@ MVS_HD inline int c2_s2d_prefix(int cls, int CC, int nch, int NB) {
     return s;
 }
 __global__ __launch_bounds__(256) void conv2d_pack_s2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int CC, int Cin, int Cout,
-                                                              int NB, int nch) {
+                                                              int NB, int nch, int wcl) {
     const int cls = blockIdx.y, py = cls >> 1, px = cls & 1, ntx = 3 - px, ntk = c2_s2d_ntaps(cls);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= c2_s2d_floats(cls, CC, nch, NB)) return;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void conv2d_pack_s2d_kernel(const float* __res
     float v = 0.f;
     if (tap < ntk && ci < Cin && co < Cout) {
         const int ty = c2_s2_tap(py + tap / ntx, py), tx = c2_s2_tap(px + tap % ntx, px);
-        v = w[((size_t)ci * Cout + co) * 25 + ty * 5 + tx];     // w[co_layer = ci][ci_layer = co][ty][tx]
+        v = c2_wt(w, ci, co, Cout, 25, ty * 5 + tx, wcl);       // w[co_layer = ci][ci_layer = co][ty][tx]
     }
     wp[c2_s2d_prefix(cls, CC, nch, NB) + idx] = v;
 }
@@ -946,7 +951,7 @@ static void c2_fwd_pack_plan(int Cin, int Cout, int ks, int stride, Pack2dItem& 
 static int c2_run_igemm(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int Hi, int Wi, int Cin,
                         int Cout, int ks, int stride, int transposed, hipStream_t st, int act = 0, float slope = 0.f,
                         double* slots = nullptr, int nslots = 0, int imgs_per_group = 1, int ws_packed = 0,
-                        const float* in_stats = nullptr, const float* bn_raw = nullptr, const float* bn_stats = nullptr) {
+                        const float* in_stats = nullptr, const float* bn_raw = nullptr, const float* bn_stats = nullptr, int wcl = 0) {
     Conv2dArgs a = {};
     a.bn_raw = bn_raw; a.bn_stats = bn_stats;
     a.act = act; a.slope = slope; a.slots = slots; a.nslots = nslots; a.imgs_per_group = imgs_per_group; a.in_stats = in_stats;
@@ -960,7 +965,7 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
         // narrow layers (3 -> 8, 8 -> 8 of FeatureNet): pixel pairs fill the MFMA's 16 columns (knob "conv2d_pp")
         const int totalp = nch * c2_ksteps(12, cc) * 256;
         if (!ws_packed)
-            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1);
+            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(totalp, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, 1, transposed, totalp, -1, 1, wcl);
         a.wp = ws;
         dim3 gridp(N * a.nth * a.ntw, 1);
         if (slots && bn_raw) {
@@ -978,7 +983,7 @@ static int c2_run_igemm(const float* x, const float* w, const float* bias, float
     }
     const int total = nch * c2_ksteps(nt, cc) * a.nb_total * 256;
     if (!ws_packed)
-        MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1, 0);
+        MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total, 256)), dim3(256), 0, st, w, ws, nt, cc, Cin, Cout, a.nb_total, transposed, total, -1, 0, wcl);
     a.wp = ws;
     const int nb = a.nb_total <= 2 ? a.nb_total : 2;   // 16-wide Cout tiles per workgroup; the rest over blockIdx.y
     dim3 grid(N * a.nth * a.ntw, mvs_cdiv(a.nb_total, nb));
@@ -1007,6 +1012,15 @@ extern "C" int mvs_conv2d_fwd(const float* x, const float* w, const float* bias,
     if (rc) return rc;
     MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_fwd: null pointer argument");
     return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
+}
+// the same with the parameter tensor channels-last in memory ([Cout][ks][ks][Cin]) when w_channels_last: read in place
+extern "C" int mvs_conv2d_fwd_wl(const float* x, const float* w, const float* bias, float* y, float* ws, int N, int H, int W, int Cin, int Cout,
+                                 int ks, int stride, int w_channels_last, hipStream_t stream) {
+    int rc = c2_check("conv2d_fwd", N, H, W, Cin, Cout, ks, stride);
+    if (rc) return rc;
+    MVS_REQUIRE(x && w && y && ws, MVS_ERR_NULL, "conv2d_fwd: null pointer argument");
+    return c2_run_igemm(x, w, bias, y, ws, N, H, W, Cin, Cout, ks, stride, 0, stream, 0, 0.f, nullptr, 0, 1, 0, nullptr, nullptr, nullptr,
+                        w_channels_last ? 1 : 0);
 }
 
 // Forward without bias that also adds BatchNorm's statistics of its output into slots [G][nslots][2][Cout] (fp64, zeroed by the
@@ -1092,12 +1106,21 @@ extern "C" int mvs_conv2d_dgrad_bnstats(const float* gy, const float* w, float* 
                         bn_stats);
 }
 
+extern "C" int mvs_conv2d_dgrad_wl(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                                   int stride, int w_channels_last, hipStream_t stream);
 extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, hipStream_t stream) {
+    return mvs_conv2d_dgrad_wl(gy, w, gx, ws, N, H, W, Cin, Cout, ks, stride, 0, stream);
+}
+// the same with the parameter tensor channels-last in memory ([Cout][ks][ks][Cin]: what module.to(memory_format=torch.channels_last) makes of
+// an nn.Conv2d weight) when w_channels_last -- read in place by the weight-image pack (rounds 2-5 needed a contiguous copy per layer and step)
+extern "C" int mvs_conv2d_dgrad_wl(const float* gy, const float* w, float* gx, float* ws, int N, int H, int W, int Cin, int Cout, int ks,
+                                   int stride, int w_channels_last, hipStream_t stream) {
     int rc = c2_check("conv2d_dgrad", N, H, W, Cin, Cout, ks, stride);
     if (rc) return rc;
     MVS_REQUIRE(gy && w && gx && ws, MVS_ERR_NULL, "conv2d_dgrad: null pointer argument");
-    if (stride == 1) return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream);
+    w_channels_last = w_channels_last ? 1 : 0;
+    if (stride == 1) return c2_run_igemm(gy, w, nullptr, gx, ws, N, H, W, Cout, Cin, ks, 1, 1, stream, 0, 0.f, nullptr, 0, 1, 0, nullptr, nullptr, nullptr, w_channels_last);
     if (g_conv2d_s2_mfma == 2) {
         // round 6: the four parity classes in ONE pass (class = blockIdx.z) behind ONE pack launch, compacted taps (25 tap slices, not 36)
         const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -1109,7 +1132,7 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
         a.Ho = mvs_cdiv(H, 2); a.Wo = mvs_cdiv(W, 2);                               // grid points of the even class (the largest)
         a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32); a.nb_total = nbt;
         a.wp = ws;
-        MVS_LAUNCH(conv2d_pack_s2d_kernel, dim3(mvs_cdiv(c2_s2d_floats(0, cc, nch, nbt), 256), 4), dim3(256), 0, stream, w, ws, cc, Cout, Cin, nbt, nch);
+        MVS_LAUNCH(conv2d_pack_s2d_kernel, dim3(mvs_cdiv(c2_s2d_floats(0, cc, nch, nbt), 256), 4), dim3(256), 0, stream, w, ws, cc, Cout, Cin, nbt, nch, w_channels_last);
         dim3 grid(N * a.nth * a.ntw, 1, 4);
 #define MVS_S2D_CASE(CCV)                                                                                                           \
     if (nbt == 1) MVS_LAUNCH((conv2d_igemm_kernel<3, 1, CCV, 1, false, false, false, false, true>), grid, dim3(256), 0, stream, a);  \
@@ -1131,7 +1154,7 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
             if (a.Ho <= 0 || a.Wo <= 0) continue;
             a.nth = mvs_cdiv(a.Ho, 8); a.ntw = mvs_cdiv(a.Wo, 32); a.nb_total = nbt;
             float* wpc = ws + (size_t)cls * total_w;
-            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls, 0);
+            MVS_LAUNCH(conv2d_pack_kernel, dim3(mvs_cdiv(total_w, 256)), dim3(256), 0, stream, w, wpc, 9, cc, Cout, Cin, nbt, 0, total_w, cls, 0, w_channels_last);
             a.wp = wpc;
             MVS_REQUIRE(nbt <= 2, MVS_ERR_UNSUPPORTED, "conv2d_dgrad: the 5x5 stride-2 layers have <= 32 input channels");
             dim3 grid(N * a.nth * a.ntw, 1);
@@ -1142,6 +1165,7 @@ extern "C" int mvs_conv2d_dgrad(const float* gy, const float* w, float* gx, floa
         }
         return mvs_check_launch("conv2d_dgrad_s2_classes");
     }
+    MVS_REQUIRE(!w_channels_last, MVS_ERR_UNSUPPORTED, "conv2d_dgrad: the direct stride-2 form (knob conv2d_s2_mfma = 0) reads a contiguous weight");
     const size_t total = (size_t)N * H * W * Cin;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     MVS_LAUNCH((conv2d_dgrad_s2_kernel<5>), dim3(blocks), dim3(256), 0, stream, gy, w, gx, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cin, Cout);

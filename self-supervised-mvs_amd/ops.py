@@ -1249,6 +1249,112 @@ FEATURE_ALL_OWN = os.environ.get("MVS_FEATURE_ALL_OWN", "1") != "0"
 FEATURE_BIAS_SIDE = os.environ.get("MVS_FEATURE_BIAS_SIDE", "1") != "0"   # with FEATURE_WGRAD_EARLY: the closing convolution's bias gradient on the side stream
 
 
+# Round 6: the node's two passes as ONE C call each (csrc/feature_pass.cpp: mvs_feature_fwd / mvs_feature_bwd), in the node's default
+# configuration (every convolution through csrc/conv2d.hip, consumer-side BatchNorm, one-launch weight gradients, the wide layers' forked
+# to the side stream).  MVS_FEATURE_C_ENTRY=0 keeps the per-layer calls from Python (same kernels, same order).
+FEATURE_C_ENTRY = os.environ.get("MVS_FEATURE_C_ENTRY", "1") != "0"
+_FEATURE_PLANS = {}
+
+
+def _w_layout(w):
+    """0: contiguous [Cout][Cin][k][k]; 1: channels-last in memory; None: neither (the C entry does not serve it)"""
+    if w.is_contiguous():
+        return 0
+    return 1 if w.is_contiguous(memory_format=CL2) else None
+
+
+class _FeaturePlan:
+    """Everything about (block table, input shape, weight layouts) that is the same every step: the C block table, tensor sizes, arena offsets."""
+
+    def __init__(self, lib, cfg, xshape, groups, wshapes, wcls, fshape, fwcl):
+        n = len(cfg)
+        N, c0, h, w = xshape
+        self.n, self.N, self.G = n, N, groups
+        self.blocks = (_lib.MvsFeatBlock * n)()
+        self.out = []                      # (N, cout, Ho, Wo) of every block
+        al = lambda v: (v + 63) // 64 * 64
+        cin = c0
+        self.dgrad_floats = 0
+        for i, ((stride, padding, eps, momentum, _), ws_) in enumerate(zip(cfg, wshapes)):
+            cout, cin_w, ks, _ = ws_
+            b = self.blocks[i]
+            b.cin, b.cout, b.ks, b.stride, b.eps, b.momentum, b.w_channels_last, b.h, b.w = cin, cout, ks, stride, float(eps), float(momentum), wcls[i], h, w
+            self.dgrad_floats = max(self.dgrad_floats, int(lib.raw("mvs_conv2d_workspace_floats", 1, N, h, w, cin, cout, ks, stride)))
+            h, w = (h + 2 * padding - ks) // stride + 1, (w + 2 * padding - ks) // stride + 1
+            self.out.append((N, cout, h, w))
+            cin = cout
+        self.close_cout, self.fwcl = fshape[0], fwcl
+        self.dgrad_floats = max(self.dgrad_floats, int(lib.raw("mvs_conv2d_workspace_floats", 1, N, h, w, cin, fshape[0], 3, 1)))
+        self.out_shape = (N, fshape[0], h, w)
+        sizes = [o[0] * o[1] * o[2] * o[3] for o in self.out]
+        # forward arena (floats): raw_i ..., y_last, stats_i ..., forward weight images, the closing convolution's weight image
+        off = 0
+        self.raw_off, self.stats_off, self.packed_off = [], [], []
+        for i in range(n):
+            self.raw_off.append(off); off += al(sizes[i])
+        self.ylast_off = off; off += al(sizes[n - 1])
+        for i in range(n):
+            self.stats_off.append(off); off += al(groups * 4 * self.out[i][1])
+        for i in range(n):
+            b = self.blocks[i]
+            self.packed_off.append(off); off += al(int(lib.raw("mvs_conv2d_workspace_floats", 0, 1, 8, 8, b.cin, b.cout, b.ks, b.stride)))
+        self.wsclose_off = off; off += al(int(lib.raw("mvs_conv2d_workspace_floats", 0, 1, 8, 8, cin, fshape[0], 3, 1)))
+        self.fwd_floats = off
+        # statistic slots (doubles): forward and backward rows of every block
+        self.nslots = (C.c_int * n)(*[bn_nslots(lib, o[1]) for o in self.out])
+        soff = 0
+        self.sf_off, self.sb_off = [], []
+        for i in range(n):
+            cnt = groups * self.nslots[i] * 2 * self.out[i][1]
+            self.sf_off.append(soff); soff += cnt
+            self.sb_off.append(soff); soff += cnt
+        self.slot_doubles = soff
+        # backward work arena: gbuf_i, draw_i, the input gradients' weight image
+        off = 0
+        self.g_off, self.draw_off = [], []
+        for i in range(n):
+            self.g_off.append(off); off += al(sizes[i])
+            self.draw_off.append(off); off += al(sizes[i])
+        self.dgws_off = off; off += al(self.dgrad_floats)
+        self.bwd_floats = off
+        self.dgb_off, off = [], 0
+        for i in range(n):
+            self.dgb_off.append(off); off += 2 * self.out[i][1]
+        self.dgb_floats = off
+        # weight-gradient batches: layer j's shape row (N, H, W, Cin, Cout, ks, stride, channels-last) as mvs_feature_bwd builds them
+        rows = [[N, self.blocks[j].h, self.blocks[j].w, self.blocks[j].cin, self.blocks[j].cout, self.blocks[j].ks, self.blocks[j].stride, wcls[j]]
+                for j in range(n)]
+        rows.append([N, self.out[n - 1][2], self.out[n - 1][3], self.out[n - 1][1], fshape[0], 3, 1, fwcl])
+        self.wrows = rows
+        self.ok = n <= 7 and all(v is not None for v in wcls) and fwcl is not None and self.dgrad_floats > 0 and \
+            int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", n + 1, (C.c_int * (8 * (n + 1)))(*sum(rows, [])))) >= 0
+
+    def wgrad_floats(self, lib, lo, hi):
+        if hi <= lo:
+            return 0
+        flat = sum(self.wrows[lo:hi], [])
+        return int(lib.raw("mvs_conv2d_wgrad_batch_workspace_floats", hi - lo, (C.c_int * len(flat))(*flat)))
+
+
+def _feature_plan(lib, cfg, xshape, groups, ws_, fw):
+    wcls = tuple(_w_layout(w) for w in ws_)
+    key = (cfg, tuple(xshape), groups, tuple(tuple(w.shape) for w in ws_), wcls, tuple(fw.shape), _w_layout(fw))
+    plan = _FEATURE_PLANS.get(key)
+    if plan is None:
+        if len(_FEATURE_PLANS) > 16:
+            _FEATURE_PLANS.clear()
+        plan = _FEATURE_PLANS[key] = _FeaturePlan(lib, cfg, tuple(xshape), groups, key[3], wcls, key[5], key[6])
+    return plan
+
+
+def _feature_early_from(ws_, n, on_gpu):
+    """first block with >= 32 output channels: its and the later layers' weight gradients go to the side stream (FEATURE_WGRAD_EARLY)"""
+    if not (FEATURE_WGRAD_EARLY and _ASYNC_WGRAD_FUSED and on_gpu and n >= 4):
+        return None
+    e = next((i for i in range(n) if ws_[i].shape[0] >= 32), None)
+    return e if (e is not None and 0 < e < n) else None
+
+
 class FeatureExtractorFn(torch.autograd.Function):
     """A chain of 2-D ConvBnReLU blocks closed by a plain convolution with bias -- FeatureNet (jdacs/models/mvsnet.py:17-34) -- in
     TRAINING as ONE autograd node: the same kernels in the same order as the per-block graph (conv2d.hip forward with BatchNorm's
@@ -1285,6 +1391,25 @@ class FeatureExtractorFn(torch.autograd.Function):
                 hh, ww_ = (hh + 2 * padding - w.shape[2]) // stride + 1, (ww_ + 2 * padding - w.shape[3]) // stride + 1
             shp.append(torch.empty((bn_, fw.shape[1], hh, ww_), device="meta"))
             fused = _wgrad_batch_serves_shapes(lib, shp, list(ws_) + [fw], [c[0] for c in cfg] + [1])
+        own = bool(FEATURE_ALL_OWN)          # this node only runs where csrc/conv2d.hip serves every block (FeatureNet.forward checks)
+        ctx.c_entry = False
+        if (FEATURE_C_ENTRY and fused and own and lib.profiler is None and _N_SIDE == 1 and not FEATURE_DGRAD_BNSTATS and fb is not None
+                and tuple(fw.shape[2:]) == (3, 3) and all(c[1] == w.shape[2] // 2 for c, w in zip(cfg, ws_))):
+            plan = _feature_plan(lib, cfg, x.shape, groups, ws_, fw)
+            if plan.ok:
+                dev = x.device
+                arena = torch.empty(plan.fwd_floats, dtype=torch.float32, device=dev)
+                (slots,) = stat_slots(x, 1, 1, plan.slot_doubles // 2 + 1, 1)      # one zero-filled run of doubles for every block's rows
+                out = torch.empty(plan.out_shape, dtype=torch.float32, device=dev, memory_format=CL2)
+                ab, sb = arena.data_ptr(), slots.data_ptr()
+                lib.call("mvs_feature_fwd", n, plan.blocks, plan.N, groups, _p(x), _ptr_array(ws_), _ptr_array(gammas), _ptr_array(betas),
+                         _ptr_array([params[5 * i + 3] for i in range(n)]), _ptr_array([params[5 * i + 4] for i in range(n)]),
+                         _ptrs(ab, plan.packed_off), _ptrs(ab, plan.raw_off), ab + 4 * plan.ylast_off, _ptrs(ab, plan.stats_off),
+                         _ptrs(sb, plan.sf_off, 8), plan.nslots, _p(fw), _p(fb.contiguous()), plan.close_cout, plan.fwcl,
+                         ab + 4 * plan.wsclose_off, _p(out), _stream(x))
+                ctx.cfg, ctx.groups, ctx.slots_used, ctx.fused, ctx.own, ctx.c_entry, ctx.plan = cfg, groups, False, True, True, True, plan
+                ctx.save_for_backward(x, fw, *ws_, arena, slots)
+                return out
         acts, raws, statss, slots_b = [x], [], [], []
         for i, (stride, padding, eps, momentum, hip_dgrad) in enumerate(cfg):
             if fused and i > 0:
@@ -1302,7 +1427,6 @@ class FeatureExtractorFn(torch.autograd.Function):
             raws.append(raw)
             statss.append(stats)
             slots_b.append(sb)
-        own = bool(FEATURE_ALL_OWN)          # this node only runs where csrc/conv2d.hip serves every block (FeatureNet.forward checks)
         if own:
             out = conv2d_forward(acts[-1], fw, fb, 1)
         else:
@@ -1315,7 +1439,62 @@ class FeatureExtractorFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _backward_c(ctx, gout):
+        """the whole backward pass as ONE C call (mvs_feature_bwd): same kernels, same order, same fork point as backward() below"""
+        plan, groups = ctx.plan, ctx.groups
+        n = plan.n
+        sv = ctx.saved_tensors
+        x, fw, ws_, arena, slots = sv[0], sv[1], sv[2:2 + n], sv[2 + n], sv[3 + n]
+        lib = _lib_for(x)
+        dev = x.device
+        need = ctx.needs_input_grad              # [x, groups, cfg, *params]
+        if ctx.slots_used:                       # a second backward through the same graph: fresh backward accumulators
+            slots = torch.zeros_like(slots)
+        ctx.slots_used = True
+        gout = as_cl2(gout)
+        main = torch.cuda.current_stream(dev) if x.is_cuda else None
+        early = _feature_early_from(ws_, n, x.is_cuda)
+        side = _side_stream(dev) if early is not None else None
+        grads = [None] * (5 * n + 2)
+        if need[3 + 5 * n + 1]:
+            if side is not None and FEATURE_BIAS_SIDE:
+                gb = torch.empty(gout.shape[1], dtype=gout.dtype, device=dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    torch.sum(gout, (0, 2, 3), out=gb)
+                grads[5 * n + 1] = gb
+            else:
+                grads[5 * n + 1] = gout.sum((0, 2, 3))
+        work = torch.empty(plan.bwd_floats, dtype=torch.float32, device=dev)
+        dgb = torch.empty(plan.dgb_floats, dtype=torch.float32, device=dev)
+        gws = [torch.empty_like(w) for w in list(ws_) + [fw]]       # preserve_format: the parameter's strides
+        lo = early if early is not None else n + 1
+        ws_main = torch.empty(max(1, plan.wgrad_floats(lib, 0, lo)), dtype=torch.float32, device=dev)
+        ws_side = torch.empty(max(1, plan.wgrad_floats(lib, lo, n + 1)), dtype=torch.float32, device=dev) if early is not None else None
+        gx = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev, memory_format=CL2) if need[0] else None
+        ab, sb, wb = arena.data_ptr(), slots.data_ptr(), work.data_ptr()
+        used = C.c_int(0)
+        lib.call("mvs_feature_bwd", n, plan.blocks, plan.N, groups, _p(x), _ptr_array(ws_), _p(fw), plan.close_cout, plan.fwcl,
+                 _ptrs(ab, plan.raw_off), ab + 4 * plan.ylast_off, _ptrs(ab, plan.stats_off), _ptrs(sb, plan.sb_off, 8), plan.nslots, _p(gout),
+                 _ptrs(wb, plan.g_off), _ptrs(wb, plan.draw_off), _p(gx), wb + 4 * plan.dgws_off, _ptr_array(gws), _p(ws_main), _p(ws_side),
+                 _ptrs(dgb.data_ptr(), plan.dgb_off), _ptrs(dgb.data_ptr(), [o + plan.out[i][1] for i, o in enumerate(plan.dgb_off)]),
+                 early if early is not None else 0, main.cuda_stream if main is not None else None,
+                 side.cuda_stream if side is not None else None, C.byref(used))
+        if used.value and side is not None:
+            for ten in [x, arena, work, gout, ws_side] + gws:
+                ten.record_stream(side)
+        for i in range(n):
+            c = plan.out[i][1]
+            grads[5 * i] = gws[i]
+            grads[5 * i + 1] = dgb[plan.dgb_off[i]:plan.dgb_off[i] + c]
+            grads[5 * i + 2] = dgb[plan.dgb_off[i] + c:plan.dgb_off[i] + 2 * c]
+        grads[5 * n] = gws[n]
+        return (gx, None, None) + tuple(grads)
+
+    @staticmethod
     def backward(ctx, gout):
+        if ctx.c_entry:
+            return FeatureExtractorFn._backward_c(ctx, gout)
         cfg, groups = ctx.cfg, ctx.groups
         n = len(cfg)
         sv = ctx.saved_tensors
@@ -1350,11 +1529,7 @@ class FeatureExtractorFn(torch.autograd.Function):
         # worth of MFMA work) are enqueued on the side stream as soon as their output gradients exist and run next to the rest of
         # this backward pass -- the main stream is the step's critical path (bench.py --step-events: the side stream ends 0.1 ms
         # before it), so what leaves it shortens the step.  Joined before this node returns.
-        early_from = None
-        if batch and FEATURE_WGRAD_EARLY and _ASYNC_WGRAD_FUSED and gout.is_cuda and n >= 4:
-            early_from = next((i for i in range(n) if ws_[i].shape[0] >= 32), None)     # first block with >= 32 output channels
-            if early_from is not None and not (0 < early_from < n):
-                early_from = None
+        early_from = _feature_early_from(ws_, n, gout.is_cuda) if batch else None
         if batch:
             if need[3 + 5 * n + 1]:
                 if early_from is not None and FEATURE_BIAS_SIDE:
@@ -1801,6 +1976,7 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
     if (packed_ws is not None or in_stats is not None) and not want_stats:
         raise ValueError("conv2d_forward: packed_ws / in_stats serve the want_stats (training) form")
     if want_stats:
+        wc = weight if packed_ws is not None else weight.contiguous()     # (a local: the pointer stays valid until the call is made)
         if bias is not None or negative_slope is not None:
             raise ValueError("conv2d_forward: statistics are those of the plain convolution (no bias / activation)")
         if n % groups:
@@ -1809,20 +1985,25 @@ def conv2d_forward(x, weight, bias=None, stride=1, negative_slope=None, want_sta
         if in_stats is not None:
             if tuple(in_stats.shape) != (groups, 4, cin) or in_stats.dtype != torch.float32 or not in_stats.is_contiguous():
                 raise ValueError("conv2d_forward: in_stats %s does not match %d groups of [4,%d]" % (tuple(in_stats.shape), groups, cin))
-            lib.call("mvs_conv2d_fwd_stats_xf", _p(x), _p(in_stats), _p(weight.contiguous() if packed_ws is None else weight), _p(y), _p(ws),
+            lib.call("mvs_conv2d_fwd_stats_xf", _p(x), _p(in_stats), _p(wc), _p(y), _p(ws),
                      _p(slots), slots.shape[1], groups, n, h, w, cin, cout, ks, stride, int(packed_ws is not None), _stream(x),
                      tag="fwd2d_stats_xf:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
             return y, slots
-        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(weight.contiguous() if packed_ws is None else weight), _p(y), _p(ws), _p(slots),
+        lib.call("mvs_conv2d_fwd_stats", _p(x), _p(wc), _p(y), _p(ws), _p(slots),
                  slots.shape[1], groups, n, h, w, cin, cout, ks, stride, int(packed_ws is not None), _stream(x),
                  tag="fwd2d_stats:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
         return y, slots
     if negative_slope is not None:
-        lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
+        wc, bc = weight.contiguous(), (None if bias is None else bias.contiguous())   # (locals: the pointers stay valid until the call is made)
+        lib.call("mvs_conv2d_lrelu_fwd", _p(x), _p(wc), _p(bc), _p(y), _p(ws),
                  n, h, w, cin, cout, ks, stride, float(negative_slope), _stream(x), tag="fwd2d_lrelu:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
         return y
-    lib.call("mvs_conv2d_fwd", _p(x), _p(weight.contiguous()), _p(None if bias is None else bias.contiguous()), _p(y), _p(ws),
-             n, h, w, cin, cout, ks, stride, _stream(x), tag="fwd2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
+    wl = _w_layout(weight)
+    if wl is None:
+        weight, wl = weight.contiguous(), 0        # (kept in a local: the pointer must stay valid until the call has been made)
+    bias_c = None if bias is None else bias.contiguous()
+    lib.call("mvs_conv2d_fwd_wl", _p(x), _p(weight), _p(bias_c), _p(y), _p(ws), n, h, w, cin, cout, ks, stride, wl, _stream(x),
+             tag="fwd2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
     return y
 
 
@@ -1840,10 +2021,14 @@ def conv2d_dgrad(gy, weight, in_shape, stride=1, bn=None, groups=1):
         if stride != 1 or ks != 3 or tuple(raw.shape) != (n, cin, h, w) or tuple(stats.shape) != (groups, 4, cin) or n % groups:
             raise ValueError("conv2d_dgrad(bn=...): a 3x3 stride-1 layer, raw %s like the input %s, stats [%d,4,%d]"
                              % (tuple(raw.shape), (n, cin, h, w), groups, cin))
-        lib.call("mvs_conv2d_dgrad_bnstats", _p(gy), _p(weight.contiguous()), _p(gx), _p(ws), n, h, w, cin, cout, ks, _p(as_cl2(raw)),
+        wc, rawc = weight.contiguous(), as_cl2(raw)
+        lib.call("mvs_conv2d_dgrad_bnstats", _p(gy), _p(wc), _p(gx), _p(ws), n, h, w, cin, cout, ks, _p(rawc),
                  _p(stats), _p(slots), slots.shape[-3], groups, _stream(gy), tag="dgrad2d_bn:%d>%d:k%d" % (cin, cout, ks))
         return gx
-    lib.call("mvs_conv2d_dgrad", _p(gy), _p(weight.contiguous()), _p(gx), _p(ws), n, h, w, cin, cout, ks, stride, _stream(gy),
+    wl = _w_layout(weight)
+    if wl is None:
+        weight, wl = weight.contiguous(), 0
+    lib.call("mvs_conv2d_dgrad_wl", _p(gy), _p(weight), _p(gx), _p(ws), n, h, w, cin, cout, ks, stride, wl, _stream(gy),
              tag="dgrad2d:%d>%d:k%d:s%d" % (cin, cout, ks, stride))
     return gx
 

@@ -1400,6 +1400,62 @@ def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused, d
             assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), k
 
 
+@pytest.mark.parametrize("channels_last_weights", [False, True], ids=["contiguous_weights", "channels_last_weights"])
+def test_training_extractor_one_c_call_per_pass_equals_per_layer_calls(emul_lib, channels_last_weights):
+    """mvs_feature_fwd / mvs_feature_bwd (csrc/feature_pass.cpp: the node's forward / backward pass as ONE C call each over pointer
+    tables into two arenas) against the same node issuing the per-layer C calls from Python (ops.FEATURE_C_ENTRY = False): the same
+    kernels in the same order => output, input gradient, every parameter gradient and the running statistics BIT-IDENTICAL.  With
+    channels-last parameters (module.to(memory_format=torch.channels_last): what bench.py trains) the C entry reads them in place
+    (mvs_conv2d_fwd_wl / mvs_conv2d_dgrad_wl; the Python path makes a contiguous copy per layer) and writes the weight gradients in
+    the parameters' layout.  Replaces the 15 module calls of FeatureNet.forward (/root/reference/jdacs/models/mvsnet.py:17-34)."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet, _FEATURE_LAYERS
+    torch.manual_seed(7)
+    ref = FeatureNet().train()
+    if channels_last_weights:
+        ref = ref.to(memory_format=torch.channels_last)
+    groups = 2
+    x = torch.randn(groups, 3, 12, 40).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for c_entry in (True, False):
+        net = copy.deepcopy(ref)
+        blocks = [getattr(net, name) for name, *_ in _FEATURE_LAYERS]
+        cfg, params = [], []
+        for m in blocks:
+            cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
+            params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+        params += [net.feature.weight, net.feature.bias]
+        xa = x.clone().requires_grad_(True)
+        old = ops.FEATURE_C_ENTRY
+        ops.FEATURE_C_ENTRY = c_entry
+        try:
+            with ops.slot_scope():
+                ya = ops.FeatureExtractorFn.apply(xa, groups, tuple(cfg), *params)
+            assert ya.grad_fn.c_entry == c_entry and ya.grad_fn.fused
+            gy = torch.randn(ya.shape, generator=torch.Generator().manual_seed(4)).contiguous(memory_format=torch.channels_last)
+            ya.backward(gy, retain_graph=c_entry)
+            g1 = {k: p.grad.clone() for k, p in net.named_parameters()}
+            gx1 = xa.grad.clone()
+            g2 = None
+            if c_entry:                                        # a second backward through the same graph: fresh statistic accumulators
+                for p_ in net.parameters():
+                    p_.grad = None
+                ya.backward(gy)
+                g2 = {k: p.grad.clone() for k, p in net.named_parameters()}
+        finally:
+            ops.FEATURE_C_ENTRY = old
+        res[c_entry] = (ya.detach(), gx1, g1, {k: v.clone() for k, v in net.state_dict().items()}, g2)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert a[2][k].stride() == b[2][k].stride(), k             # the parameter's own memory layout
+        assert torch.equal(a[2][k], b[2][k]), k
+        assert torch.equal(a[4][k], a[2][k]), k                    # the second backward reproduces the first
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
 def test_training_extractor_with_a_frozen_weight_keeps_its_activations(emul_lib):
     """A convolution weight that needs no gradient (fine-tuning with a frozen layer): the node does not take the consumer-side
     BatchNorm path (whose backward has no normalised activations to hand to the library's per-layer weight gradients) and the

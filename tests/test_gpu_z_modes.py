@@ -290,3 +290,46 @@ def test_regulariser_one_c_call_per_pass_equals_per_layer_calls(dev, which, asyn
         n_exact += int(torch.equal(ta, tb))
         n_all += 1
     print("one C call per pass vs per-layer calls: %d of %d tensors bit-identical" % (n_exact, n_all))
+
+
+@pytest.mark.parametrize("channels_last_weights", [True, False], ids=["channels_last_weights", "contiguous_weights"])
+def test_extractor_one_c_call_per_pass_equals_per_layer_calls(dev, channels_last_weights):
+    """mvs_feature_fwd / mvs_feature_bwd (the training FeatureNet's forward / backward pass as ONE C call each, the wide layers' weight
+    gradients forked to the side stream behind a HIP event inside the library) against the same autograd node issuing the per-layer
+    calls from Python: the same kernels in the same order on the same streams => features, every parameter gradient and the BatchNorm
+    buffers agree to the order of BatchNorm's statistic-sum noise (normally bit for bit).  3 views of 128x160, the parameters in the
+    layout bench.py trains with (channels-last) and contiguous.  Replaces the 15 module calls of FeatureNet.forward and the ~30
+    autograd nodes of its backward pass (/root/reference/jdacs/models/mvsnet.py:17-34, module.py:15-22)."""
+    import copy
+    from mvs_amd import ops
+    from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    torch.manual_seed(11)
+    ref = FeatureNet().train()
+    if channels_last_weights:
+        ref = ref.to(memory_format=torch.channels_last)
+    x = torch.randn(3, 3, 128, 160, generator=torch.Generator().manual_seed(1)).contiguous(memory_format=torch.channels_last).to(dev)
+    res = {}
+    for c_entry in (True, False):
+        net = copy.deepcopy(ref).to(dev)
+        old = ops.FEATURE_C_ENTRY
+        ops.FEATURE_C_ENTRY = c_entry
+        try:
+            y = net(x, 3)
+            assert type(y.grad_fn).__name__.startswith("FeatureExtractorFn") and y.grad_fn.c_entry == c_entry
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).contiguous(memory_format=torch.channels_last).to(dev)
+            y.backward(gy)
+            torch.cuda.synchronize()
+        finally:
+            ops.FEATURE_C_ENTRY = old
+        res[c_entry] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                        {k: v.clone() for k, v in net.state_dict().items()})
+    a, b = res[True], res[False]
+    n_exact, n_all = 0, 0
+    for what, ta, tb in [("features", a[0], b[0])] + [(k, a[1][k], b[1][k]) for k in a[1]] + [(k, a[2][k], b[2][k]) for k in a[2]]:
+        assert ta.stride() == tb.stride(), what
+        ta, tb = ta.double(), tb.double()
+        assert float((ta - tb).abs().max()) <= 1e-5 * float(tb.abs().max()) + 1e-30, what
+        n_exact += int(torch.equal(ta, tb))
+        n_all += 1
+    print("extractor: one C call per pass vs per-layer calls: %d of %d tensors bit-identical" % (n_exact, n_all))
+    assert not ops._BWD_OPEN
