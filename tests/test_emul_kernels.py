@@ -1400,7 +1400,7 @@ def test_training_extractor_as_one_autograd_node(emul_lib, wgrad_batch, fused, d
             assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), k
 
 
-@pytest.mark.parametrize("channels_last_weights", [False, True], ids=["contiguous_weights", "channels_last_weights"])
+@pytest.mark.parametrize("channels_last_weights", [pytest.param(False, marks=_full), True], ids=["contiguous_weights", "channels_last_weights"])
 def test_training_extractor_one_c_call_per_pass_equals_per_layer_calls(emul_lib, channels_last_weights):
     """mvs_feature_fwd / mvs_feature_bwd (csrc/feature_pass.cpp: the node's forward / backward pass as ONE C call each over pointer
     tables into two arenas) against the same node issuing the per-layer C calls from Python (ops.FEATURE_C_ENTRY = False): the same
