@@ -377,9 +377,11 @@ def main():
                     help="side streams the regulariser's weight gradients are dealt to round-robin (ops.set_wgrad_streams)")
     ap.add_argument("--side-priority", type=str, default="default", choices=["default", "low", "high"],
                     help="priority of the weight-gradient side stream (ops.set_side_stream_priority)")
-    ap.add_argument("--defer-join", type=int, default=1,
-                    help="1: join the regulariser's side-stream weight gradients at the end of the backward pass (this loop has no "
-                         "gradient hooks); 0: inside the regulariser node (the library default)")
+    ap.add_argument("--defer-join", type=int, default=0,
+                    help="0 (default since round 6): the LIBRARY DEFAULT -- no set_async_wgrad opt-in; MVSNet's tail node "
+                         "(ops.DeferredJoinFn) joins the regulariser's side-stream weight gradients at the end of the backward pass, safely "
+                         "under gradient hooks; 1: round 5's opt-in (ops.set_async_wgrad(True, defer_join=True): the join by an autograd "
+                         "engine callback, only for loops without gradient hooks)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the nccl (== RCCL) process group even at world size 1 and run the gradient bucket's all-reduce "
                          "inside every step: RCCL init + one ncclAllReduce of the flat bucket execute on a 1-GPU box")
@@ -569,8 +571,8 @@ def main():
     # MVS_ASYNC_WGRAD=0 times the synchronous mode, and the line reports the other mode's ms/step beside the headline either way
     from mvs_amd import ops as _ops
     async_wgrad = os.environ.get("MVS_ASYNC_WGRAD", "1") != "0"
-    # this loop reads gradients only after backward() (bucket.gather()), registers no gradient hooks and clears .grad every step, so
-    # the regulariser's side-stream weight gradients may be joined ONCE at the end of the backward pass (ops.set_async_wgrad)
+    # Round 6: the headline runs the LIBRARY DEFAULT (--defer-join 0): what a drop-in caller under the reference's train.py gets.  The
+    # late join that round 5 measured as an opt-in now happens in MVSNet's tail node (ops.DeferredJoinFn), safely under gradient hooks.
     defer_join = bool(args.defer_join) and async_wgrad
     _ops.set_async_wgrad(async_wgrad, defer_join=defer_join)
     _ops.set_wgrad_streams(args.wgrad_streams)
@@ -743,6 +745,22 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ms_library_default = float(tm.item()) / args.steps * 1e3
         _ops.set_async_wgrad(True, defer_join=True)
+    ms_join_in_node = None
+    if train and not graph_mode and async_wgrad and not defer_join and _ops.TAIL_JOIN:
+        # what the library default was in rounds 3-5 (MVS_TAIL_JOIN=0): the side stream joined INSIDE the regulariser node
+        _ops.TAIL_JOIN = False
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_join_in_node = float(tm.item()) / args.steps * 1e3
+        _ops.TAIL_JOIN = True
     if train and not graph_mode:
         _ops.set_async_wgrad(not async_wgrad)
         for _ in range(2):
@@ -835,6 +853,9 @@ def main():
             elif spec == "feature_fused_apply":
                 def setter(on, base=_ops.FEATURE_FUSED_APPLY):
                     _ops.FEATURE_FUSED_APPLY = (not base) if on else base
+            elif spec == "tail_join":
+                def setter(on, base=_ops.TAIL_JOIN):
+                    _ops.TAIL_JOIN = (not base) if on else base
             elif spec == "feature_c_entry":
                 def setter(on, base=_ops.FEATURE_C_ENTRY):
                     _ops.FEATURE_C_ENTRY = (not base) if on else base
@@ -985,12 +1006,17 @@ def main():
             "launch_mode": "hipGraph replay" if graph_mode else "eager",
             "async_wgrad": bool(async_wgrad) if train else None, "async_wgrad_is_library_default": bool(_ops.FUSED_REGULARISER),
             "fused_regulariser_node": bool(_ops.FUSED_REGULARISER),
-            "wgrad_join": ("end of backward pass" if defer_join else "inside the regulariser node") if train else None,
+            "wgrad_join": ("end of backward pass (opt-in engine callback, ops.set_async_wgrad(defer_join=True))" if defer_join else
+                           ("end of backward pass (library default: MVSNet's tail node, ops.DeferredJoinFn)" if (_ops.TAIL_JOIN and async_wgrad and args.config in (2, 3))
+                            else "inside the regulariser node")) if train else None,
+            "headline_mode_is_library_default": bool(async_wgrad and not defer_join) if train else None,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "host_enqueue_ms_per_step_median_max": [host_steps[len(host_steps) // 2], host_steps[-1]], "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "ms_per_step_library_default": (ms_library_default if (async_wgrad and defer_join) else (dt / args.steps * 1e3 if async_wgrad else ms_other_mode)) if train else None,
-            "library_default_is": "side-stream weight gradients joined inside the regulariser node (MVS_ASYNC_WGRAD unset, no set_async_wgrad call)",
+            "ms_per_step_join_inside_regulariser_node": ms_join_in_node,
+            "library_default_is": "MVS_ASYNC_WGRAD unset, no set_async_wgrad call: side-stream weight gradients, joined by MVSNet's tail node at the "
+                                  "end of the backward pass (MVS_TAIL_JOIN=0: inside the regulariser node, rounds 3-5)",
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,
         }
         if ms_sustained is not None:

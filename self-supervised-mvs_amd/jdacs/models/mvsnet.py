@@ -77,7 +77,14 @@ class CostRegNet(nn.Module):
             setattr(self, name, DeconvBnReLU3D(cin, cout, stride=2))
         self.prob = ProbConv3d(8)
 
-    def forward(self, x):
+    def conv_weights(self):
+        """the convolution weights whose gradients the fused node computes on the side stream (ops.tail_join_views)"""
+        ws = [getattr(self, name).conv.weight for name, *_ in _REG_ENCODER] + [getattr(self, name)[0].weight for name, *_ in _REG_DECODER]
+        return ws + [self.prob.weight]
+
+    def forward(self, x, tail=None):
+        """tail: ops.tail_join_views(self.conv_weights()) made at the START of the model's forward pass (MVSNet._forward): the join of
+        the side-stream weight gradients then happens at the end of the backward pass, safely (ops.DeferredJoinFn)."""
         if x.dim() != 5 or x.shape[1] != 32:
             raise ValueError("CostRegNet expects [B,32,D,H,W], got %s" % (tuple(x.shape),))
         if x.dtype == torch.bfloat16 and self.training:
@@ -95,7 +102,7 @@ class CostRegNet(nn.Module):
             for j, (name, _, _, skip) in enumerate(_REG_DECODER):
                 m = getattr(self, name)
                 blocks.append((m[0], m[1], True, 2, len(_REG_ENCODER) + j - 1, order.index(skip)))
-            return ops.unet_regulariser(x, blocks, self.prob)
+            return ops.unet_regulariser(x, blocks, self.prob, tail)
         keep = {}
         for name, *_ in _REG_ENCODER:
             x = getattr(self, name)(x)
@@ -147,6 +154,11 @@ class MVSNet(nn.Module):
             return self._forward(imgs, proj_matrices, depth_values)
 
     def _forward(self, imgs, proj_matrices, depth_values):
+        # the tail node of the regulariser's weight gradients FIRST: the autograd engine runs ready nodes newest first, so the node
+        # created before everything else of this forward pass is the one that runs last in the backward pass (ops.DeferredJoinFn)
+        tail = None
+        if self.training and torch.is_grad_enabled() and imgs.is_cuda and self.storage_dtype == torch.float32 and ops.FUSED_REGULARISER:
+            tail = ops.tail_join_views(self.cost_regularization.conv_weights())
         imgs_in = imgs
         imgs = torch.unbind(imgs, 1)
         proj_matrices = torch.unbind(proj_matrices, 1)
@@ -174,7 +186,7 @@ class MVSNet(nn.Module):
                                                    out_dtype=self.storage_dtype)
 
         # step 3. cost volume regularisation (MFMA implicit-GEMM convs)
-        cost_reg = self.cost_regularization(volume_variance).squeeze(1)
+        cost_reg = self.cost_regularization(volume_variance, tail).squeeze(1)
 
         # step 4. softmax over depth + soft-argmin + photometric confidence (one kernel)
         depth, photometric_confidence = ops.softargmin_conf(cost_reg, depth_values)

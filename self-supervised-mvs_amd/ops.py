@@ -602,6 +602,50 @@ def _end_of_backward(idx: int) -> None:
         _join_side(ent[0], idx)
 
 
+# Round 6: the deferred join as the SAFE library default.  `set_async_wgrad(True, defer_join=True)` (round 5, bench-only) hands the
+# regulariser's weight gradients to autograd while the side stream is still writing them and joins once at the end of the backward
+# pass -- unsafe under anything that READS a gradient when AccumulateGrad fires (DDP / DataParallel hooks are C++ hooks no Python test
+# can see), so the library default joined inside the node and conv0's weight gradient (0.6 ms) held the main stream (5.05 vs 4.75 ms).
+# The tail node makes the late join safe: an identity autograd node on the regulariser's convolution weights, CREATED FIRST in the
+# model's forward (MVSNet._forward), whose backward joins the side streams and only then passes the gradients on to AccumulateGrad.
+# The autograd engine runs ready nodes in order of creation, newest first, so the tail node runs when nothing newer is left -- after the
+# plane-sweep backward and the 2-D extractor's backward, i.e. at the end of the pass -- and every gradient any hook ever sees is finished.
+# (If the engine ran it earlier, the join would simply come earlier: correctness does not depend on the order, only the overlap does.)
+TAIL_JOIN = os.environ.get("MVS_TAIL_JOIN", "1") != "0"
+
+
+class DeferredJoinFn(torch.autograd.Function):
+    """identity on a list of weights; backward: join the device's weight-gradient side streams, then hand the gradients on"""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        return tuple(w.view_as(w) for w in ws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        for g in gs:
+            if g is not None and g.is_cuda:
+                idx = g.device.index
+                _join_side(torch.cuda.current_stream(g.device), idx)
+                ent = _BWD_OPEN.get(idx)
+                if ent is not None:
+                    ent[1] = False                # joined: the end-of-backward callback has nothing left to wait for
+                break
+        return gs
+
+
+def tail_join_views(weights):
+    """{id(weight): view} through ONE DeferredJoinFn node for the weights that need a gradient (call it before anything else of the
+    forward pass builds autograd nodes); {} when the tail join does not apply (CPU tensors, no gradient, switched off)."""
+    ws = [w for w in weights if w.requires_grad and w.is_cuda]
+    if not (TAIL_JOIN and _ASYNC_WGRAD_FUSED and ws and torch.is_grad_enabled()):
+        return {}
+    views = DeferredJoinFn.apply(*ws)
+    for v in views:
+        v._mvs_tail_join = True
+    return {id(w): v for w, v in zip(ws, views)}
+
+
 def _async_safe(weight: torch.Tensor) -> bool:
     return (weight.is_leaf and weight.grad is None and weight.is_contiguous()
             and not getattr(weight, "_backward_hooks", None)
@@ -902,6 +946,8 @@ class UNetRegulariserFn(torch.autograd.Function):
         bq, cq, dq, hq, wq = in_shape[n - 1]
         pshape = (bq, dq, hq, wq, cq, wp.shape[0], 1)
         any_grad = any(need)
+        # every convolution weight that gets a gradient came through the tail node (DeferredJoinFn): the join may be left to it
+        ctx.tail_join = all(getattr(params[k], "_mvs_tail_join", False) or not need[2 + k] for k in list(range(0, 5 * n, 5)) + [5 * n])
         items = [(OP_CONVT_FWD if prog[i][0] else OP_CONV_FWD, params[5 * i], shapes[i]) for i in range(n)]
         dg_index = {}
         if any_grad:
@@ -977,7 +1023,7 @@ class UNetRegulariserFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev) if x.is_cuda else None
         use_side = _ASYNC_WGRAD_FUSED and x.is_cuda
         side = _side_stream(dev) if use_side else None
-        deferred = bool(use_side and _DEFER_JOIN and all(gw is None or _async_safe(wt) for gw, wt in zip(gws, ctx.params_w)))
+        deferred = bool(use_side and (ctx.tail_join or (_DEFER_JOIN and all(gw is None or _async_safe(wt) for gw, wt in zip(gws, ctx.params_w)))))
         ab, sb, wb = arena.data_ptr(), slots.data_ptr(), work.data_ptr()
         pd = (C.c_void_p * (n + 1))()
         for i in range(n + 1):
@@ -1100,7 +1146,7 @@ class UNetRegulariserFn(torch.autograd.Function):
             if not early:
                 grads[5 * i] = wgrad(xin, draw, w, stride, transposed, need[2 + 5 * i])
         if side_used[0]:
-            deferred = _DEFER_JOIN and all(gw is None or _async_safe(params_w) for gw, params_w in zip(grads[0:5 * n:5] + [grads[5 * n]], list(ws_) + [wp]))
+            deferred = ctx.tail_join or (_DEFER_JOIN and all(gw is None or _async_safe(params_w) for gw, params_w in zip(grads[0:5 * n:5] + [grads[5 * n]], list(ws_) + [wp])))
             if deferred:
                 # ONE join at the end of the whole backward pass (autograd engine callback): see set_async_wgrad
                 idx = dev.index
@@ -1114,16 +1160,19 @@ class UNetRegulariserFn(torch.autograd.Function):
         return (gx, None) + tuple(grads)
 
 
-def unet_regulariser(x, blocks, prob):
+def unet_regulariser(x, blocks, prob, tail=None):
     """blocks: list of (module-with-.conv/.bn or Sequential(deconv, bn), transposed, stride, src, skip); prob: the bias-only conv.
-    Train-mode fp32 forward of a whole regulariser through UNetRegulariserFn (the modules are parameter containers)."""
+    Train-mode fp32 forward of a whole regulariser through UNetRegulariserFn (the modules are parameter containers).
+    tail: {id(weight): view} of tail_join_views() -- the convolution weights as outputs of the tail node (the node then leaves the join
+    of its side-stream weight gradients to it)."""
     from . import nn3d
+    tail = tail or {}
     prog, params = [], []
     for conv, bn, transposed, stride, src, skip in blocks:
         momentum = nn3d._bn_step(bn, True)
         prog.append((bool(transposed), int(stride), int(src), int(skip), float(bn.eps), float(momentum)))
-        params += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    params += [prob.weight, prob.bias]
+        params += [tail.get(id(conv.weight), conv.weight), bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    params += [tail.get(id(prob.weight), prob.weight), prob.bias]
     return UNetRegulariserFn.apply(x, tuple(prog), *params)
 
 

@@ -1,10 +1,13 @@
 """GPU tests (-m gpu) of the EXECUTION MODES of the training step -- the things a kernel-level parity test cannot see:
 
-* the mode bench.py's headline is measured in (`ops.set_async_wgrad(True, defer_join=True)`: the regulariser hands its weight
-  gradients to autograd before the side stream has finished them, ONE join at the end of the backward pass) against the
-  synchronous mode (what `loss.backward()` of the reference means: finished gradients, /root/reference/jdacs/train.py:205),
-  at BASELINE config 2's full size and at config 3's per-GPU shape, two steps in a row, plus the two cases that must fall
-  back to the in-node join (a pre-existing .grad, a tensor hook on a weight);
+* the late join of the regulariser's side-stream weight gradients -- round 5's opt-in (`ops.set_async_wgrad(True, defer_join=True)`:
+  the regulariser hands its weight gradients to autograd before the side stream has finished them, ONE join at the end of the backward
+  pass by an engine callback) and round 6's LIBRARY DEFAULT (the tail node `ops.DeferredJoinFn` created first in MVSNet._forward joins at
+  the end of the backward pass and only then hands the gradients to AccumulateGrad; bench.py's headline mode) -- against the synchronous
+  mode (what `loss.backward()` of the reference means: finished gradients, /root/reference/jdacs/train.py:205), at BASELINE config 2's
+  full size and at config 3's per-GPU shape, two steps in a row, plus the cases that READ a gradient while it is handed over (a
+  pre-existing .grad, a tensor hook, a post-accumulate hook on a weight);
+* one C call per pass (regulariser: mvs_unet_fwd / _bwd; training extractor: mvs_feature_fwd / _bwd) against the per-layer calls;
 * SURVEY 8(b)'s threading contract: the reference's caller is one Python thread per GPU (nn.DataParallel's parallel_apply,
   /root/reference/jdacs/train.py:65); here two threads drive the C ABI concurrently on two streams of ONE GPU.
 
@@ -333,3 +336,50 @@ def test_extractor_one_c_call_per_pass_equals_per_layer_calls(dev, channels_last
         n_all += 1
     print("extractor: one C call per pass vs per-layer calls: %d of %d tensors bit-identical" % (n_exact, n_all))
     assert not ops._BWD_OPEN
+
+
+def test_library_default_joins_at_the_end_of_backward_through_the_tail_node(dev):
+    """Round 6: the LIBRARY DEFAULT (side-stream weight gradients, no defer_join opt-in) leaves the join to the tail node
+    (ops.DeferredJoinFn, created first in MVSNet._forward): the regulariser returns its weight gradients while the side stream is still
+    writing them, the tail node -- the last node of the backward pass -- joins and only then hands them to AccumulateGrad.  Checked at
+    BASELINE config 2's full size against the synchronous mode, with the three things that READ a gradient when it is handed over:
+    a tensor hook on conv0's weight (the last weight gradient forked), a post-accumulate hook on it (what DDP-style reducers use), and
+    a pre-existing .grad that autograd accumulates into -- none of which the node can see any more (its weights are the tail node's
+    views), so none of which may get an unfinished gradient.  /root/reference/jdacs/train.py:205: loss.backward() returns finished
+    gradients."""
+    from mvs_amd import ops
+    assert ops.TAIL_JOIN
+    net, imgs, proj, dv, cams = _make(dev, 3, 512, 640, 192, False)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    refs, _ = _sync_refs(net, imgs, proj, dv, None, state0)
+    ops.set_async_wgrad(True, defer_join=False)            # the library default
+    k0 = "cost_regularization.conv0.conv.weight"
+    w0 = net.cost_regularization.conv0.conv.weight
+    seen = {}
+    h1 = w0.register_hook(lambda g: seen.__setitem__("tensor_hook", g.detach().clone()))
+    h2 = w0.register_post_accumulate_grad_hook(lambda p: seen.__setitem__("post_accumulate", p.grad.detach().clone()))
+    try:
+        got, _ = _step(net, imgs, proj, dv, None, state0)
+        assert net.cost_regularization.conv0.conv.weight.grad is not None
+    finally:
+        h1.remove()
+        h2.remove()
+    _compare(refs, got, "library default (tail-node join)")
+    for what in ("tensor_hook", "post_accumulate"):
+        _compare([{k0: r[k0]} for r in refs], {k0: seen[what]}, "what the %s on conv0.weight saw" % what)
+    got2, _ = _step(net, imgs, proj, dv, None, state0, keep_grad=True)        # accumulates into the .grad of the step above
+    _compare(refs, got2, "accumulation into an existing .grad (tail-node join)", times=2.0)
+    assert not ops._BWD_OPEN
+    # and the regulariser node did leave the join to the tail node: its weights arrived as the tail node's views
+    out = net(imgs, proj, dv)
+    fn = out["depth"].grad_fn
+    seen_nodes, stack = set(), [fn]
+    names = set()
+    while stack:
+        f = stack.pop()
+        if f is None or f in seen_nodes:
+            continue
+        seen_nodes.add(f)
+        names.add(type(f).__name__)
+        stack.extend(g for g, _ in f.next_functions)
+    assert any(n.startswith("DeferredJoinFn") for n in names) and any(n.startswith("UNetRegulariserFn") for n in names), names
