@@ -218,9 +218,9 @@ def wgrad_all_cus(lib, dev, dims, flops, groups_all=256, reps=12):
     return {"ms_all_cus": ms, "frac_all_cus": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "groups_in_step": int(cur.value),
             "all_cus_is": "the same kernel on the same shape with %d workgroups (one per CU) and nothing beside it, convolution + the "
                           "reduction of its partial images (the C-ABI call), on RANDOM operands right after the timed passes (median of "
-                          "%d calls); in the step it is launched with `groups_in_step` workgroups on the side stream.  Random fp32 "
-                          "operands on a warm chip are the slowest case of this MFMA-bound kernel: the step's own tensors at %d "
-                          "workgroups take 0.46 ms, a fresh process on random tensors 0.45 (profiles/README.md)" % (groups_all, reps, groups_all)}
+                          "%d calls); in the step it is launched with `groups_in_step` workgroups on the side stream.  THIS is the "
+                          "kernel's own quality as measured in this process; `frac` (in the step) is what the roofline object reports "
+                          "(DESIGN.md section 4, 'reconciled': round 5's 77 %% was a best case and is withdrawn)" % (groups_all, reps)}
 
 
 def host_cpu():
