@@ -352,6 +352,10 @@ def main():
                          "self-supervised step N=5; 4 CVP-MVSNet 3-level inference at 1152x864; 5 MVSNet N=7 1600x1184 D=256 inference")
     ap.add_argument("--dtype", type=str, default="", choices=["", "f32", "bf16"],
                     help="storage dtype of the cost volume / regulariser activations for --config 5 (default bf16 there; f32 elsewhere)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="samples per GPU per step of the training configs (default 1: the reference's recipe -- jdacs/train.sh: batch 4 over 4 "
+                         "GPUs -- and what every round's headline was measured at); > 1: BatchNorm statistics over the rank's samples, "
+                         "`value` counts samples, `config.samples_per_gpu_per_step` says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gpu-reference", type=int, default=-1,
                     help="time the same step with the oracle's stock torch ops on this GPU (sampler='aten': F.grid_sample, MIOpen conv3d) = "
@@ -504,6 +508,13 @@ def main():
         net = net.to(dev).train()
         mdist.broadcast_parameters(net)
         imgs, proj, dv = synthetic_mvsnet_inputs(1, nviews, img_h, img_w, ndepth, seed=1 + rank)
+        if args.batch > 1:
+            if cfg["kind"] != "train":
+                raise SystemExit("bench.py: --batch > 1 is implemented for --config 2")
+            more = [synthetic_mvsnet_inputs(1, nviews, img_h, img_w, ndepth, seed=1 + rank + 1000 * k) for k in range(1, args.batch)]
+            imgs = torch.cat([imgs] + [m[0] for m in more])
+            proj = torch.cat([proj] + [m[1] for m in more])
+            dv = torch.cat([dv] + [m[2] for m in more])
         if cfg["kind"] == "selfsup":
             import torch.nn.functional as F
             from mvs_amd.jdacs.losses.unsup_loss import UnSupLoss
@@ -517,7 +528,7 @@ def main():
             cams = cams.to(dev)
             unsup = UnSupLoss()
         imgs, proj, dv = imgs.to(dev), proj.to(dev), dv.to(dev)
-        gt = torch.full((1, img_h // 4, img_w // 4), 650.0, device=dev)
+        gt = torch.full((max(1, args.batch), img_h // 4, img_w // 4), 650.0, device=dev)
         mask = torch.ones_like(gt)
         if train:
             # gradients AND parameters live in two flat fp32 buffers: one collective, one fused Adam launch
@@ -992,13 +1003,13 @@ def main():
                   4: "depth-samples/sec (CVP-MVSNet 3-level inference, N=5, 1152x864, D=(48,8,8))",
                   5: "depth-samples/sec (MVSNet inference, N=7, 1600x1184, D=256)"}[args.config]
         res = {
-            "metric": metric, "value": world * args.steps / dt,
+            "metric": metric, "value": world * max(1, args.batch) * args.steps / dt,
             "unit": "depth-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["what"], "baseline_config_index": args.config - 1,
                        "views": nviews, "image": [img_h, img_w], "depth_planes": ndepth,
-                       "global_batch": world, "parallelism": "dp%d" % world},
+                       "global_batch": world * max(1, args.batch), "samples_per_gpu_per_step": max(1, args.batch), "parallelism": "dp%d" % world},
             "ranks": (dist.get_world_size() if world > 1 else 1), "multi_gpu": multi,
             "collective": ("RCCL all_reduce(sum) of one flat fp32 bucket, %d ranks%s" % (world, " (--force-collective)" if world == 1 else ""))
             if ((world > 1 or args.force_collective) and train) else "none",

@@ -1469,6 +1469,21 @@ static int pick_cc(int geom, int cin) {
     return (cin % 16 == 0) ? 16 : 8;
 }
 
+// Round 6, knob "cc_wide" (MEASURED AND REJECTED, default off): the quarter-tile kernels of the deep U-Net levels with ALL input channels
+// as ONE chunk (32 / 64 for stride 1, 16 / 32 for stride 2) instead of 16- / 8-channel chunks -- one exposed staging round trip and two
+// barriers per workgroup instead of 2-4 and 4-8.  It is SLOWER: 64 -> 64 at 24x16x20 0.040 -> 0.077 ms forward, 0.042 -> 0.078 input
+// gradient; 32 -> 32 at 48x32x40 0.052 -> 0.062; 32 -> 64 stride 2 0.034 -> 0.058; step 4.699 -> 4.871 ms (profiles/r06_run11_*).  The
+// small chunks ARE the pipeline of these launches: 24 KB of LDS per workgroup lets several workgroups share a CU and overlap each other's
+// stage / MFMA phases, while a 78-128 KB tile leaves one workgroup per CU alone with a 28-load staging phase and nothing to hide it.
+int g_conv_cc_wide = 0;
+static int pick_cc_k(int geom, int kgeom, int cin) {
+    if (g_conv_cc_wide) {
+        if (kgeom == GEOM_S1_SMALL && (cin == 32 || cin == 64)) return cin;
+        if (kgeom == GEOM_S2_SMALL && (cin == 16 || cin == 32)) return cin;
+    }
+    return pick_cc(geom, cin);
+}
+
 static size_t packed_floats(int geom, int cin, int cout) {
     const int cc = pick_cc(geom, cin);
     int nb = mvs_cdiv(cout, 16);
@@ -1633,7 +1648,7 @@ static int plan_pack(const IgemmPlan& p, const float* w, float* ws, PackItem& it
     int QD, QH, QW, kgeom, NB, nblocks;
     plan_grid(p, QD, QH, QW);
     igemm_tiling(p.geom, p.B, QD, QH, QW, p.cout, kgeom, NB, nblocks);
-    const int cc = pick_cc(p.geom, p.cin);
+    const int cc = pick_cc_k(p.geom, kgeom, p.cin);
     const int nb_total = mvs_cdiv(p.cout, 16) == 3 ? 4 : mvs_cdiv(p.cout, 16);
     const int pgeom = (kgeom == GEOM_TR2 && cc == 16 && p.cout == 8 && g_conv_tr2pw) ? GEOM_TR2_PW : p.geom;
     it.kind = 0; it.geom = pgeom; it.CC = cc; it.Cin = p.cin; it.Cout = p.cout; it.NB = nb_total; it.layout = p.wlayout; it.flip = p.flip;
@@ -1690,10 +1705,10 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
         else MVS_LAUNCH((conv_cout1_kernel<16>), dim3(nblocks), dim3(256), 0, st, a, wsrc);
         return mvs_check_launch("conv_cout1");
     }
-    const int cc = pick_cc(geom, cin);
     int NB, kgeom;
     a.nb_total = mvs_cdiv(cout, 16) == 3 ? 4 : mvs_cdiv(cout, 16);
     igemm_tiling(geom, B, a.QD, a.QH, a.QW, cout, kgeom, NB, nblocks);
+    const int cc = pick_cc_k(geom, kgeom, cin);
     a.ntd = mvs_cdiv(a.QD, geom_tqd(kgeom)); a.nth = mvs_cdiv(a.QH, geom_tqh(kgeom));
     if (!ws_packed) {
         PackItem it;
@@ -1719,9 +1734,16 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
     if (kgeom == GEOM_S1) return cc == 16 ? launch_igemm_nb<GEOM_S1, 16>(a, NB, nblocks, st)
                                           : launch_igemm_nb<GEOM_S1, 8>(a, NB, nblocks, st);
     if (kgeom == GEOM_S2) return launch_igemm_nb<GEOM_S2, 8>(a, NB, nblocks, st);
-    if (kgeom == GEOM_S1_SMALL) return cc == 16 ? launch_igemm_nb<GEOM_S1_SMALL, 16>(a, NB, nblocks, st)
-                                                : launch_igemm_nb<GEOM_S1_SMALL, 8>(a, NB, nblocks, st);
-    if (kgeom == GEOM_S2_SMALL) return launch_igemm_nb<GEOM_S2_SMALL, 8>(a, NB, nblocks, st);
+    if (kgeom == GEOM_S1_SMALL) {
+        if (cc == 64) return launch_igemm_nb<GEOM_S1_SMALL, 64>(a, NB, nblocks, st);
+        if (cc == 32) return launch_igemm_nb<GEOM_S1_SMALL, 32>(a, NB, nblocks, st);
+        return cc == 16 ? launch_igemm_nb<GEOM_S1_SMALL, 16>(a, NB, nblocks, st) : launch_igemm_nb<GEOM_S1_SMALL, 8>(a, NB, nblocks, st);
+    }
+    if (kgeom == GEOM_S2_SMALL) {
+        if (cc == 32) return launch_igemm_nb<GEOM_S2_SMALL, 32>(a, NB, nblocks, st);
+        if (cc == 16) return launch_igemm_nb<GEOM_S2_SMALL, 16>(a, NB, nblocks, st);
+        return launch_igemm_nb<GEOM_S2_SMALL, 8>(a, NB, nblocks, st);
+    }
     if (kgeom == GEOM_TR2_SMALL) {
         if (cc == 16) return launch_igemm_nb<GEOM_TR2_SMALL, 16>(a, NB, nblocks, st);
         if (cc == 32) return launch_igemm_nb<GEOM_TR2_SMALL, 32>(a, NB, nblocks, st);
