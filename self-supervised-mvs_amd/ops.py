@@ -1529,9 +1529,11 @@ class FeatureExtractorFn(torch.autograd.Function):
                  _ptrs(dgb.data_ptr(), plan.dgb_off), _ptrs(dgb.data_ptr(), [o + plan.out[i][1] for i, o in enumerate(plan.dgb_off)]),
                  early if early is not None else 0, main.cuda_stream if main is not None else None,
                  side.cuda_stream if side is not None else None, C.byref(used))
-        if used.value and side is not None:
-            for ten in [x, arena, work, gout, ws_side] + gws:
-                ten.record_stream(side)
+        # (no record_stream on the tensors the side stream touched: mvs_feature_bwd has made the main stream wait for the side stream
+        #  before it returned, so everything enqueued on the main stream from here on -- which is where the caching allocator hands these
+        #  blocks out again -- is ordered behind the side stream's work.  With record_stream the allocator could not reuse the 1 GB work
+        #  arena of a batch-4 step until an event had been polled complete and fell back to hipMalloc / hipFree every step: 48 ms per
+        #  step instead of 17, profiles/r06_run12_*.)
         for i in range(n):
             c = plan.out[i][1]
             grads[5 * i] = gws[i]
