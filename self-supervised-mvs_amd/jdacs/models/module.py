@@ -32,9 +32,11 @@ def conv2d_maybe_hip(conv: nn.Conv2d, x):
 
 
 class ConvBnReLU(nn.Module):
-    """module.py:15-22.  The 2-D convolution stays MIOpen (stock PyTorch); BatchNorm2d + ReLU run through the
-    library's BatchNorm kernels when the activation is channels-last on the GPU with C % 4 == 0 (``hip_bn``);
-    otherwise (e.g. RefineNet's 1-channel output layer) the stock modules are used."""
+    """module.py:15-22.  In training inside FeatureNet the block is part of ONE autograd node (ops.FeatureExtractorFn; round 6: every
+    convolution, input gradient, weight gradient and BatchNorm pass through csrc/conv2d.hip + csrc/bn.hip, two C calls per step); in eval
+    mode under no_grad BatchNorm is folded into the convolution (``fold_eval``).  Used stand-alone (a user's own block, a channel count the
+    kernels do not serve, RefineNet's 1-channel output layer) the convolution is the stock module's and BatchNorm2d + ReLU run through this
+    library's BatchNorm kernels when the activation is channels-last on the GPU with C in {4, 8, 16, 32, 64} (``hip_bn``)."""
     hip_bn = True
     # SURVEY 8(f)-3, first cut: the convolution itself through csrc/conv2d.hip instead of MIOpen.  Parity-tested (CPU
     # emulation of the kernels), not yet measured on the GPU -> off unless MVS_HIP_FEATURE=1 / ConvBnReLU.hip_conv = True.
