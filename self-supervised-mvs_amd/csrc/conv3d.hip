@@ -434,7 +434,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // Cin == 1 (input gradient of the Cout=1 probability layer): direct form, one thread per voxel.
 // y[v][co] = sum_t x[v + t - 1] * wt[t][co]   (wt already flipped / transposed by the caller-side packer)
 // ------------------------------------------------------------------------------------------------
-template <int COUT>
+// VPT (round 6): voxels per thread -- the workgroup walks VPT consecutive runs of 256 voxels and reduces the backward statistics ONCE
+// (the wave reduction is 16 values x 6 shuffle steps per thread: a quarter of the kernel's vector instructions at one voxel per thread).
+template <int COUT, int VPT>
 __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                         float* __restrict__ y, int B, int D, int H, int W,
                                                         const float* __restrict__ bn_raw, const float* __restrict__ bn_stats,
@@ -445,59 +447,63 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
     // read at compile-time offsets of the read-only table (uniform: scalar loads, SGPR operands of the FMAs), not from LDS.
     __shared__ float red[4 * 2 * COUT];
     const size_t total = (size_t)B * D * H * W;
-    const size_t v0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = v0 < total;
-    const size_t v = live ? v0 : total - 1;
-    const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
-    // the raw tensor of the backward statistics: requested first (it arrives under the taps' loads and FMAs)
-    float4 rwq[COUT / 4];
+    float sv[2 * COUT];
 #pragma unroll
-    for (int q = 0; q < COUT / 4; ++q)
-        rwq[q] = (slots && live) ? *reinterpret_cast<const float4*>(bn_raw + v * COUT + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    int dofs[3], hofs[3], wofs[3];
-    bool vd[3], vh[3], vw[3];
+    for (int k = 0; k < 2 * COUT; ++k) sv[k] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < VPT; ++it) {
+        const size_t v0 = ((size_t)blockIdx.x * VPT + it) * 256 + threadIdx.x;
+        const bool live = v0 < total;
+        const size_t v = live ? v0 : total - 1;
+        const int w_ = (int)(v % W), h_ = (int)((v / W) % H), d_ = (int)((v / ((size_t)W * H)) % D);
+        // the raw tensor of the backward statistics: requested first (it arrives under the taps' loads and FMAs)
+        float4 rwq[COUT / 4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int d = d_ + i - 1, h = h_ + i - 1, w = w_ + i - 1;
-        vd[i] = d >= 0 && d < D; vh[i] = h >= 0 && h < H; vw[i] = w >= 0 && w < W;
-        dofs[i] = (min(max(d, 0), D - 1) - d_) * H * W;
-        hofs[i] = (min(max(h, 0), H - 1) - h_) * W;
-        wofs[i] = min(max(w, 0), W - 1) - w_;
-    }
-    const float* __restrict__ xc = x + v;
-    float xv[27];
+        for (int q = 0; q < COUT / 4; ++q)
+            rwq[q] = (slots && live) ? *reinterpret_cast<const float4*>(bn_raw + v * COUT + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int dofs[3], hofs[3], wofs[3];
+        bool vd[3], vh[3], vw[3];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) xv[t] = xc[dofs[t / 9] + hofs[(t / 3) % 3] + wofs[t % 3]];
-    float acc[COUT];
+        for (int i = 0; i < 3; ++i) {
+            const int d = d_ + i - 1, h = h_ + i - 1, w = w_ + i - 1;
+            vd[i] = d >= 0 && d < D; vh[i] = h >= 0 && h < H; vw[i] = w >= 0 && w < W;
+            dofs[i] = (min(max(d, 0), D - 1) - d_) * H * W;
+            hofs[i] = (min(max(h, 0), H - 1) - h_) * W;
+            wofs[i] = min(max(w, 0), W - 1) - w_;
+        }
+        const float* __restrict__ xc = x + v;
+        float xv[27];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+        for (int t = 0; t < 27; ++t) xv[t] = xc[dofs[t / 9] + hofs[(t / 3) % 3] + wofs[t % 3]];
+        float acc[COUT];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const float xt = (vd[t / 9] && vh[(t / 3) % 3] && vw[t % 3]) ? xv[t] : 0.f;
+        for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xt, wt[t * COUT + c], acc[c]);
-    }
-    if (live) {
+        for (int t = 0; t < 27; ++t) {
+            const float xt = (vd[t / 9] && vh[(t / 3) % 3] && vw[t % 3]) ? xv[t] : 0.f;
 #pragma unroll
-        for (int c = 0; c < COUT; c += 4)
-            *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-    }
-    if (slots) {
-        // y is the complete output gradient of the BatchNorm+ReLU block in front of this layer (bn_raw = that block's raw
-        // output): its backward statistics (sum dyh, sum dyh*xhat) per channel -> wave sums -> workgroup sums -> one slot row
-        float sv[2 * COUT];
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xt, wt[t * COUT + c], acc[c]);
+        }
+        if (live) {
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) {
-            float d1 = 0.f, d2 = 0.f;
-            if (live) {
+            for (int c = 0; c < COUT; c += 4)
+                *reinterpret_cast<float4*>(y + v * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+        }
+        if (slots && live) {
+            // y is the complete output gradient of the BatchNorm+ReLU block in front of this layer (bn_raw = that block's raw
+            // output): its backward statistics (sum dyh, sum dyh*xhat) per channel, summed over the thread's voxels
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
                 const float4 rq = rwq[c / 4];
                 const float rw = (c & 3) == 0 ? rq.x : ((c & 3) == 1 ? rq.y : ((c & 3) == 2 ? rq.z : rq.w));
-                d1 = (rw * bn_stats[2 * COUT + c] + bn_stats[3 * COUT + c] > 0.f) ? acc[c] : 0.f;
-                d2 = d1 * ((rw - bn_stats[c]) * bn_stats[COUT + c]);
+                const float d1 = (rw * bn_stats[2 * COUT + c] + bn_stats[3 * COUT + c] > 0.f) ? acc[c] : 0.f;
+                sv[c] += d1;
+                sv[COUT + c] += d1 * ((rw - bn_stats[c]) * bn_stats[COUT + c]);
             }
-            sv[c] = d1;
-            sv[COUT + c] = d2;
         }
+    }
+    if (slots) {
+        // -> wave sums -> workgroup sums -> one slot row
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int k = 0; k < 2 * COUT; ++k) {
@@ -1476,6 +1482,7 @@ static int pick_cc(int geom, int cin) {
 // small chunks ARE the pipeline of these launches: 24 KB of LDS per workgroup lets several workgroups share a CU and overlap each other's
 // stage / MFMA phases, while a 78-128 KB tile leaves one workgroup per CU alone with a 28-load staging phase and nothing to hide it.
 int g_conv_cc_wide = 0;
+int g_conv_cin1_vpt = 1;   // tuning knob "cin1_vpt": voxels per thread of the Cout == 1 layer's input gradient (1 = default; 4 = four from 1 M voxels on, 5 = always four).  MEASURED AND REJECTED (round 6, profiles/r06_run13_*): four voxels per thread amortise the wave reduction of the backward statistics but serialise the loads of a quarter as many workgroups: 0.090 -> 0.123 ms, step 4.726 -> 4.749
 static int pick_cc_k(int geom, int kgeom, int cin) {
     if (g_conv_cc_wide) {
         if (kgeom == GEOM_S1_SMALL && (cin == 32 || cin == 64)) return cin;
@@ -1774,9 +1781,13 @@ static int run_cin1(const IgemmPlan& p, const float* gy, const float* w, float* 
         MVS_REQUIRE(C == 8 || C == 16, MVS_ERR_UNSUPPORTED, "conv3d_dgrad(Cout=1): Cin must be 8 or 16, got %d", C);
     }
     const size_t total = (size_t)p.B * p.Di * p.Hi * p.Wi;
-    dim3 grid((unsigned)((total + 255) / 256));
-    if (C == 8) MVS_LAUNCH((conv_cin1_kernel<8>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
-    else MVS_LAUNCH((conv_cin1_kernel<16>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    // knob "cin1_vpt": 4 = four voxels per thread from 1 M voxels on (small volumes keep one: they need the workgroups), 5 = always (tests), 1 = never
+    const int vpt = (g_conv_cin1_vpt == 5 || (g_conv_cin1_vpt == 4 && total >= (size_t)1 << 20)) ? 4 : 1;
+    dim3 grid((unsigned)((total + 256 * vpt - 1) / (256 * vpt)));
+    if (C == 8 && vpt == 4) MVS_LAUNCH((conv_cin1_kernel<8, 4>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    else if (C == 8) MVS_LAUNCH((conv_cin1_kernel<8, 1>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    else if (vpt == 4) MVS_LAUNCH((conv_cin1_kernel<16, 4>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
+    else MVS_LAUNCH((conv_cin1_kernel<16, 1>), grid, dim3(256), 0, st, gy, (const float*)ws, gx, p.B, p.Di, p.Hi, p.Wi, ep.bn_raw, ep.bn_stats, ep.slots, ep.nslots);
     return mvs_check_launch("conv_cin1");
 }
 

@@ -299,10 +299,13 @@ def test_conv3d_dgrad_with_summand_and_batchnorm_backward_statistics(emul_lib, c
     stats = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
     slots = torch.zeros((8, 2, cin), dtype=torch.float64)
     emul_lib.call("mvs_set_tuning", b"side_pre", side_pre)
+    if cout == 1:      # the direct Cin == 1 kernel: one voxel per thread (side_pre = 1) and four (knob cin1_vpt = 5: always; measured slower on the GPU, off by default)
+        emul_lib.call("mvs_set_tuning", b"cin1_vpt", 1 if side_pre else 5)
     try:
         gx = ops.conv3d_dgrad(gy, w, x_shape, stride, transposed, add=add, bn=(raw.detach(), stats, slots))
     finally:
         emul_lib.call("mvs_set_tuning", b"side_pre", 1)
+        emul_lib.call("mvs_set_tuning", b"cin1_vpt", 1)
     assert float((gx - gtot).abs().max()) < 5e-4
     view = lambda v: v.view(1, cin, 1, 1, 1)
     dyh = gtot * (raw.detach() * view(stats[2]) + view(stats[3]) > 0)
