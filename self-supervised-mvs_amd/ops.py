@@ -382,8 +382,10 @@ def conv3d_forward_bf16(x, weight, stride=1, transposed=False, scale=None, shift
         if skip.dtype != torch.bfloat16 or skip.shape != y.shape:
             raise ValueError("skip must be bf16 with the output's shape %s, got %s %s" % (tuple(y.shape), skip.dtype, tuple(skip.shape)))
         skip = as_cl3(skip)
+    scale_c = None if scale is None else scale.contiguous()      # (locals: pointers handed to the C ABI stay valid until the call is made)
+    shift_c = None if shift is None else shift.contiguous()
     lib.call("mvs_conv3d_bf16_fwd", _p(x), _p(wt), _p(y), _p(ws), b, d, h, w, cin, cout, stride, int(transposed),
-             _p(None if scale is None else scale.contiguous()), _p(None if shift is None else shift.contiguous()), _p(skip),
+             _p(scale_c), _p(shift_c), _p(skip),
              int(relu), int(out_f32), _stream(x), tag=_ctag("fwdT_bf16" if transposed else "fwd_bf16", cin, cout, stride, b, d, h, w))
     return y
 
@@ -1451,10 +1453,11 @@ class FeatureExtractorFn(torch.autograd.Function):
                 (slots,) = stat_slots(x, 1, 1, plan.slot_doubles // 2 + 1, 1)      # one zero-filled run of doubles for every block's rows
                 out = torch.empty(plan.out_shape, dtype=torch.float32, device=dev, memory_format=CL2)
                 ab, sb = arena.data_ptr(), slots.data_ptr()
+                fbc = fb.contiguous()                 # (a local: the pointer must stay valid until the call has been made)
                 lib.call("mvs_feature_fwd", n, plan.blocks, plan.N, groups, _p(x), _ptr_array(ws_), _ptr_array(gammas), _ptr_array(betas),
                          _ptr_array([params[5 * i + 3] for i in range(n)]), _ptr_array([params[5 * i + 4] for i in range(n)]),
                          _ptrs(ab, plan.packed_off), _ptrs(ab, plan.raw_off), ab + 4 * plan.ylast_off, _ptrs(ab, plan.stats_off),
-                         _ptrs(sb, plan.sf_off, 8), plan.nslots, _p(fw), _p(fb.contiguous()), plan.close_cout, plan.fwcl,
+                         _ptrs(sb, plan.sf_off, 8), plan.nslots, _p(fw), _p(fbc), plan.close_cout, plan.fwcl,
                          ab + 4 * plan.wsclose_off, _p(out), _stream(x))
                 ctx.cfg, ctx.groups, ctx.slots_used, ctx.fused, ctx.own, ctx.c_entry, ctx.plan = cfg, groups, False, True, True, True, plan
                 ctx.save_for_backward(x, fw, *ws_, arena, slots)
@@ -1767,7 +1770,8 @@ class SoftArgminConf(torch.autograd.Function):
         lib = _lib_for(logits)
         b, nd, h, w = logits.shape
         gl = torch.empty_like(logits)
-        lib.call("mvs_softargmin_conf_bwd", _p(gdepth.contiguous()), _p(logits), _p(dv), ctx.per_pixel, _p(depth),
+        gdepth = gdepth.contiguous()
+        lib.call("mvs_softargmin_conf_bwd", _p(gdepth), _p(logits), _p(dv), ctx.per_pixel, _p(depth),
                  _p(smax), _p(ssum), b, nd, h, w, _p(gl), _stream(logits))
         return gl, None
 
