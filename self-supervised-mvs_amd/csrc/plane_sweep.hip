@@ -269,6 +269,164 @@ __global__ __launch_bounds__(256) void plane_sweep_variance_fwd_cached_kernel(Sw
     }
 }
 
+// Forward, register-cached taps + PROJECTION TABLE (round 6; per-plane hypotheses).  In the kernel above every one of the LPP lanes of a
+// pixel repeats the pixel's projective arithmetic for every view and plane: 16 instructions of projection + 6 of weights per (view,
+// plane) -- at 7 views that is 52 % of a VALU-bound kernel (84 % issue: DESIGN.md section 4).  Here the 64 / LPP pixels of a wave and the
+// NS_T views form <= 64 (pixel, view) PAIRS and lane l of the wave computes pair (pixel l % PPW, view l / PPW) ONCE per plane -- base texel
+// and the four bilinear weights -- into a per-wave LDS table that the lanes of the pixel read back (two broadcast reads per view).  The
+// table is double-buffered by plane parity and filled one plane ahead, so a plane's reads never wait for its own writes; a wave's DS
+// operations execute in order: no barrier in the plane loop.  Same arithmetic on the same values as the kernel above: bit-identical.
+// Round 3's "shared projection" (DPP / ds_bpermute exchange between the lanes of a pixel, each still walking all views) was slower;
+// this form divides the work instead of exchanging it -- and is slower too (knob "fwd_pt", off: N=3 0.108 -> 0.117 ms, N=7 bf16 2.56 ->
+// 2.95 with 26 % fewer vector instructions per plane): the table's LDS round trip and the wave-wide dependency on the slowest pair weigh
+// more than the instructions saved.  K1's "84 % VALU issue" is a symptom of how its waves overlap, not a budget that buys time back.
+template <int C, int NS_T, int CPT, bool BF = false>
+__global__ __launch_bounds__(256) void plane_sweep_variance_fwd_pt_kernel(SweepArgs a) {
+    static_assert(!BF || CPT == 8 || CPT == 4, "bf16 store: 4 or 8 consecutive channels per thread");
+    constexpr int V = CPT / 4;
+    constexpr int LPP = TileC<C, CPT>::LPP, PPB = TileC<C, CPT>::PPB, PPW = 64 / LPP;
+    static_assert(PPW * NS_T <= 64, "the (pixel, view) pairs of a wave must fit its 64 lanes");
+    const int TW = a.tile_w, TH = PPB / TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tid % LPP, pl = tid / LPP;
+    const SweepWg wg = sweep_wg(a);
+    const int tx0 = (wg.tile % a.tiles_x) * TW, ty0 = (wg.tile / a.tiles_x) * TH;
+    const int xr = tx0 + pl % TW, yr = ty0 + pl / TW;
+    const int b = wg.b;
+    const int d0 = wg.slab * a.dslab;
+    const int d1 = min(a.D, d0 + a.dslab);
+    __shared__ float s_dep[512];                                         // the launcher keeps a slab <= 512 planes
+    __shared__ __attribute__((aligned(16))) float s_w[4][2][NS_T][PPW][4];   // [wave][plane parity][view][pixel]: w00, w01, w10, w11
+    __shared__ __attribute__((aligned(8))) int s_xy[4][2][NS_T][PPW][2];    //                                   : x0, y0
+    for (int i = tid; i < d1 - d0; i += 256) s_dep[i] = a.depth[b * a.D + d0 + i];
+    __syncthreads();
+    // a lane outside the image stays (the wave shares the table); it works on a clamped pixel and does not store
+    const bool live = xr < a.W && yr < a.H;
+    const int x = min(xr, a.W - 1), y = min(yr, a.H - 1);
+    const int HW = a.H * a.W, pix = y * a.W + x;
+    const int cq = BF ? CPT * q : 4 * q;
+    constexpr int ck = BF ? 4 : 4 * LPP;
+    const size_t fbase = (size_t)b * HW * C + cq;
+    float4 r[V], r2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        r[k] = ld4(a.ref + fbase + (size_t)pix * C + ck * k);
+        r2[k] = make_float4(r[k].x * r[k].x, r[k].y * r[k].y, r[k].z * r[k].z, r[k].w * r[k].w);
+    }
+    const float inv_n = 1.0f / (float)(NS_T + 1);
+    // ---- this lane as the owner of ONE (pixel, view) pair of its wave ----
+    const int pp = lane % PPW, ps = lane / PPW;                          // pair: pixel pp of the wave, view ps (< NS_T: a real pair)
+    const bool pair = ps < NS_T;
+    const int ppl = wave * PPW + pp;                                      // the pair's pixel within the workgroup's tile
+    const float pxf = (float)min(tx0 + ppl % TW, a.W - 1), pyf = (float)min(ty0 + ppl / TW, a.H - 1);
+    const float* __restrict__ R = a.rot + ((size_t)b * NS_T + (pair ? ps : 0)) * 9;
+    const float* __restrict__ T = a.trans + ((size_t)b * NS_T + (pair ? ps : 0)) * 3;
+    const float prx = fmaf(R[0], pxf, fmaf(R[1], pyf, R[2]));
+    const float pry = fmaf(R[3], pxf, fmaf(R[4], pyf, R[5]));
+    const float prz = fmaf(R[6], pxf, fmaf(R[7], pyf, R[8]));
+    const float ptx = T[0], pty = T[1], ptz = T[2];
+    auto fill = [&](int d, int par) __attribute__((always_inline)) {
+        if (!pair) return;
+        const float dep = s_dep[d - d0];
+        const float zz = fmaf(prz, dep, ptz);
+        float iz = MVS_RCP(zz);
+        iz = fmaf(fmaf(-zz, iz, 1.0f), iz, iz);
+        const float ix = fmaf(fmaf(prx, dep, ptx) * iz, a.sx, a.ox);
+        const float iy = fmaf(fmaf(pry, dep, pty) * iz, a.sy, a.oy);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float wx = ix - fx, wy = iy - fy;
+        const float ex = 1.0f - wx, ey = 1.0f - wy;
+        *reinterpret_cast<float4*>(&s_w[wave][par][ps][pp][0]) = make_float4(ey * ex, ey * wx, wy * ex, wy * wx);
+        s_xy[wave][par][ps][pp][0] = MVS_F2I(fx);
+        s_xy[wave][par][ps][pp][1] = MVS_F2I(fy);
+    };
+    int cx[NS_T], cy[NS_T];
+    float4 t00[NS_T][V], t01[NS_T][V], t10[NS_T][V], t11[NS_T][V];
+#pragma unroll
+    for (int s = 0; s < NS_T; ++s) {
+        cx[s] = -0x40000000; cy[s] = -0x40000000;
+#pragma unroll
+        for (int k = 0; k < V; ++k) t00[s][k] = t01[s][k] = t10[s][k] = t11[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int mp = pl % PPW;                                              // this lane's pixel within its wave's table
+    fill(d0, 0);
+    for (int d = d0; d < d1; ++d) {
+        const int par = (d - d0) & 1;
+        MVS_WAVE_SYNC();                                                 // every lane has finished plane d - 1's reads of the other buffer
+        if (d + 1 < d1) fill(d + 1, par ^ 1);                            // one plane ahead, into the buffer plane d - 1 has finished with
+        MVS_WAVE_SYNC();
+        float4 S[V], Q[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { S[k] = a.ms_alias ? r2[k] : r[k]; Q[k] = r2[k]; }
+        // every view's table entry first (2 x NS_T reads in flight, ONE wait): read inside the view loop, each view's block test waited
+        // for its own LDS round trip
+        float4 wts[NS_T];
+        int x0s[NS_T], y0s[NS_T];
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            wts[s] = *reinterpret_cast<const float4*>(&s_w[wave][par][s][mp][0]);
+            x0s[s] = s_xy[wave][par][s][mp][0]; y0s[s] = s_xy[wave][par][s][mp][1];
+        }
+        MVS_SCHED_FENCE();
+#pragma unroll
+        for (int s = 0; s < NS_T; ++s) {
+            const float4 wt = wts[s];
+            const int x0 = x0s[s], y0 = y0s[s];
+            if (x0 != cx[s] || y0 != cy[s]) {
+                cx[s] = x0; cy[s] = y0;
+                const bool xin0 = x0 >= 0 && x0 < a.W, xin1 = x0 + 1 >= 0 && x0 + 1 < a.W;
+                const bool yin0 = y0 >= 0 && y0 < a.H, yin1 = y0 + 1 >= 0 && y0 + 1 < a.H;
+                const float* __restrict__ f = a.src[s] + fbase + ((long)y0 * a.W + x0) * C;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    t00[s][k] = (xin0 && yin0) ? ld4(f + ck * k) : z4;
+                    t01[s][k] = (xin1 && yin0) ? ld4(f + C + ck * k) : z4;
+                    t10[s][k] = (xin0 && yin1) ? ld4(f + a.W * C + ck * k) : z4;
+                    t11[s][k] = (xin1 && yin1) ? ld4(f + a.W * C + C + ck * k) : z4;
+                }
+            }
+            const float w00 = wt.x, w01 = wt.y, w10 = wt.z, w11 = wt.w;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float4 v;
+                v.x = fmaf(t11[s][k].x, w11, fmaf(t10[s][k].x, w10, fmaf(t01[s][k].x, w01, t00[s][k].x * w00)));
+                v.y = fmaf(t11[s][k].y, w11, fmaf(t10[s][k].y, w10, fmaf(t01[s][k].y, w01, t00[s][k].y * w00)));
+                v.z = fmaf(t11[s][k].z, w11, fmaf(t10[s][k].z, w10, fmaf(t01[s][k].z, w01, t00[s][k].z * w00)));
+                v.w = fmaf(t11[s][k].w, w11, fmaf(t10[s][k].w, w10, fmaf(t01[s][k].w, w01, t00[s][k].w * w00)));
+                S[k].x += v.x; S[k].y += v.y; S[k].z += v.z; S[k].w += v.w;
+                Q[k].x = fmaf(v.x, v.x, Q[k].x); Q[k].y = fmaf(v.y, v.y, Q[k].y);
+                Q[k].z = fmaf(v.z, v.z, Q[k].z); Q[k].w = fmaf(v.w, v.w, Q[k].w);
+            }
+        }
+        const size_t oidx = (((size_t)b * a.D + d) * HW + pix) * C + cq;
+        float* __restrict__ outp = a.var + oidx;
+        unsigned packed[2 * V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float4 o;
+            float m;
+            m = S[k].x * inv_n; o.x = Q[k].x * inv_n - m * m;
+            m = S[k].y * inv_n; o.y = Q[k].y * inv_n - m * m;
+            m = S[k].z * inv_n; o.z = Q[k].z * inv_n - m * m;
+            m = S[k].w * inv_n; o.w = Q[k].w * inv_n - m * m;
+            if (BF) {
+                packed[2 * k] = mvs_cvt_pk_bf16(o.x, o.y);
+                packed[2 * k + 1] = mvs_cvt_pk_bf16(o.z, o.w);
+                continue;
+            }
+            if (!live) continue;
+            if (a.nt_store) MVS_NT_STORE4(outp + ck * k, o);
+            else *reinterpret_cast<float4*>(outp + ck * k) = o;
+        }
+        if (BF && live) {
+            if (V == 2) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.var) + oidx) =
+                            make_uint4(packed[0], packed[1], packed[2 % (2 * V)], packed[3 % (2 * V)]);
+            else { uint2 o2; o2.x = packed[0]; o2.y = packed[1]; *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.var) + oidx) = o2; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward.  With Sm = S/N:  dL/dv_i = g*(2/N)*(v_i - Sm);
 //   dL/dr = sum_d g*(2/N)*(r - Sm)            (MVSNet)
@@ -1246,6 +1404,7 @@ static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 
 static int g_sweep_xcd = 0;           // knob "sweep_xcd": XCD-compact workgroup order of the cached forward and the per-wave-window backward
 static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
+static int g_sweep_fwd_pt = 0;        // knob "fwd_pt": the cached forward with the per-wave projection table (plane_sweep_variance_fwd_pt_kernel).  MEASURED AND REJECTED (round 6, profiles/r06_run15_*, r06_run16_*): 9-26 % fewer vector instructions per plane, bit-identical, and SLOWER at every view count -- N=3 0.108 -> 0.117 ms, N=5 0.208 -> 0.226, N=7 bf16 2.56 -> 2.95
 static int g_sweep_bwd_gd34 = 0;      // knob "bwd_gd34": 3-4 source views with the upstream gradient requested two planes ahead (as 1-2 views run), 2 waves/SIMD
 static int g_sweep_bwd_gpf = 0;       // knob "bwd_gpf": where the per-wave-window backward requests the next planes' upstream gradient: 0 top of the group, 1 after the plane's gathers
 int g_sweep_bwd_nowin = 0;            // knob "bwd_nowin" (tests): 1 = no LDS windows, every flush through global atomics
@@ -1259,7 +1418,7 @@ static const MvsKnob* mvs_find_knob(const char* key) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"cc_wide", &g_conv_cc_wide, 0, 1}, {"cin1_vpt", &g_conv_cin1_vpt, 1, 5}, {"k8", &g_conv_c8, 0, 15},             {"cout1_d4", &g_conv_cout1_d4, 0, 3}, {"bf16_dp", &g_conv_bf16_dp, 0, 1}, {"conv2d_pp", &g_conv2d_pp, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20}, {"wgrad2d_batch", &g_conv2d_wgrad_batch_groups, 1, 4096},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 2},
         {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1}, {"conv_pers", &g_conv_pers, 0, 1}, {"conv_pers_min", &g_conv_pers_min_wgs, 0, 1 << 30}, {"conv_pers_groups", &g_conv_pers_groups, 0, 4096}, {"conv_pers_nw", &g_conv_pers_nw, 4, 8}, {"wgrad_pers", &g_conv_wgrad_pers, 0, 1}, {"wgrad_small", &g_conv_wgrad_small, 0, 3}, {"wgrad_groups", &g_conv_wgrad_groups, 1, 768}, {"wgrad8_groups", &g_conv_wgrad8_groups, 1, 512}, {"wgrad8_gs", &g_conv_wgrad8_gs, 0, 2}, {"wgrad8_nch", &g_conv_wgrad8_nch, 1, 2}, {"cout1_h4", &g_conv_cout1_h4, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"bwd_gd34", &g_sweep_bwd_gd34, 0, 1}, {"bwd_gpf", &g_sweep_bwd_gpf, 0, 1}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"bwd_gd34", &g_sweep_bwd_gd34, 0, 1}, {"fwd_pt", &g_sweep_fwd_pt, 0, 1}, {"bwd_gpf", &g_sweep_bwd_gpf, 0, 1}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1},
     };
     for (const MvsKnob& k : knobs)
         if (strcmp(key, k.name) == 0) return &k;
@@ -1286,6 +1445,17 @@ extern "C" int mvs_get_tuning(const char* key, int* value) {
     }
     *value = *k->var;
     return MVS_OK;
+}
+
+// the projection-table forward serves a (C, views, channels per thread) combination when the (pixel, view) pairs of a wave fit its 64 lanes
+template <int C, int N, int CPT, bool BF>
+static bool launch_fwd_pt(const SweepArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr ((64 / (C / CPT)) * N <= 64) {
+        MVS_LAUNCH((plane_sweep_variance_fwd_pt_kernel<C, N, CPT, BF>), grid, dim3(256), 0, st, a);
+        return true;
+    } else {
+        return false;
+    }
 }
 
 template <int C>
@@ -1338,7 +1508,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
             dim3 gridb(a.tiles_x * a.tiles_y, mvs_cdiv(a.D, a.dslab), a.B);
 #define MVS_BF_CASE(N, CPTN)                                                                                                   \
     case N:                                                                                                                    \
-        if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 2>), gridb, block, 0, st, a);       \
+        if (dl && g_sweep_fwd_pt && launch_fwd_pt<CB, N, CPTN, true>(a, gridb, st)) {}                                         \
+        else if (dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 2>), gridb, block, 0, st, a);  \
         else if (dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 1>), gridb, block, 0, st, a);       \
         else MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<CB, N, CPTN, true, 0>), gridb, block, 0, st, a);               \
         break;
@@ -1349,6 +1520,8 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
 #define MVS_CACHED_CASE(N)                                                                                      \
     case N:                                                                                                     \
         if (c16) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT16>), gridc, block, 0, st, a);    \
+        else if (c8 && dl && g_sweep_fwd_pt && launch_fwd_pt<C, N, CPT8, false>(a, gridc, st)) {}              \
+        else if (!c8 && dl && g_sweep_fwd_pt && launch_fwd_pt<C, N, 4, false>(a, gridc, st)) {}                \
         else if (c8 && dl == 2) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, 2>), gridc, block, 0, st, a); \
         else if (c8 && dl) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8, false, 1>), gridc, block, 0, st, a); \
         else if (c8) MVS_LAUNCH((plane_sweep_variance_fwd_cached_kernel<C, N, CPT8>), gridc, block, 0, st, a); \

@@ -188,15 +188,18 @@ def test_plane_sweep_fwd_depth_staging_forms_agree(dev, c, ns, d):
     depth = (430 + 9.0 * torch.arange(d)).unsqueeze(0).repeat(b, 1)
     vols = []
     try:
-        for dl in (0, 1, 2):
+        # (round 6: knob fwd_pt = 1 sends fwd_dl != 0 to the projection-table kernel -- measured slower, off by default; the fourth volume is the cached kernel's dl = 1 form)
+        for dl, pt in ((0, 1), (1, 1), (2, 1), (1, 0)):
             lib.call("mvs_set_tuning", b"fwd_dl", dl)
+            lib.call("mvs_set_tuning", b"fwd_pt", pt)
             with torch.no_grad():
                 vols.append(ops.plane_sweep_variance(ref.to(dev), [s.to(dev) for s in srcs], rot.to(dev), trans.to(dev), depth.to(dev)).cpu())
     finally:
         lib.call("mvs_set_tuning", b"fwd_dl", 1)
+        lib.call("mvs_set_tuning", b"fwd_pt", 0)
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((vols[1] - exp).abs().max()) < 2e-4
-    assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2])
+    assert torch.equal(vols[0], vols[1]) and torch.equal(vols[1], vols[2]) and torch.equal(vols[1], vols[3])
 
 
 @pytest.mark.parametrize("c,ns,d,hw,per_pixel", [(8, 1, 1, (2, 3), False), (8, 1, 1, (2, 2), True), (16, 2, 2, (3, 2), False),
