@@ -660,6 +660,7 @@ def main():
     t_gap = time.perf_counter()
     barrier()
     t_gap = time.perf_counter() - t_gap
+    _ms0 = torch.cuda.memory_stats(dev)        # hipMalloc / hipFree calls of the caching allocator inside the timed region (should be 0: each one stalls the launch thread for milliseconds)
     if roctx is not None:
         roctx.roctxProfilerResume(0)
     t0 = time.perf_counter()
@@ -681,6 +682,9 @@ def main():
     host_steps = sorted((b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:]))
     barrier()
     dt = time.perf_counter() - t0
+    _ms1 = torch.cuda.memory_stats(dev)
+    alloc_diag = {k: int(_ms1.get(k, 0) - _ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc_diag["reserved_bytes_end"] = int(_ms1.get("reserved_bytes.all.current", 0))
     if roctx is not None:
         roctx.roctxProfilerPause(0)
     gc.enable()
@@ -1021,7 +1025,7 @@ def main():
                            ("end of backward pass (library default: MVSNet's tail node, ops.DeferredJoinFn)" if (_ops.TAIL_JOIN and async_wgrad and args.config in (2, 3))
                             else "inside the regulariser node")) if train else None,
             "headline_mode_is_library_default": bool(async_wgrad and not defer_join) if train else None,
-            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "allocator_in_timed_region": alloc_diag,
             "host_enqueue_ms_per_step_median_max": [host_steps[len(host_steps) // 2], host_steps[-1]], "wgrad_streams": args.wgrad_streams, "side_stream_priority": args.side_priority,
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "ms_per_step_library_default": (ms_library_default if (async_wgrad and defer_join) else (dt / args.steps * 1e3 if async_wgrad else ms_other_mode)) if train else None,

@@ -1402,7 +1402,7 @@ static int g_sweep_bwd_variant = 0;   // knob "sweep_bwd": 0 = per-wave windows 
 static int g_sweep_bwd_cpt = 4;       // knob "bwd_cpt": accepted and ignored (the 8-channels-per-thread form was measured slower and removed)
 static int g_sweep_bwd_pf = 0;        // knob "bwd_pf": 1 = block lookahead for 1-2 source views, 2 = ONE wave per SIMD for 3-4 source views
 static int g_sweep_xcd = 0;           // knob "sweep_xcd": XCD-compact workgroup order of the cached forward and the per-wave-window backward
-static int g_sweep_fwd_dl = 1;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + in-block gather waits (2); 0: the round-1 loop
+static int g_sweep_fwd_dl = 2;        // knob "fwd_dl": forward with LDS-staged per-plane depths (1), + all views' re-gathers in flight before the first sample (2, default since round 6: with the 4-wide tile -5.6 % at N = 3, -4.4 % at N = 5); 0: the round-1 loop
 static int g_sweep_bwd_gd = 2;        // knob "bwd_gd": 2 = upstream gradient requested two planes ahead at 2 waves/SIMD (1-2 source views), 0 = rotating set at 3 waves/SIMD
 static int g_sweep_fwd_pt = 0;        // knob "fwd_pt": the cached forward with the per-wave projection table (plane_sweep_variance_fwd_pt_kernel).  MEASURED AND REJECTED (round 6, profiles/r06_run15_*, r06_run16_*): 9-26 % fewer vector instructions per plane, bit-identical, and SLOWER at every view count -- N=3 0.108 -> 0.117 ms, N=5 0.208 -> 0.226, N=7 bf16 2.56 -> 2.95
 static int g_sweep_bwd_gd34 = 0;      // knob "bwd_gd34": 3-4 source views with the upstream gradient requested two planes ahead (as 1-2 views run), 2 waves/SIMD
@@ -1475,18 +1475,21 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         // measured 3.99 ms against 2.98 ms with 4 channels at config 5 (N = 7, 1600x1184, D = 256; profiles/r02_run11_*)
         const bool c8 = !c16 && variant >= 3 && CPT8 == 8 && a.NS <= 4;
         const int ppb = c16 ? TileC<C, CPT16>::PPB : (c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB);
-        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? TileC<C, CPT8>::TW : TileC<C, 4>::TW));
+        // (round 6, 8 channels per thread: a 4-wide x 16-high pixel tile instead of 8 x 8 -- with the merged re-gather form below K1 at
+        //  config 2 0.1141 -> 0.1077 ms, at N = 5 0.2034 -> 0.1945, six interleaved rounds each: profiles/r06_run18_k1_knobs.log)
+        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? 4 : TileC<C, 4>::TW));
         if (tw > ppb) tw = ppb;
         while (ppb % tw) --tw;
         a.tile_w = tw;
         a.tiles_x = mvs_cdiv(a.W, tw);
         a.tiles_y = mvs_cdiv(a.H, ppb / tw);
         if (g_sweep_dslab <= 0) {
-            // >= ~5000 workgroups, >= 8 planes each: measured optimum 12-16 planes at config 2
-            // (profiles/r01_run16_k1_depth_slab_sweep.log); fewer, longer workgroups lose to load imbalance
+            // >= ~2500 workgroups, >= 8 planes each (rounds 1-5, 8 x 8 tiles: ~5000 workgroups, 12-16 planes:
+            // profiles/r01_run16_k1_depth_slab_sweep.log); fewer, longer workgroups lose to load imbalance
             const long tiles = (long)a.tiles_x * a.tiles_y * a.B;
             int slab = a.D;
-            while (slab > 8 && tiles * mvs_cdiv(a.D, slab) < 5000) slab = (slab + 1) / 2;
+            // (round 6, with the 4-wide tile: 24 planes per workgroup at config 2's 320 tiles -- N = 3 0.1092 -> 0.1076 ms, N = 5 0.1944 -> 0.1880 against 12 planes)
+            while (slab > 8 && tiles * mvs_cdiv(a.D, slab) < 2500) slab = (slab + 1) / 2;
             a.dslab = slab;
         }
         const int dl = a.per_pixel ? 0 : g_sweep_fwd_dl;   // knob "fwd_dl": 1 = LDS-staged depths, 2 = + in-block gather waits (per-plane hypotheses)

@@ -530,6 +530,21 @@ def _side_stream(dev):
 JOIN_TRACE = None        # diagnostics (bench.py --step-events): a list -> (main-stream event, side-stream event) recorded right before each join
 
 
+# Tensors the side stream is still reading / writing when the node that allocated them returns (deferred join): kept ALIVE here until
+# the join instead of being handed to Tensor.record_stream.  record_stream makes the caching allocator poll an event before it may
+# reuse the block; whether the block is free when the next request comes then depends on timing, the pool fragments (a 500 MB block
+# split for a 126 MB request, the next 500 MB request then needs a fresh hipMalloc) and keeps GROWING: 6-18 hipMalloc calls inside
+# bench.py's 20 timed steps, 10-21 GB reserved for a 1.6 GB step, launch-thread stalls of 16-29 ms each
+# (profiles/r06_run20_allocator_before.txt).  Freed at the join, the blocks go back to the main stream's pool in stream order: the
+# same blocks serve the same requests every step.  Keyed by (device, main stream): the join of one host thread's stream must not
+# release what another thread's side-stream work still uses.
+_HELD = {}
+
+
+def _hold(idx, main, tensors) -> None:
+    _HELD.setdefault((idx, main.cuda_stream), []).extend(tensors)
+
+
 def _join_side(main, idx) -> None:
     for sd in _SIDE_STREAMS.get(idx, ()):
         if JOIN_TRACE is not None:
@@ -538,6 +553,7 @@ def _join_side(main, idx) -> None:
             es.record(sd)
             JOIN_TRACE.append((em, es))
         main.wait_stream(sd)
+    _HELD.pop((idx, main.cuda_stream), None)     # everything enqueued on `main` from here on is ordered behind the side streams' work
 _WEIGHT_USES = {}       # device index -> {weight data_ptr: forward uses whose backward node has not run yet}
 _WEIGHT_MULTI = {}      # device index -> {weight data_ptr} that had > 1 outstanding use at some point (until all of them have run)
 _BWD_OPEN = {}          # device index -> [main stream, side stream used?] while a backward pass with our nodes is running
@@ -1052,10 +1068,10 @@ class UNetRegulariserFn(torch.autograd.Function):
         if need[2 + 5 * n + 1]:
             grads[5 * n + 1] = gy.sum().reshape(1) if gy.shape[1] == 1 else gy.sum(dim=(0, 2, 3, 4))
         if used.value and side is not None:
-            for ten in [x, arena, work, wws, gy] + [t for t in gws if t is not None]:
-                ten.record_stream(side)
-            if deferred:                       # ONE join at the end of the whole backward pass (autograd engine callback)
+            # (not deferred: mvs_unet_bwd has made the main stream wait for the side stream before it returned -- nothing to keep)
+            if deferred:                       # ONE join at the end of the whole backward pass (tail node / autograd engine callback)
                 idx = dev.index
+                _hold(idx, main, [x, arena, work, wws, gy])       # (the weight gradients themselves go to autograd and outlive the join)
                 ent = _BWD_OPEN.get(idx)
                 if ent is None:
                     ent = _BWD_OPEN[idx] = [main, False]

@@ -385,7 +385,7 @@ def test_plane_sweep_fwd_depth_staging_forms_agree(emul_lib, c, ns):
             with torch.no_grad():
                 vols.append(ops.plane_sweep_variance(ref, srcs, rot, trans, depth).clone())
     finally:
-        emul_lib.call("mvs_set_tuning", b"fwd_dl", 1)
+        emul_lib.call("mvs_set_tuning", b"fwd_dl", 2)
         emul_lib.call("mvs_set_tuning", b"fwd_pt", 0)
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((vols[1] - exp).abs().max()) < 2e-4
@@ -1192,7 +1192,7 @@ def test_plane_sweep_xcd_compact_order_and_merged_regather(emul_lib, ns, hw, d):
     try:
         for key, knobs in (("base", {}), ("xcd", {b"sweep_xcd": 1}), ("both", {b"sweep_xcd": 1, b"fwd_dl": 2})):
             emul_lib.call("mvs_set_tuning", b"sweep_xcd", knobs.get(b"sweep_xcd", 0))
-            emul_lib.call("mvs_set_tuning", b"fwd_dl", knobs.get(b"fwd_dl", 1))
+            emul_lib.call("mvs_set_tuning", b"fwd_dl", knobs.get(b"fwd_dl", 2))
             emul_lib.call("mvs_set_tuning", b"dslab", 4)        # several slabs per tile: the slab index goes through the re-deal too
             emul_lib.call("mvs_set_tuning", b"bwd_dslab", 4)
             fr = [t.clone().requires_grad_(True) for t in [ref] + srcs]
@@ -1202,7 +1202,7 @@ def test_plane_sweep_xcd_compact_order_and_merged_regather(emul_lib, ns, hw, d):
                 v16 = ops.plane_sweep_variance(ref, srcs, rot, trans, depth, out_dtype=torch.bfloat16)
             res[key] = (var.detach(), v16, grads)
     finally:
-        for k, v in ((b"sweep_xcd", 0), (b"fwd_dl", 1), (b"dslab", 0), (b"bwd_dslab", 0)):
+        for k, v in ((b"sweep_xcd", 0), (b"fwd_dl", 2), (b"dslab", 0), (b"bwd_dslab", 0)):
             emul_lib.call("mvs_set_tuning", k, v)
     for key in ("xcd", "both"):
         assert torch.equal(res[key][0], res["base"][0]), key

@@ -195,7 +195,7 @@ def test_plane_sweep_fwd_depth_staging_forms_agree(dev, c, ns, d):
             with torch.no_grad():
                 vols.append(ops.plane_sweep_variance(ref.to(dev), [s.to(dev) for s in srcs], rot.to(dev), trans.to(dev), depth.to(dev)).cpu())
     finally:
-        lib.call("mvs_set_tuning", b"fwd_dl", 1)
+        lib.call("mvs_set_tuning", b"fwd_dl", 2)
         lib.call("mvs_set_tuning", b"fwd_pt", 0)
     exp = R.plane_sweep_variance(ref, srcs, [rot[:, i] for i in range(ns)], [trans[:, i] for i in range(ns)], depth)
     assert float((vols[1] - exp).abs().max()) < 2e-4
