@@ -1477,7 +1477,9 @@ static int launch_fwd(SweepArgs& a, hipStream_t st) {
         const int ppb = c16 ? TileC<C, CPT16>::PPB : (c8 ? TileC<C, CPT8>::PPB : TileC<C, 4>::PPB);
         // (round 6, 8 channels per thread: a 4-wide x 16-high pixel tile instead of 8 x 8 -- with the merged re-gather form below K1 at
         //  config 2 0.1141 -> 0.1077 ms, at N = 5 0.2034 -> 0.1945, six interleaved rounds each: profiles/r06_run18_k1_knobs.log)
-        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? 4 : TileC<C, 4>::TW));
+        //  Per-plane hypotheses at 32 channels only: with 16 channels (a 4 x 32 tile) and per-pixel hypotheses -- CVP's refine sweep at
+        //  1152 x 864 -- the narrow tile costs 0.39 -> 0.43 ms and 1.02 -> 1.50 GB of traffic (profiles/r06_final_bench_c4.json vs r06_final5_*).
+        int tw = g_sweep_tile_w > 0 ? g_sweep_tile_w : (c16 ? TileC<C, CPT16>::TW : (c8 ? ((C == 32 && !a.per_pixel) ? 4 : TileC<C, CPT8>::TW) : TileC<C, 4>::TW));
         if (tw > ppb) tw = ppb;
         while (ppb % tw) --tw;
         a.tile_w = tw;
