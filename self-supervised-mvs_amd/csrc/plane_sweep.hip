@@ -723,7 +723,10 @@ __device__ __forceinline__ float& f4r(float4& v, int c) { return c == 0 ? v.x : 
 template <int C, int CPT> struct PwCfg {
     static constexpr int LPP = C / CPT;             // lanes per pixel
     static constexpr int PPW = 64 / LPP;            // pixels per wave, as a BW x BH block
-    static constexpr int BW = PPW >= 32 ? 8 : 4, BH = PPW / BW;
+#ifndef MVS_PW_BW
+#define MVS_PW_BW 4            // width of a wave's pixel block at 8 pixels per wave (4 x 2); build-time A/B: -DMVS_PW_BW=2 (2 x 4), =8 (8 x 1)
+#endif
+    static constexpr int BW = PPW >= 32 ? 8 : MVS_PW_BW, BH = PPW / BW;
     static constexpr int V = CPT / 4;               // float4s per tap per thread
 };
 
