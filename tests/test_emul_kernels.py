@@ -1411,23 +1411,31 @@ def test_training_extractor_one_c_call_per_pass_equals_per_layer_calls(emul_lib,
     tables into two arenas) against the same node issuing the per-layer C calls from Python (ops.FEATURE_C_ENTRY = False): the same
     kernels in the same order => output, input gradient, every parameter gradient and the running statistics BIT-IDENTICAL.  With
     channels-last parameters (module.to(memory_format=torch.channels_last): what bench.py trains) the C entry reads them in place
-    (mvs_conv2d_fwd_wl / mvs_conv2d_dgrad_wl; the Python path makes a contiguous copy per layer) and writes the weight gradients in
-    the parameters' layout.  Replaces the 15 module calls of FeatureNet.forward (/root/reference/jdacs/models/mvsnet.py:17-34)."""
+    (mvs_conv2d_fwd_wl / mvs_conv2d_dgrad_wl) and writes the weight gradients in the parameters' layout.  A three-block chain (3x3, 5x5
+    stride 2, 3x3 + the closing convolution: every branch of the two entry points; the emulated one-launch weight gradient of the full
+    FeatureNet alone takes 18 s) -- the full FeatureNet through the C entry against the STOCK modules is
+    test_training_extractor_as_one_autograd_node[consumer_side_batchnorm].  Replaces the module calls of FeatureNet.forward
+    (/root/reference/jdacs/models/mvsnet.py:17-34)."""
     import copy
     from mvs_amd import ops
-    from mvs_amd.jdacs.models.mvsnet import FeatureNet, _FEATURE_LAYERS
+    from mvs_amd.jdacs.models.module import ConvBnReLU
     torch.manual_seed(7)
-    ref = FeatureNet().train()
+
+    class Chain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.b0, self.b1, self.b2 = ConvBnReLU(3, 8, 3, 1, 1), ConvBnReLU(8, 16, 5, 2, 2), ConvBnReLU(16, 16, 3, 1, 1)
+            self.feature = torch.nn.Conv2d(16, 16, 3, 1, 1)
+    ref = Chain().train()
     if channels_last_weights:
         ref = ref.to(memory_format=torch.channels_last)
     groups = 2
-    x = torch.randn(groups, 3, 12, 40).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(groups, 3, 10, 36).contiguous(memory_format=torch.channels_last)
     res = {}
     for c_entry in (True, False):
         net = copy.deepcopy(ref)
-        blocks = [getattr(net, name) for name, *_ in _FEATURE_LAYERS]
         cfg, params = [], []
-        for m in blocks:
+        for m in (net.b0, net.b1, net.b2):
             cfg.append((m.conv.stride[0], m.conv.padding[0], float(m.bn.eps), float(m.bn.momentum), m._hip_dgrad()))
             params += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
         params += [net.feature.weight, net.feature.bias]
