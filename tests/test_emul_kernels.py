@@ -487,6 +487,37 @@ def test_conv3d_smallest_volumes(emul_lib, cin, cout, stride, transposed, dims):
     assert float((gw - w.grad).abs().max()) < 3e-4 * max(1.0, float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize("b,dims,layout", [(1, (5, 6, 19), "conv"), (2, (4, 4, 16), "conv"), (1, (2, 9, 33), "transposed_forward")],
+                         ids=["ragged", "two_whole_tiles", "oik_layout_through_the_transposed_forward"])
+def test_conv0_input_gradient_split_bf16_form(emul_lib, b, dims, layout):
+    """Opt-in knob conv0_x3 (csrc/conv3d_x3.hip): the 8 -> 32 channel stride-1 convolution behind conv0's input gradient
+    (mvsnet.py:40 backward) as six bf16 MFMA products of three-term splits of the fp32 operands.  Against fp64 it must be as close
+    as the fp32-MFMA kernel (it is closer), with partial tiles, a batch, and BOTH weight layouts / tap orders the dispatcher hands
+    it (conv dgrad: [in'][out'] flipped; a transposed stride-1 forward: the same; checked against ATen in fp64)."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(sum(dims))
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) * 0.2
+    gy = torch.randn(b, 8, *dims, generator=g) * torch.rand(b, 8, *dims, generator=g).pow(4) * 10     # a wide dynamic range
+    if layout == "conv":
+        ref = torch.nn.grad.conv3d_input((b, 32, *dims), w.double(), gy.double(), padding=1)
+        run = lambda: ops.conv3d_dgrad(gy, w, (b, 32, *dims), 1, False)
+    else:     # ConvTranspose3d(8 -> 32, stride 1) forward: weight [Cin = 8][Cout = 32]
+        ref = F.conv_transpose3d(gy.double(), w.double(), stride=1, padding=1)
+        run = lambda: ops.conv3d_forward(gy, w, 1, True)[0]
+    try:
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 0)
+        base = run()
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 1)
+        got = run()
+    finally:
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    assert not torch.equal(base, got)                          # (the knob did select another kernel)
+    e0 = (base.double() - ref).abs().sum() / ref.abs().sum()
+    e1 = (got.double() - ref).abs().sum() / ref.abs().sum()
+    assert float(e1) < 1.2 * float(e0) + 1e-8 and float(e1) < 5e-7, (float(e0), float(e1))
+    assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+
+
 def test_relative_projections_one_launch(emul_lib):
     """mvs_relative_projection (all source views, fp64 Gauss-Jordan + product) vs the reference's lines
     torch.matmul(src_proj, torch.inverse(ref_proj)) per view (jdacs/models/module.py:116-118), on DTU-like cameras

@@ -775,6 +775,68 @@ def test_config2_train_step_vs_gpu_oracle(dev):
     _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet 256x320 D=96")
 
 
+@pytest.mark.parametrize("b,dims", [(1, (24, 40, 72)), (2, (5, 6, 19))], ids=["interior_tiles", "ragged_batch_2"])
+def test_conv0_input_gradient_split_bf16_form_vs_fp64(dev, b, dims):
+    """Opt-in knob conv0_x3 (csrc/conv3d_x3.hip: conv0's input gradient, mvsnet.py:40 backward, as six bf16 MFMA products of
+    three-term splits of the fp32 operands, fp32 accumulation) against autograd in fp64: at least as accurate as the default
+    fp32-MFMA kernel on the same inputs (gradients with a wide dynamic range), and inside 2e-6 of the result's scale everywhere."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) * 0.1
+    gy = torch.randn(b, 8, *dims, generator=g) * torch.rand(b, 8, *dims, generator=g).pow(4) * 10
+    ref = torch.nn.grad.conv3d_input((b, 32, *dims), w.double(), gy.double(), padding=1)
+    got = {}
+    try:
+        for knob in (0, 1):
+            lib.call("mvs_set_tuning", b"conv0_x3", knob)
+            got[knob] = ops.conv3d_dgrad(gy.to(dev), w.to(dev), (b, 32, *dims), 1, False).cpu().double()
+    finally:
+        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    assert not torch.equal(got[0], got[1])
+    e = {k: float((v - ref).abs().sum() / ref.abs().sum()) for k, v in got.items()}
+    print("conv0 input gradient, relative L1 error against fp64: fp32 MFMA %.3e, split bf16 %.3e" % (e[0], e[1]))
+    assert e[1] <= 1.05 * e[0] + 1e-9 and e[1] < 3e-7
+    assert float((got[1] - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+
+
+def test_conv0_input_gradient_split_bf16_form_at_config2_size(dev):
+    """... and at BASELINE config 2's size (1 x 192 x 128 x 160, every tile of the persistent walk) against the default kernel, plus
+    linearity in the gradient (a size-independent property of the op)."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(32)
+    w = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.1).to(dev)
+    shape = (1, 32, 192, 128, 160)
+    ga = torch.randn(1, 8, 192, 128, 160, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    gb = torch.randn(1, 8, 192, 128, 160, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    base = ops.conv3d_dgrad(ga, w, shape, 1, False)
+    try:
+        lib.call("mvs_set_tuning", b"conv0_x3", 1)
+        xa = ops.conv3d_dgrad(ga, w, shape, 1, False)
+        xb = ops.conv3d_dgrad(gb, w, shape, 1, False)
+        xab = ops.conv3d_dgrad(2.0 * ga - 0.5 * gb, w, shape, 1, False)
+    finally:
+        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    scale = float(base.abs().max())
+    assert not torch.equal(base, xa)
+    assert float((xa - base).abs().max()) < 2e-6 * scale and rel_l1(xa, base) < 1e-6
+    assert float((xab - (2.0 * xa - 0.5 * xb)).abs().max()) < 4e-6 * scale
+
+
+def test_config2_train_step_with_split_bf16_conv0_input_gradient_vs_gpu_oracle(dev):
+    """The reduced config-2 training step of test_config2_train_step_vs_gpu_oracle with the opt-in knob on: the same criteria."""
+    from mvs_amd import _lib
+    lib = _lib.get()
+    try:
+        lib.call("mvs_set_tuning", b"conv0_x3", 1)
+        net, o, oracle, r, oracle64, t = _mvsnet_train_step_three_ways(dev, 3, 256, 320, 96, 1, torch.device("cpu"))
+    finally:
+        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    assert rel_l1(o["depth"], r["depth"]) < 1e-3
+    _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet 256x320 D=96, conv0_x3=1")
+
+
 @_heavy
 def test_config2_full_size_train_step_vs_gpu_oracle(dev):
     """BASELINE configs[1] at its real size (N=3, 640x512, D=192, fp32): forward AND backward of the whole model against the
