@@ -34,6 +34,7 @@
 #include "conv_map.h"
 #include "conv_args.h"
 
+__device__ __attribute__((aligned(16))) float g_x3_zero_page[4];   // what an out-of-volume halo item loads
 int g_conv_x3 = 0;   // tuning knob "conv0_x3": bit 0 = conv0's input gradient through this file
 
 // Which tap lane group kg of k-step ks multiplies (27 = none: zero weights).  ds_read_b128 is served in four groups of 16 lanes
@@ -135,8 +136,10 @@ __global__ __launch_bounds__(256, MINW) void conv_x3_s1_8_32_kernel(ConvArgs a, 
                 const int rd = crd[k] & 255, rh = (crd[k] >> 8) & 255, rw = (crd[k] >> 16) & 255;
                 ok = id0 + rd >= 0 && id0 + rd < a.Di && ih0 + rh >= 0 && ih0 + rh < a.Hi && iw0 + rw >= 0 && iw0 + rw < a.Wi;
             }
-            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) pf[k] = *reinterpret_cast<const float4*>(xb + rel[k]);
+            // BRANCH-FREE on purpose: a load under `if (ok)` is a phi with the zero, and hipcc waits for it right there -- the first
+            // version's "prefetch" sat in front of an s_waitcnt vmcnt(0) ahead of the MFMAs, one exposed memory round trip per tile
+            const float* src = ok ? xb + rel[k] : g_x3_zero_page;
+            pf[k] = *reinterpret_cast<const float4*>(src);
         }
     };
     auto deposit = [&](const float4 (&pf)[NIT]) {
