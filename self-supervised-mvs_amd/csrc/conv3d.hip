@@ -1521,6 +1521,8 @@ bool conv_pers_serves(int geom, int cin, int cout);
 int run_conv_pers(int geom, const ConvArgs& a, hipStream_t st);
 bool conv_x3_serves(int geom, const ConvArgs& a);       // conv3d_x3.hip (knob "conv0_x3", opt-in)
 int run_conv_x3(const ConvArgs& a, const float* w, int wlayout, int flip, hipStream_t st);
+bool conv_x3_fwd_serves(int geom, const ConvArgs& a);
+int run_conv_x3_fwd(const ConvArgs& a, const float* w, int wlayout, int flip, float* ws, hipStream_t st);
 extern int g_conv_x3;
 int g_conv_xcd = 1;     // tuning knob "xcd": XCD-aware tile order in the broadcast-operand forward and the Cout == 8 weight gradient
 
@@ -1698,6 +1700,7 @@ static int run_igemm(const IgemmPlan& p, const float* in, const float* wsrc, flo
     else { a.Do = 2 * p.Di; a.Ho = 2 * p.Hi; a.Wo = 2 * p.Wi; }
     a.ntd = mvs_cdiv(a.QD, geom_tqd(geom)); a.nth = mvs_cdiv(a.QH, geom_tqh(geom)); a.ntw = mvs_cdiv(a.QW, 16);
     if ((g_conv_x3 & 1) && conv_x3_serves(geom, a)) return run_conv_x3(a, wsrc, p.wlayout, p.flip, st);   // opt-in: split-bf16 products
+    if ((g_conv_x3 & 2) && conv_x3_fwd_serves(geom, a)) return run_conv_x3_fwd(a, wsrc, p.wlayout, p.flip, ws, st);
     if (plan_is_c8(p, &ep)) {
         // 4x4x1 MFMA with the weights as the broadcast operand, tile 4 x 4 x 16 positions (reads the parameter tensor itself)
         const int ntl = B * a.ntd * a.nth * a.ntw;

@@ -35,7 +35,7 @@
 #include "conv_args.h"
 
 __device__ __attribute__((aligned(16))) float g_x3_zero_page[4];   // what an out-of-volume halo item loads
-int g_conv_x3 = 0;   // tuning knob "conv0_x3": bit 0 = conv0's input gradient through this file
+int g_conv_x3 = 0;   // tuning knob "conv0_x3": bit 0 = conv0's input gradient, bit 1 = conv0's forward through this file
 
 // Which tap lane group kg of k-step ks multiplies (27 = none: zero weights).  ds_read_b128 is served in four groups of 16 lanes
 // that MIX two lane groups of the MFMA layout ({0-3, 12-15} of kg 0 with {4-11} of kg 1, ...: MI355X_MICROARCH.md, LDS table), and a
@@ -218,6 +218,212 @@ __global__ __launch_bounds__(256, MINW) void conv_x3_s1_8_32_kernel(ConvArgs a, 
         }
         __syncthreads();     // every wave is done with the planes before the next tile's deposit
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv0's FORWARD (mvsnet.py:40: 32 -> 8 channels, stride 1) in the same arithmetic (knob bit 1): a D-MARCHING kernel.
+// Cout = 8 fills half of the MFMA's 16 rows, so TWO output depth slices share one MFMA (the bf16 inference path's GEOM_S1_DP,
+// conv3d_bf16.hip): row m = pd*8 + co; the pair (2j, 2j+1) reads the four input slices 2j-1 .. 2j+2 = "kd' 0..3", and tap
+// (kd', kh, kw) carries W[kd' - pd] for row parity pd, zero where kd' - pd is outside 0..2 (75 % of the MFMA work is real).
+// A k-step = ONE tap x all 32 input channels (lane group kg = channels 8 kg ..), so a phase of the kernel needs ONE input depth slice:
+//   * a workgroup owns an 8 x 16 (H x W) column and a segment of D and marches along D: per phase it stages one input slice of the
+//     column (10 x 18 voxels x 32 channels, every 128-byte voxel record read ONCE, halo overhead 1.4 x 1.17) as three bf16 term planes
+//     (34.5 KB), and every slice pair that has this slice among its four multiplies it by the nine (kh, kw) taps of its kd';
+//   * waves 0-1 take the EVEN pairs, waves 2-3 the ODD ones (four H rows each): pair j is live for input slices 2j .. 2j+3, the next
+//     pair of the same parity starts right after it -- every wave works in every phase and its accumulators follow one pair;
+//   * the whole three-term weight image [tap][co][32 ci] (43 KB, packed once per call by conv_x3_pack_fwd_kernel) is resident in LDS;
+//     per k-step a wave reads 3 A fragments (shared by its four rows) and 12 B fragments for 24 MFMAs;
+//   * both LDS layouts keep a 64-byte record per voxel / per (tap, co) with the four 16-byte channel-group slots XOR-swizzled by
+//     bit 2 of the record index: every ds_read_b128 lane group ({0-3, 12-15} of one kg with {4-11} of the next) is conflict-free
+//     for every alignment (checked exhaustively when the layout was chosen).
+// (The first form of this kernel staged a 4 x 4 x 16 tile in four 8-channel chunks: each chunk phase read 32 of the 128 bytes of every
+//  voxel record, its staging side alone took 0.40 ms and the kernel 0.55 ms against the fp32 form's 0.58: profiles/r06_x3_forward_attempt_*.)
+// BatchNorm statistics (sum y, sum y^2 per channel) are accumulated per lane and added to the fp64 slots once per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int X3F_TH = 8, X3F_TW = 16, X3F_RH = X3F_TH + 2, X3F_RW = X3F_TW + 2, X3F_PV = X3F_RH * X3F_RW;   // 180 voxels per input slice
+constexpr int X3F_WENT = 28 * 8;                                         // (tap, co) records; tap 27 = zeros
+
+__device__ __forceinline__ int x3_slot(int kg, int rec) { return kg ^ ((rec >> 1) & 2); }     // 16-byte slot of channel group kg in record rec
+
+// [term 3][tap 28][co 8][slot 4] x 16 bytes, swizzled as the kernel reads it
+__global__ __launch_bounds__(256) void conv_x3_pack_fwd_kernel(const float* __restrict__ w, int wlayout, int flip, uint4* __restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;         // (record, channel group)
+    if (i >= X3F_WENT * 4) return;
+    const int kg = i & 3, rec = i >> 2, co = rec & 7, tap = rec >> 3;
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = 8 * kg + j, kidx = flip ? 26 - tap : tap;
+        float v = 0.f;
+        if (tap < 27) v = wlayout == WL_OIK ? w[((size_t)co * 32 + ci) * 27 + kidx] : w[((size_t)ci * 8 + co) * 27 + kidx];
+        x3_split(v, h[j], m[j], l[j]);
+    }
+    uint4* dst = img + rec * 4 + x3_slot(kg, rec);
+    dst[0] = make_uint4(x3_pk(h[0], h[1]), x3_pk(h[2], h[3]), x3_pk(h[4], h[5]), x3_pk(h[6], h[7]));
+    dst[X3F_WENT * 4] = make_uint4(x3_pk(m[0], m[1]), x3_pk(m[2], m[3]), x3_pk(m[4], m[5]), x3_pk(m[6], m[7]));
+    dst[2 * X3F_WENT * 4] = make_uint4(x3_pk(l[0], l[1]), x3_pk(l[2], l[3]), x3_pk(l[4], l[5]), x3_pk(l[6], l[7]));
+}
+
+// grid: (column, segment) = blockIdx.x; SD = depth slices per segment (even)
+__global__ __launch_bounds__(256, 2) void conv_x3_fwd_march_kernel(ConvArgs a, const uint4* __restrict__ wimg, int nch, int ncw, int SD) {
+    constexpr int RW = X3F_RW, PV = X3F_PV;
+    constexpr int NITEMS = PV * 8, NIT = (NITEMS + 255) / 256;          // 16-byte items of one fp32 input slice of the column
+    __shared__ __attribute__((aligned(16))) uint4 plane[3][PV * 4];
+    __shared__ __attribute__((aligned(16))) uint4 wl[3][X3F_WENT * 4];
+    __shared__ float red[4 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kg = lane >> 4;
+    const int role = wv >> 1, hh = wv & 1;                // pair parity of the wave, its four rows 4 hh ..
+    int bid = blockIdx.x;
+    const int cw = bid % ncw; bid /= ncw;
+    const int ch = bid % nch; bid /= nch;
+    const int nseg = (a.Di + SD - 1) / SD;
+    const int seg = bid % nseg, b = bid / nseg;
+    const int d0 = seg * SD, d1 = d0 + SD < a.Di ? d0 + SD : a.Di;
+    const int npairs = (d1 - d0 + 1) >> 1;
+    const int h0 = ch * X3F_TH, w0 = cw * X3F_TW;
+
+    // ---- the weight image -> LDS (once) ----
+    for (int i = tid; i < 3 * X3F_WENT * 4; i += 256) (&wl[0][0])[i] = wimg[i];
+
+    // A: row m = lane & 15 = (pd, co)
+    const int pdA = n >> 3, coA = n & 7;
+    const int slotA = x3_slot(kg, coA);                  // record (tap*8 + co): bit 2 of it is bit 2 of co
+    // B: voxel (row 4 hh + r + kh, column n + kw)
+    const int vb0 = (4 * hh) * RW + n;
+
+    // ---- staging items: (voxel, 16-byte part) -- 8 consecutive lanes read one voxel's whole 128-byte record ----
+    int rel[NIT], dst[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k, vox = i >> 3, part = i & 7;
+        const int rw = vox % RW, rh = vox / RW;
+        const bool in = i < NITEMS && h0 - 1 + rh >= 0 && h0 - 1 + rh < a.Hi && w0 - 1 + rw >= 0 && w0 - 1 + rw < a.Wi;
+        rel[k] = in ? (((h0 - 1 + rh) * a.Wi + (w0 - 1 + rw)) * 32 + 4 * part) : -1;
+        dst[k] = i < NITEMS ? (vox * 4 + x3_slot(part >> 1, vox)) * 2 + (part & 1) : -1;      // uint2 index inside a term plane
+    }
+    float4 pf[NIT];
+    auto request = [&](int p) {                           // input slice d0 - 1 + p
+        const int din = d0 - 1 + p;
+        const bool ind = din >= 0 && din < a.Di;
+        const float* __restrict__ xb = a.x + ((size_t)b * a.Di + (ind ? din : 0)) * a.Hi * a.Wi * 32;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const float* src = (ind && rel[k] >= 0) ? xb + rel[k] : g_x3_zero_page;       // branch-free
+            pf[k] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (dst[k] < 0) continue;
+            unsigned h[4], m[4], l[4];
+            x3_split(pf[k].x, h[0], m[0], l[0]); x3_split(pf[k].y, h[1], m[1], l[1]);
+            x3_split(pf[k].z, h[2], m[2], l[2]); x3_split(pf[k].w, h[3], m[3], l[3]);
+            uint2 qh, qm, ql;
+            qh.x = x3_pk(h[0], h[1]); qh.y = x3_pk(h[2], h[3]);
+            qm.x = x3_pk(m[0], m[1]); qm.y = x3_pk(m[2], m[3]);
+            ql.x = x3_pk(l[0], l[1]); ql.y = x3_pk(l[2], l[3]);
+            reinterpret_cast<uint2*>(&plane[0][0])[dst[k]] = qh;
+            reinterpret_cast<uint2*>(&plane[1][0])[dst[k]] = qm;
+            reinterpret_cast<uint2*>(&plane[2][0])[dst[k]] = ql;
+        }
+    };
+
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};     // statistics of channels 4 (kg & 1) + e
+    f32x4 acc[4], acs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acs[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nplanes = 2 * npairs + 2;
+    request(0);
+#pragma unroll 1
+    for (int p = 0; p < nplanes; ++p) {
+        deposit();
+        __syncthreads();
+        if (p + 1 < nplanes) request(p + 1);              // in flight under this phase's MFMAs
+        // the wave's pair and which of its four input slices this is
+        const int q = p - 2 * role;
+        const int j = 2 * (q >> 2) + role, kdp = q & 3;
+        if (q >= 0 && j < npairs) {                       // wave-uniform
+            const int kd = kdp - pdA;
+            const bool av = kd >= 0 && kd <= 2;
+            const int abase = ((av ? kd * 9 : 27) * 8 + coA) * 4 + slotA, astep = av ? 32 : 0;      // uint4 units; + ks * astep
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                mvs_bf16x8 at[3], bt[4][3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) at[t] = *reinterpret_cast<const mvs_bf16x8*>(&wl[t][abase + ks * astep]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = vb0 + (r + ks / 3) * RW + ks % 3;
+                    const int o = v * 4 + x3_slot(kg, v);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bt[r][t] = *reinterpret_cast<const mvs_bf16x8*>(&plane[t][o]);
+                }
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q6 = 0; q6 < 6; ++q6)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (q6 < 5) acs[r] = MVS_MFMA_16x16x32_BF16(at[PA[q6]], bt[r][PB[q6]], acs[r]);
+                        else acc[r] = MVS_MFMA_16x16x32_BF16(at[PA[q6]], bt[r][PB[q6]], acc[r]);
+                    }
+            }
+            if (kdp == 3) {
+                // ---- the pair is complete: lane (n, kg) holds channels 4 (kg & 1) .. + 3 of slice d0 + 2 j + (kg >> 1), rows 4 hh + r ----
+                const int qd = d0 + 2 * j + (kg >> 1), qw = w0 + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qh = h0 + 4 * hh + r;
+                    const float4 o = make_float4(acc[r][0] + acs[r][0], acc[r][1] + acs[r][1], acc[r][2] + acs[r][2], acc[r][3] + acs[r][3]);
+                    acc[r] = acs[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (qd >= d1 || qh >= a.Ho || qw >= a.Wo) continue;
+                    *reinterpret_cast<float4*>(a.y + ((((size_t)b * a.Do + qd) * a.Ho + qh) * a.Wo + qw) * 8 + 4 * (kg & 1)) = o;
+                    s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
+                    s2[0] += o.x * o.x; s2[1] += o.y * o.y; s2[2] += o.z * o.z; s2[3] += o.w * o.w;
+                }
+            }
+        }
+        __syncthreads();     // every wave is done with the slice before the next deposit
+    }
+    if (a.slots) {
+        // lanes that share (kg & 1) hold the same four channels: sum over n (16 lanes) and over the slice parity (kg >> 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int msk = 1; msk <= 8; msk <<= 1) { s1[e] += __shfl_xor(s1[e], msk); s2[e] += __shfl_xor(s2[e], msk); }
+            s1[e] += __shfl_xor(s1[e], 32); s2[e] += __shfl_xor(s2[e], 32);
+        }
+        if (n == 0 && kg < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[wv * 16 + 4 * kg + e] = s1[e]; red[wv * 16 + 8 + 4 * kg + e] = s2[e]; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int stat = tid >> 3, co = tid & 7;
+            MVS_GLOBAL_ATOMIC_ADD_F64(a.slots + ((size_t)(blockIdx.x & (a.nslots - 1)) * 2 + stat) * a.Cout + co,
+                                      (double)(red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid]));
+        }
+    }
+}
+
+bool conv_x3_fwd_serves(int geom, const ConvArgs& a) {
+    return geom == GEOM_S1 && a.Cin == 32 && a.Cout == 8 && !a.scale && !a.shift && !a.skip && !a.bn_raw && !a.relu;
+}
+
+// ws: the op's weight workspace (mvs_conv3d_workspace_bytes: 55 KB for this layer, unused by the default 4x4x1-MFMA forward)
+int run_conv_x3_fwd(const ConvArgs& a, const float* w, int wlayout, int flip, float* ws, hipStream_t st) {
+    uint4* img = reinterpret_cast<uint4*>(ws);
+    MVS_LAUNCH(conv_x3_pack_fwd_kernel, dim3(mvs_cdiv(X3F_WENT * 4, 256)), dim3(256), 0, st, w, wlayout, flip, img);
+    const int nch = mvs_cdiv(a.Hi, X3F_TH), ncw = mvs_cdiv(a.Wi, X3F_TW), ncol = a.B * nch * ncw;
+    int nseg = mvs_cdiv(2560, ncol);                      // ~5 rounds of 2 x 256 resident workgroups
+    if (nseg > a.Di / 4) nseg = a.Di / 4;
+    if (nseg < 1) nseg = 1;
+    int SD = mvs_cdiv(a.Di, nseg);
+    SD += SD & 1;
+    nseg = mvs_cdiv(a.Di, SD);
+    MVS_LAUNCH(conv_x3_fwd_march_kernel, dim3(ncol * nseg), dim3(256), 0, st, a, (const uint4*)img, nch, ncw, SD);
+    return mvs_check_launch("conv_x3_fwd_march");
 }
 
 bool conv_x3_serves(int geom, const ConvArgs& a) {

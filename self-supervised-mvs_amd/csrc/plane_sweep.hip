@@ -1422,7 +1422,7 @@ static const MvsKnob* mvs_find_knob(const char* key) {
         {"conv_split", &g_conv_split, 0, 1}, {"conv_small", &g_conv_small, 0, 2}, {"conv_small_wgs", &g_conv_small_wgs, 0, 1 << 20}, {"tr2pw", &g_conv_tr2pw, 0, 1}, {"cc_wide", &g_conv_cc_wide, 0, 1}, {"cin1_vpt", &g_conv_cin1_vpt, 1, 5}, {"k8", &g_conv_c8, 0, 15},             {"cout1_d4", &g_conv_cout1_d4, 0, 3}, {"bf16_dp", &g_conv_bf16_dp, 0, 1}, {"conv2d_pp", &g_conv2d_pp, 0, 1},
         {"wgrad2d_groups", &g_conv2d_wgrad_groups, 0, 1 << 20}, {"wgrad2d_batch", &g_conv2d_wgrad_batch_groups, 1, 4096},                     {"conv2d_s2_mfma", &g_conv2d_s2_mfma, 0, 2},
         {"xcd", &g_conv_xcd, 0, 1}, {"side_pre", &g_conv_side_pre, 0, 1}, {"conv_pers", &g_conv_pers, 0, 1}, {"conv_pers_min", &g_conv_pers_min_wgs, 0, 1 << 30}, {"conv_pers_groups", &g_conv_pers_groups, 0, 4096}, {"conv_pers_nw", &g_conv_pers_nw, 4, 8}, {"wgrad_pers", &g_conv_wgrad_pers, 0, 1}, {"wgrad_small", &g_conv_wgrad_small, 0, 3}, {"wgrad_groups", &g_conv_wgrad_groups, 1, 768}, {"wgrad8_groups", &g_conv_wgrad8_groups, 1, 512}, {"wgrad8_gs", &g_conv_wgrad8_gs, 0, 2}, {"wgrad8_nch", &g_conv_wgrad8_nch, 1, 2}, {"cout1_h4", &g_conv_cout1_h4, 0, 1},          {"sweep_fwd", &g_sweep_fwd_variant, 0, 4}, {"sweep_bwd", &g_sweep_bwd_variant, 0, 1},
-        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"bwd_gd34", &g_sweep_bwd_gd34, 0, 1}, {"fwd_pt", &g_sweep_fwd_pt, 0, 1}, {"bwd_gpf", &g_sweep_bwd_gpf, 0, 1}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1}, {"conv0_x3", &g_conv_x3, 0, 1},
+        {"bwd_dslab", &g_sweep_bwd_dslab, 0, 1 << 20}, {"bwd_nowin", &g_sweep_bwd_nowin, 0, 1}, {"bwd_cpt", &g_sweep_bwd_cpt, 4, 8}, {"bwd_pf", &g_sweep_bwd_pf, 0, 2}, {"bwd_gd", &g_sweep_bwd_gd, 0, 2}, {"bwd_gd34", &g_sweep_bwd_gd34, 0, 1}, {"fwd_pt", &g_sweep_fwd_pt, 0, 1}, {"bwd_gpf", &g_sweep_bwd_gpf, 0, 1}, {"fwd_dl", &g_sweep_fwd_dl, 0, 2}, {"sweep_xcd", &g_sweep_xcd, 0, 1}, {"conv0_x3", &g_conv_x3, 0, 3},
     };
     for (const MvsKnob& k : knobs)
         if (strcmp(key, k.name) == 0) return &k;

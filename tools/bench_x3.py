@@ -51,6 +51,26 @@ def main():
         lib.call("mvs_set_tuning", b"conv0_x3", knob)
         med, mn = timeit(lambda: ops.conv3d_dgrad(x8, w0, (1, 32, D, H, W), 1, False))
         print("conv0_x3=%d  conv0 dgrad 1x192x128x160: median %.4f ms  min %.4f ms" % (knob, med, mn))
+    # ---- forward (knob bit 1) ----
+    import torch.nn.functional as F
+    D, H, W = 48, 64, 80
+    xs = (torch.randn(1, 32, D, H, W, generator=g) * torch.rand(1, 32, D, H, W, generator=g).pow(4) * 10).to(dev).contiguous(memory_format=cl)
+    ref = F.conv3d(xs.double().cpu(), w0.double().cpu(), padding=1).to(dev)
+    for knob in (0, 2):
+        lib.call("mvs_set_tuning", b"conv0_x3", knob)
+        out, slots = ops.conv3d_forward(xs, w0, 1, False, want_stats=True)
+        e = (out.double() - ref).abs()
+        st = slots.sum(0)
+        print("conv0_x3=%d  forward error vs fp64: max abs %.3e (scale %.1f), relative L1 %.3e; statistics: sum %.2e, sum of squares %.2e (relative)" % (
+            knob, e.max().item(), ref.abs().max().item(), (e.sum() / ref.abs().sum()).item(),
+            ((st[0] - ref.sum((0, 2, 3, 4))).abs() / ref.abs().sum((0, 2, 3, 4))).max().item(),
+            ((st[1] - ref.pow(2).sum((0, 2, 3, 4))).abs() / ref.pow(2).sum((0, 2, 3, 4))).max().item()))
+    D, H, W = 192, 128, 160
+    x32 = torch.randn(1, 32, D, H, W, generator=g).to(dev).contiguous(memory_format=cl)
+    for knob in (0, 2, 0, 2):
+        lib.call("mvs_set_tuning", b"conv0_x3", knob)
+        med, mn = timeit(lambda: ops.conv3d_forward(x32, w0, 1, False, want_stats=True))
+        print("conv0_x3=%d  conv0 forward (+statistics) 1x192x128x160: median %.4f ms  min %.4f ms" % (knob, med, mn))
     lib.call("mvs_set_tuning", b"conv0_x3", 1)
     x8s = x8[:, :, :4].contiguous(memory_format=cl)
     med, mn = timeit(lambda: ops.conv3d_dgrad(x8s, w0, (1, 32, 4, H, W), 1, False))
