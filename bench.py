@@ -762,10 +762,10 @@ def main():
         _ops.set_async_wgrad(True, defer_join=True)
     ms_split_bf16 = None
     if train and not graph_mode:
-        # OPT-IN arithmetic (knob conv0_x3, csrc/conv3d_x3.hip), never the headline: conv0's input gradient on the bf16 MFMA with every
-        # fp32 operand split into three bf16 terms (six exact products per fp32 product, fp32 accumulation; measured error against
-        # fp64 BELOW the fp32-MFMA kernel's: tests/test_gpu_parity.py::test_conv0_input_gradient_split_bf16_form_vs_fp64)
-        lib.call("mvs_set_tuning", b"conv0_x3", 1)
+        # OPT-IN arithmetic (knob conv0_x3 = 3, csrc/conv3d_x3.hip), never the headline: conv0's forward and input gradient on the bf16
+        # MFMA with every fp32 operand split into three bf16 terms (six exact products per fp32 product, fp32 accumulation; measured
+        # error against fp64 BELOW the fp32-MFMA kernels': tests/test_gpu_parity.py::test_conv0_*_split_bf16_form_vs_fp64)
+        lib.call("mvs_set_tuning", b"conv0_x3", 3)
         for _ in range(2):
             step()
         barrier()
@@ -1048,10 +1048,11 @@ def main():
             ("ms_per_step_async_wgrad_off" if async_wgrad else "ms_per_step_async_wgrad_on"): ms_other_mode,
             "ms_per_step_library_default": (ms_library_default if (async_wgrad and defer_join) else (dt / args.steps * 1e3 if async_wgrad else ms_other_mode)) if train else None,
             "ms_per_step_join_inside_regulariser_node": ms_join_in_node,
-            "ms_per_step_opt_in_split_bf16_conv0_dgrad": ms_split_bf16,
-            "opt_in_split_bf16_is": "the same K steps with mvs_set_tuning('conv0_x3', 1): conv0's input gradient as six bf16 MFMA products "
-                                    "of three-term splits of the fp32 operands, fp32 accumulation (csrc/conv3d_x3.hip). NOT the headline and "
-                                    "not the default: `value`, `ms_per_step` and `dtype` are the all-fp32-MFMA step" if ms_split_bf16 else None,
+            "ms_per_step_opt_in_split_bf16_conv0": ms_split_bf16,
+            "opt_in_split_bf16_is": "the same K steps with mvs_set_tuning('conv0_x3', 3): conv0's forward and input gradient as six bf16 MFMA "
+                                    "products of three-term splits of the fp32 operands, fp32 accumulation (csrc/conv3d_x3.hip; its weight "
+                                    "gradient stays on the fp32 MFMA). NOT the headline and not the default: `value`, `ms_per_step` and `dtype` "
+                                    "are the all-fp32-MFMA step" if ms_split_bf16 else None,
             "library_default_is": "MVS_ASYNC_WGRAD unset, no set_async_wgrad call: side-stream weight gradients, joined by MVSNet's tail node at the "
                                   "end of the backward pass (MVS_TAIL_JOIN=0: inside the regulariser node, rounds 3-5)",
             "grad_bucket_bytes": bucket.nbytes if bucket is not None else 0,

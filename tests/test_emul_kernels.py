@@ -518,6 +518,33 @@ def test_conv0_input_gradient_split_bf16_form(emul_lib, b, dims, layout):
     assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("b,dims", [(1, (5, 6, 19)), (2, (4, 9, 16)), (1, (3, 17, 5))], ids=["ragged", "batch_2_two_columns", "odd_depth_three_columns"])
+def test_conv0_forward_split_bf16_form(emul_lib, b, dims):
+    """Opt-in knob conv0_x3 bit 1 (csrc/conv3d_x3.hip: conv_x3_fwd_march_kernel): conv0's forward (mvsnet.py:40, 32 -> 8 channels) as
+    split-bf16 products, marching along D with two output slices per MFMA.  Output and fused BatchNorm statistics against ATen in fp64:
+    as close as the fp32-MFMA kernel; odd depth (a half-filled last pair), partial columns, a batch."""
+    from mvs_amd import ops
+    g = torch.Generator().manual_seed(sum(dims))
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) * 0.2
+    x = torch.randn(b, 32, *dims, generator=g) * torch.rand(b, 32, *dims, generator=g).pow(4) * 10
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    try:
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 0)
+        base, _ = ops.conv3d_forward(x, w, 1, False, want_stats=True)
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 2)
+        got, slots = ops.conv3d_forward(x, w, 1, False, want_stats=True)
+    finally:
+        emul_lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    assert not torch.equal(base, got)
+    e0 = (base.double() - ref).abs().sum() / ref.abs().sum()
+    e1 = (got.double() - ref).abs().sum() / ref.abs().sum()
+    assert float(e1) < 1.2 * float(e0) + 1e-8 and float(e1) < 6e-7, (float(e0), float(e1))
+    assert float((got.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    st = slots.sum(0)
+    assert float(((st[0] - ref.sum((0, 2, 3, 4))).abs() / ref.abs().sum((0, 2, 3, 4))).max()) < 1e-6
+    assert float(((st[1] - ref.pow(2).sum((0, 2, 3, 4))).abs() / ref.pow(2).sum((0, 2, 3, 4))).max()) < 1e-6
+
+
 def test_relative_projections_one_launch(emul_lib):
     """mvs_relative_projection (all source views, fp64 Gauss-Jordan + product) vs the reference's lines
     torch.matmul(src_proj, torch.inverse(ref_proj)) per view (jdacs/models/module.py:116-118), on DTU-like cameras

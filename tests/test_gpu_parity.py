@@ -824,17 +824,71 @@ def test_conv0_input_gradient_split_bf16_form_at_config2_size(dev):
     assert float((xab - (2.0 * xa - 0.5 * xb)).abs().max()) < 4e-6 * scale
 
 
+@pytest.mark.parametrize("b,dims", [(1, (24, 40, 72)), (2, (5, 6, 19))], ids=["interior_columns", "ragged_batch_2_odd_depth"])
+def test_conv0_forward_split_bf16_form_vs_fp64(dev, b, dims):
+    """Opt-in knob conv0_x3 bit 1: conv0's forward (32 -> 8, the D-marching split-bf16 kernel) with its fused BatchNorm statistics
+    against ATen in fp64 (CPU): at least as accurate as the default fp32-MFMA kernel on the same inputs."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(33)
+    w = torch.randn(8, 32, 3, 3, 3, generator=g) * 0.1
+    x = torch.randn(b, 32, *dims, generator=g) * torch.rand(b, 32, *dims, generator=g).pow(4) * 10
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    got, stats = {}, {}
+    try:
+        for knob in (0, 2):
+            lib.call("mvs_set_tuning", b"conv0_x3", knob)
+            y, slots = ops.conv3d_forward(x.to(dev), w.to(dev), 1, False, want_stats=True)
+            got[knob], stats[knob] = y.cpu().double(), slots.sum(0).cpu()
+    finally:
+        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    assert not torch.equal(got[0], got[2])
+    e = {k: float((v - ref).abs().sum() / ref.abs().sum()) for k, v in got.items()}
+    print("conv0 forward, relative L1 error against fp64: fp32 MFMA %.3e, split bf16 %.3e" % (e[0], e[2]))
+    assert e[2] <= 1.05 * e[0] + 1e-9 and e[2] < 4e-7
+    assert float((got[2] - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    assert float(((stats[2][0] - ref.sum((0, 2, 3, 4))).abs() / ref.abs().sum((0, 2, 3, 4))).max()) < 1e-6
+    assert float(((stats[2][1] - ref.pow(2).sum((0, 2, 3, 4))).abs() / ref.pow(2).sum((0, 2, 3, 4))).max()) < 1e-6
+
+
+def test_conv0_forward_split_bf16_form_at_config2_size(dev):
+    """... and at BASELINE config 2's size (1 x 32 x 192 x 128 x 160: 160 columns x 16 depth segments) against the default kernel:
+    output, statistics, and linearity in the input."""
+    from mvs_amd import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(34)
+    w = (torch.randn(8, 32, 3, 3, 3, generator=g) * 0.1).to(dev)
+    xa = torch.randn(1, 32, 192, 128, 160, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    xb = torch.randn(1, 32, 192, 128, 160, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    base, s0 = ops.conv3d_forward(xa, w, 1, False, want_stats=True)
+    try:
+        lib.call("mvs_set_tuning", b"conv0_x3", 2)
+        ya, s1 = ops.conv3d_forward(xa, w, 1, False, want_stats=True)
+        yb, _ = ops.conv3d_forward(xb, w, 1, False)
+        yab, _ = ops.conv3d_forward(2.0 * xa - 0.5 * xb, w, 1, False)
+    finally:
+        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+    scale = float(base.abs().max())
+    assert not torch.equal(base, ya)
+    assert float((ya - base).abs().max()) < 3e-6 * scale and rel_l1(ya, base) < 1e-6
+    assert float((yab - (2.0 * ya - 0.5 * yb)).abs().max()) < 6e-6 * scale
+    t0, t1 = s0.sum(0), s1.sum(0)
+    l1 = base.double().abs().sum((0, 2, 3, 4))       # (the channel sums of random data nearly cancel: their yardstick is sum |y|)
+    assert float(((t1[0] - t0[0]).abs() / l1).max()) < 1e-7 and float(((t1[1] - t0[1]).abs() / t0[1]).max()) < 1e-6
+
+
 def test_config2_train_step_with_split_bf16_conv0_input_gradient_vs_gpu_oracle(dev):
-    """The reduced config-2 training step of test_config2_train_step_vs_gpu_oracle with the opt-in knob on: the same criteria."""
+    """The reduced config-2 training step of test_config2_train_step_vs_gpu_oracle with the opt-in knob on (forward AND input
+    gradient of conv0 as split-bf16 products): the same criteria."""
     from mvs_amd import _lib
     lib = _lib.get()
     try:
-        lib.call("mvs_set_tuning", b"conv0_x3", 1)
+        lib.call("mvs_set_tuning", b"conv0_x3", 3)
         net, o, oracle, r, oracle64, t = _mvsnet_train_step_three_ways(dev, 3, 256, 320, 96, 1, torch.device("cpu"))
     finally:
         lib.call("mvs_set_tuning", b"conv0_x3", 0)
     assert rel_l1(o["depth"], r["depth"]) < 1e-3
-    _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet 256x320 D=96, conv0_x3=1")
+    _check_param_grads(net, oracle, oracle64, ("prob.bias",), "MVSNet 256x320 D=96, conv0_x3=3")
 
 
 @_heavy
