@@ -765,6 +765,9 @@ def main():
         # OPT-IN arithmetic (knob conv0_x3 = 3, csrc/conv3d_x3.hip), never the headline: conv0's forward and input gradient on the bf16
         # MFMA with every fp32 operand split into three bf16 terms (six exact products per fp32 product, fp32 accumulation; measured
         # error against fp64 BELOW the fp32-MFMA kernels': tests/test_gpu_parity.py::test_conv0_*_split_bf16_form_vs_fp64)
+        import ctypes as _ct
+        x3_before = _ct.c_int(0)
+        lib.call("mvs_get_tuning", b"conv0_x3", _ct.byref(x3_before))
         lib.call("mvs_set_tuning", b"conv0_x3", 3)
         for _ in range(2):
             step()
@@ -777,7 +780,7 @@ def main():
         if world > 1:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ms_split_bf16 = float(tm.item()) / args.steps * 1e3
-        lib.call("mvs_set_tuning", b"conv0_x3", 0)
+        lib.call("mvs_set_tuning", b"conv0_x3", int(x3_before.value))
     ms_join_in_node = None
     if train and not graph_mode and async_wgrad and not defer_join and _ops.TAIL_JOIN:
         # what the library default was in rounds 3-5 (MVS_TAIL_JOIN=0): the side stream joined INSIDE the regulariser node
