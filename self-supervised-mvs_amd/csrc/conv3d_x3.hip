@@ -1,5 +1,7 @@
-// OPT-IN (knob "conv0_x3", default 0): conv0's input gradient (mvsnet.py:40 backward: 8 -> 32 channels, stride 1, 192x128x160 at
-// BASELINE config 2) on the bf16 MFMA with fp32 operands SPLIT into three bf16 terms each ("bf16x3"), fp32 accumulation.
+// OPT-IN (knob "conv0_x3", default 0; bit 0 = input gradient, bit 1 = forward): conv0 of the regulariser (mvsnet.py:40: 32 -> 8
+// channels, stride 1, 192x128x160 at BASELINE config 2) on the bf16 MFMA with fp32 operands SPLIT into three bf16 terms each
+// ("bf16x3"), fp32 accumulation.  This header describes the arithmetic and the INPUT-GRADIENT kernel (8 -> 32 channels); the forward
+// kernel (a D-marching kernel, further down) has its own.  Step at config 2: 4.69 ms default, 4.48 with either kernel, 4.28 with both.
 //
 // Why: the fp32 MFMA rate of gfx950 (157 TFLOP/s) is what bounds conv0's three kernels (1.7 of the step's 4.7 ms, 56-65 % of that
 // peak); v_mfma_f32_16x16x32_bf16 runs at 16x that rate.  An fp32 number is EXACTLY the sum of three bf16 numbers
